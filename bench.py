@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- whole-slide tiled inference throughput (tiles/s) on N MI355X of one node.
+
+A "step" is one pass of the hot path over one synthetic slide already resident in HBM:
+  PI2D gather + normalise -> UNet forward (all classes) -> fp16-compat stitch  [-> halo exchange + RCCL all-gather, N>1].
+Default workload (``wsi-synth256``): BASELINE.json's metric tile (256x256x2, v2 graph, duo widths 36..1152, seeded
+weights) on a 2-channel synthetic slide of 2048*N x 16384 px -- each rank holds a 2048-row band, so per-GPU work is
+fixed ("weak") and N=8 is exactly the 16384 x 16384 slide of the north star (86 x 86 = 7396 tiles).
+Other workloads (parity-test configs of BASELINE.json, not the headline): solo-1024, duo-4096, legacy-105.
+
+Prints ONE JSON line on rank 0.  Launch: `python bench.py` (N=1) or
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (model key, channels in image, band rows per GPU, cols)
+    "wsi-synth256": ("synthetic-256", 2, 2048, 16384),
+    "solo-1024": ("nucleiDAPI1-5", 1, 1024, 1024),
+    "duo-4096": ("nucleiDAPILAMIN", 2, 4096, 4096),
+    "legacy-1024": ("nucleiDAPI", 1, 1024, 1024),
+}
+
+
+def synth_rows(torch, C, row0, rows, W, device):
+    """Deterministic synthetic slide content for image rows [row0, row0+rows): smooth structure + hashed noise in
+    [0, 0.983] (what the driver's rescale_intensity produces), float64 [C, rows, W].  Any rank can generate any rows."""
+    y = torch.arange(row0, row0 + rows, device=device, dtype=torch.float64)[None, :, None]
+    x = torch.arange(W, device=device, dtype=torch.float64)[None, None, :]
+    c = torch.arange(C, device=device, dtype=torch.float64)[:, None, None]
+    base = 0.22 + 0.18 * torch.sin(y / 37.0 + c) * torch.cos(x / 53.0) + 0.1 * torch.sin((x + 2 * y) / 11.0 + 2 * c)
+    h = torch.frac(torch.sin(x * 12.9898 + y * 78.233 + c * 37.719) * 43758.5453)
+    return torch.clamp(base + 0.12 * h, 0.0, 0.983).contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="wsi-synth256", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=64, help="tiles per UNet launch group")
+    ap.add_argument("--band-rows", type=int, default=0, help="override rows per GPU")
+    ap.add_argument("--cols", type=int, default=0, help="override slide width")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-layer table to stderr")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from unmicst_amd import model, sharding, umx
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world),
+                  file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a MI355X (there is no CPU fallback)", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    key, C_img, band_rows, W = WORKLOADS[args.workload]
+    band_rows = args.band_rows or band_rows
+    W = args.cols or W
+    hp = model.KNOWN_HP[key]
+    blob = model.random_blob(hp, seed=20260101)
+    mean, std = {"synthetic-256": (0.18, 0.17), "nucleiDAPI1-5": (0.34, 0.25), "nucleiDAPILAMIN": (0.18, 0.17),
+                 "nucleiDAPI": (0.19808, 0.16236)}[key]
+    H = band_rows * world
+
+    eng = umx.Engine(hp, blob, device=local_rank, max_batch=args.batch)
+    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    npr, npc, _, _ = eng.tile_grid(H, W)
+    tiles_total = npr * npc
+    margin = hp.margin
+    sub = hp.imSize - 2 * margin
+    pa, pb = sharding.band_partition(npr, world)[rank]
+    r0, r1 = sharding.needed_image_rows(pa, pb, sub, margin, hp.imSize, H)
+    band = synth_rows(torch, C_img, r0, max(r1 - r0, 1), W, dev)   # resident in HBM before the timed region
+    out_full = torch.empty((hp.nClasses, H, W), dtype=torch.float16, device=dev) if world == 1 else None
+
+    def step():
+        if world == 1:
+            eng.infer_image_dev(band.data_ptr(), C_img, H, W, mean, std, umx.MODE_ACCUMULATE, umx.STITCH_FP16_COMPAT,
+                                out_full.data_ptr())
+            return out_full
+        return sharding.infer_image_sharded(eng, band, r0, H, W, mean, std, umx.MODE_ACCUMULATE,
+                                            umx.STITCH_FP16_COMPAT)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    checksum = float(res.float().mean().item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = tiles_total * args.steps / elapsed
+        # ---- roofline of the dominant kernel (largest share of the timed region), from the in-library HIP events
+        convs = [p for p in prof if p["kernel"].startswith("conv_mfma")]
+        dom = max(convs, key=lambda p: p["total_ms"])
+        dom_tflops = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+        all_flops = sum(p["flops"] for p in convs)
+        all_ms = sum(p["total_ms"] for p in convs)
+        roofline = {
+            "bound": "mfma", "achieved": round(dom_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(dom_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": dom["kernel"], "layer": dom["name"],
+            "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
+            "flop_per_launch": dom["flops"] / dom["launches"],
+            "all_conv_launches": {"achieved": round(all_flops / (all_ms * 1e-3) / 1e12, 2),
+                                  "frac": round(all_flops / (all_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                  "share_of_step": round(all_ms / (1e3 * elapsed), 4)},
+        }
+        if args.breakdown:
+            print("%-24s %-30s %8s %10s %9s %9s" % ("layer", "kernel", "launches", "total_ms", "TFLOP/s", "GB/s"),
+                  file=sys.stderr)
+            for p in sorted(prof, key=lambda p: -p["total_ms"]):
+                s = p["total_ms"] * 1e-3
+                print("%-24s %-30s %8d %10.3f %9.2f %9.1f" % (p["name"], p["kernel"], p["launches"], p["total_ms"],
+                                                              p["flops"] / s / 1e12, p["bytes"] / s / 1e9),
+                      file=sys.stderr)
+        cpu = None
+        if world == 1 and args.cpu_seconds > 0:
+            cpu = cpu_baseline(hp, blob, band, mean, std, args.cpu_seconds)
+        line = {
+            "metric": "tiles/sec (%dx%dx%d) whole-slide inference" % (hp.imSize, hp.imSize, hp.nChannels),
+            "value": round(value, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %s hp (%s graph, seeded weights), %d-channel synthetic slide %dx%d, "
+                                   "%d tiles/step, batch %d, fp16-compat stitch%s" % (
+                                       args.workload, key, "v2" if hp.graph else "legacy", C_img, H, W, tiles_total,
+                                       args.batch, ", band halo exchange + RCCL all-gather" if world > 1 else ""),
+                       "tiles_per_step": tiles_total, "slide": [H, W], "flop_per_tile_as_written": hp.flops_per_tile(),
+                       "flop_per_tile_executed_unpadded": umx.describe(hp)["flops_per_tile"], "checksum": checksum},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(hp, blob, band, mean, std, budget_s):
+    """The oracle (C restatement, OpenMP on every host core) on a bounded sample of the same workload's tiles."""
+    from oracle import oracle, pi2d_oracle
+    P, m = hp.imSize, hp.margin
+    sub = P - 2 * m
+    rows = min(band.shape[1], 2 * sub + 2 * m)
+    cols = min(band.shape[2], 8 * sub + 2 * m)
+    crop = band[:, :rows, :cols].cpu().numpy()
+    if hp.nChannels == 1:
+        crop = crop[0]
+    pi = pi2d_oracle.PI2DOracle(crop, P, m, "accumulate")
+    x1 = pi2d_oracle.normalised_batch(pi, 0, 1, hp.nChannels, mean, std, False)
+    t = time.perf_counter()
+    oracle.forward(hp, blob, x1)
+    per_tile = max(time.perf_counter() - t, 1e-4)
+    n = int(max(1, min(pi.num_patches, budget_s / per_tile)))
+    t = time.perf_counter()
+    done = 0
+    while done < n:
+        nb = min(4, n - done)
+        oracle.forward(hp, blob, pi2d_oracle.normalised_batch(pi, done, nb, hp.nChannels, mean, std, False))
+        done += nb
+    dt = time.perf_counter() - t
+    return {"value": round(n / dt, 3), "unit": "tiles/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": "first %d tiles of the same slide (PI2D gather+normalise + UNet forward, oracle/unet_oracle.c, "
+                      "double-accumulate fp32, OpenMP), %.1f s" % (n, dt)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,136 @@
+/*
+ * umx.h -- C ABI of the MI355X-native UnMicst inference engine (libumx.so).
+ *
+ * The reference (HMS-IDAC/UnMicst) has no FFI layer: its hot path sits behind three static methods of a
+ * Python namespace-class and one TensorFlow call.  Each entry point below names the reference interface it
+ * replaces (file:line relative to the reference tree).  Conventions: every function returns 0 on success and a
+ * non-zero umx_status otherwise (no exceptions cross the ABI); umx_last_error() gives the message; the caller
+ * owns every buffer it passes; a ctx owns its device memory and stream; one ctx per host thread (a ctx is not
+ * thread-safe, the library is re-entrant across ctxs).  "_dev" variants take DEVICE pointers and only enqueue
+ * work on the ctx stream (call umx_synchronize); the plain variants take HOST pointers and are synchronous.
+ * There is no CPU fallback: every compute entry point fails with UMX_ERR_NO_DEVICE without a gfx950 GPU.
+ */
+#ifndef UMX_H
+#define UMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define UMX_API __attribute__((visibility("default")))
+#else
+#define UMX_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct umx_ctx umx_ctx;
+
+enum umx_status {
+    UMX_OK = 0,
+    UMX_ERR_INVALID = 1,     /* bad argument / unsupported hyper-parameters */
+    UMX_ERR_BLOB = 2,        /* weight blob size does not match the graph (reference: tf NotFoundError on restore) */
+    UMX_ERR_NO_DEVICE = 3,   /* no usable HIP device */
+    UMX_ERR_HIP = 4,         /* a HIP runtime call failed */
+    UMX_ERR_OOM = 5
+};
+
+enum umx_graph {
+    UMX_GRAPH_LEGACY = 0,    /* reference UnMicst.py:51-187 (ReLU, 1x1 shortcut, BN after ReLU, no BN elsewhere) */
+    UMX_GRAPH_V2 = 1         /* reference UnMicst1-5.py:55-237 == UnMicst2.py:52-235 at inference */
+};
+
+/* The reference's hp dict (UnMicst1-5.py:57-67) + which graph builder consumes it.  downSampFact is fixed at 2. */
+typedef struct umx_hparams {
+    int32_t graph, imSize, nChannels, nClasses, nOut0, nLayers, ks, nExtraConvs, featMapsFact;
+} umx_hparams;
+
+enum umx_mode { UMX_MODE_ACCUMULATE = 0, UMX_MODE_REPLACE = 1 };      /* PI2D.Mode, PartitionOfImage.py:75 */
+enum umx_stitch { UMX_STITCH_FP16_COMPAT = 0, UMX_STITCH_FP32 = 1 }; /* fp16-compat reproduces the reference's
+    float16 Output/Count accumulators bit for bit (PartitionOfImage.py:84-122); fp32 blends in double and
+    returns float32 */
+
+/*
+ * Weight blob: one flat little-endian float32 array of the raw TensorFlow tensors in graph-execution order
+ * (unmicst_amd/model.py: tensor_specs):
+ *   for i in 0..nLayers-1:  ld{i}: w1 [ks,ks,Cin,Cout]; nExtraConvs x wextra [ks,ks,Cout,Cout];
+ *                           wshort [s,s,Cin,Cout] (s = 1 legacy, ks v2); BN gamma,beta,moving_mean,moving_var [Cout]
+ *   lb: w [ks,ks,Cn,2Cn]; (v2 only) BN x4 [2Cn]
+ *   for i in nLayers-1..0:  lu{i}: wt [ks,ks,C(i+1),C(i+2)] (conv2d_transpose filter, OUTPUT channel first);
+ *                           w2 [ks,ks,C(i)+C(i+1),C(i+1)]; (v2 only) BN x4; nExtraConvs x wextra
+ *   lt: w [1,1,C1,nClasses]; (v2 only) BN x4 [nClasses]
+ * All folding/packing happens inside umx_create.
+ */
+
+/* Replaces the nvidia-smi / NVML device probing of reference UnMicst1-5.py:750-769, toolbox/GPUselect.py:4-22. */
+UMX_API int umx_device_count(void);
+
+/* Replaces UNet2D.singleImageInferenceSetup's graph build + Saver.restore (UnMicst1-5.py:656-682).
+ * max_batch = tiles per UNet launch group (activation arena is sized for it; any n is accepted later). */
+UMX_API int umx_create(const umx_hparams* hp, const float* weight_blob, size_t blob_floats, int device_ordinal,
+               int max_batch, umx_ctx** out);
+
+/* Replaces UNet2D.singleImageInferenceCleanup (UnMicst1-5.py:684-685). NULL is a no-op. */
+UMX_API void umx_destroy(umx_ctx* ctx);
+
+/* Message of the last failure on this ctx (ctx == NULL: last failure of a ctx-less call on this thread). */
+UMX_API const char* umx_last_error(const umx_ctx* ctx);
+
+/* Use the caller's HIP stream (hipStream_t passed as void*; NULL restores the ctx's own stream). */
+UMX_API int umx_set_stream(umx_ctx* ctx, void* hip_stream);
+UMX_API int umx_synchronize(umx_ctx* ctx);
+
+/* Replaces Session.run(UNet2D.nn, {tfData: tiles, tfTraining: 0}) (UnMicst1-5.py:704):
+ * tiles [n,imSize,imSize,nChannels] float32 NHWC (already normalised) -> probs [n,imSize,imSize,nClasses]. */
+UMX_API int umx_forward_tiles(umx_ctx* ctx, const float* tiles_host, int n, float* probs_host);
+UMX_API int umx_forward_tiles_dev(umx_ctx* ctx, const float* tiles_dev, int n, float* probs_dev);
+
+/* Tile grid of an H x W image for this model (PI2D.setup, PartitionOfImage.py:23-75; margin = imSize/8,
+ * UnMicst1-5.py:694).  Any output pointer may be NULL. */
+UMX_API int umx_tile_grid(const umx_ctx* ctx, int H, int W, int* patch_rows, int* patch_cols, int* padded_rows,
+                  int* padded_cols);
+
+/* Replaces UNet2D.singleImageInference (UnMicst1-5.py:687-710, UnMicst2.py:666-689, UnMicst.py:520-541) for
+ * ALL classes in one pass: image float64 [C_img,H,W] (C_img == 1: the plane is copied to every input channel,
+ * as solo does; else C_img == nChannels), already resized/rescaled by the driver.
+ * out: [nClasses,H,W], uint16-encoded IEEE float16 for UMX_STITCH_FP16_COMPAT, float32 for UMX_STITCH_FP32. */
+UMX_API int umx_infer_image(umx_ctx* ctx, const double* image_host, int C_img, int H, int W, double mean, double std,
+                    int mode, int stitch, void* out_host);
+UMX_API int umx_infer_image_dev(umx_ctx* ctx, const double* image_dev, int C_img, int H, int W, double mean, double std,
+                        int mode, int stitch, void* out_dev);
+
+/* The two halves of umx_infer_image, exposed for band sharding across GPUs (one process per GPU):
+ * umx_band_tiles_dev: PI2D.getPatch + normalise + UNet for patch rows [pr0,pr1) -> probs
+ *   [(pr1-pr0)*patch_cols, P,P,K] float32.  image_dev holds image rows [band_row0, band_row0+band_rows) of the
+ *   full H x W image ([C_img, band_rows, W]); rows the requested patch rows need but the band lacks are an error.
+ * umx_stitch_dev: PI2D.patchOutput/getValidOutput restricted to image rows [y0,y1), given the probabilities of
+ *   patch rows [tpr0,tpr1) (every tile touching those rows must be inside that range) -> out [K, y1-y0, W]. */
+UMX_API int umx_band_tiles_dev(umx_ctx* ctx, const double* image_dev, int C_img, int H, int W, int band_row0,
+                       int band_rows, double mean, double std, int pr0, int pr1, float* probs_dev);
+UMX_API int umx_stitch_dev(umx_ctx* ctx, const float* probs_dev, int tpr0, int tpr1, int H, int W, int mode, int stitch,
+                   int y0, int y1, void* out_dev);
+
+/* Per-launch-site timing with HIP events on the ctx stream (used by bench.py for the roofline object). */
+typedef struct umx_prof_entry {
+    char name[48];          /* layer name, e.g. "lu1.conv" */
+    char kernel[48];        /* kernel family, e.g. "conv_mfma_f32<NT=5>" */
+    int64_t launches;
+    double total_ms;
+    double flops_per_launch_sum;  /* sum over launches of algorithmic FLOPs (no padded work counted) */
+    double bytes_per_launch_sum;  /* sum over launches of compulsory HBM bytes */
+} umx_prof_entry;
+UMX_API int umx_profile_enable(umx_ctx* ctx, int on);          /* on: bracket every launch with events; resets counters */
+UMX_API int umx_profile_read(umx_ctx* ctx, umx_prof_entry* entries, int max_entries, int* n_entries);
+
+/* Host-side helpers exported for the CPU test-suite (no GPU needed): the double->float16 round-to-nearest-even
+ * used by the fp16-compat stitch, and the library's view of a model (layer count, packed weight bytes, FLOPs). */
+UMX_API void umx_test_double_to_half(const double* in, uint16_t* out, size_t n);
+UMX_API int umx_describe(const umx_hparams* hp, int* n_launches, double* flops_per_tile, double* executed_flops_per_tile);
+UMX_API const char* umx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UMX_H */

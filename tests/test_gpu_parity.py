@@ -1,0 +1,156 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the oracle and the committed golden fixtures.
+
+Tolerances: per-tile softmax <= 1e-4 max-abs vs the fp32 CPU restatement (north_star);
+fp16-compat stitch bit-exact vs the imported reference PI2D fed the same tile probabilities; end-to-end file
+values <= 1 uint8 LSB vs the reference's bundled "UNet sample data" outputs.
+"""
+import numpy as np
+import pytest
+
+import helpers
+from unmicst_amd import model, umx
+
+pytestmark = pytest.mark.gpu
+
+TILE_TOL = 1e-4  # north_star: probability maps within 1e-4 max-abs
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch
+
+
+@pytest.mark.parametrize("name", sorted(helpers.small_hps()))
+def test_forward_tiles_matches_oracle(name):
+    from oracle import oracle
+    hp = helpers.small_hps()[name]
+    blob = model.random_blob(hp, seed=11)
+    rng = np.random.default_rng(5)
+    n = 5  # not a multiple of any tile-group size: exercises the image predicate
+    x = rng.normal(size=(n, hp.imSize, hp.imSize, hp.nChannels)).astype(np.float32)
+    ref = oracle.forward(hp, blob, x)
+    with umx.Engine(hp, blob, max_batch=3) as eng:   # 5 tiles through batches of 3 + 2
+        got = eng.forward_tiles(x)
+    assert got.shape == ref.shape
+    err = np.abs(got - ref).max()
+    assert err <= TILE_TOL, (name, err)
+    assert np.allclose(got.sum(-1), 1.0, atol=1e-5)
+
+
+def test_forward_tiles_real_weights_nucleiDAPI():
+    """Legacy graph with the reference's shipped models/nucleiDAPI weights (5x5 kernels) on real sample tiles."""
+    from oracle import oracle, pi2d_oracle
+    hp, blob, mean, std = helpers.load_nuclei_dapi()
+    raw = helpers.load_sample_105()[0]
+    I = helpers.legacy_preprocess(raw)
+    pi = pi2d_oracle.PI2DOracle(I, hp.imSize, hp.margin, "accumulate")
+    x = pi2d_oracle.normalised_batch(pi, 33, 6, 1, mean, std, False)
+    ref = oracle.forward(hp, blob, x)
+    with umx.Engine(hp, blob, max_batch=4) as eng:
+        got = eng.forward_tiles(x)
+    assert np.abs(got - ref).max() <= TILE_TOL
+
+
+@pytest.mark.parametrize("name", helpers.PI2D_CASES)
+def test_stitch_bit_exact_vs_reference_pi2d(name, torch_cuda):
+    """umx_stitch_dev (fp16-compat) on the golden tile probabilities == outputs of the imported reference PI2D."""
+    torch = torch_cuda
+    c = helpers.load_pi2d_case(name)
+    if c["margin"] != c["patch"] // 8:
+        pytest.skip("engine ties margin to imSize/8 like singleImageInference does (UnMicst1-5.py:694)")
+    img = c["image"]
+    H, W = img.shape[-2:]
+    hp = model.HParams(model.GRAPH_V2, c["patch"], 1, c["nclass"], 4, 1, 3, 0)
+    with umx.Engine(hp, model.random_blob(hp), max_batch=2) as eng:
+        npr, npc, nrpi, ncpi = eng.tile_grid(H, W)
+        assert (nrpi, ncpi) == (c["nrpi"], c["ncpi"]) and npr * npc == c["probs"].shape[0]
+        probs = torch.from_numpy(c["probs"]).cuda()
+        out = torch.empty((c["nclass"], H, W), dtype=torch.float16, device="cuda")
+        mode = umx.MODE_REPLACE if c["mode"] == "replace" else umx.MODE_ACCUMULATE
+        eng.stitch_dev(probs.data_ptr(), 0, npr, H, W, mode, umx.STITCH_FP16_COMPAT, 0, H, out.data_ptr())
+        eng.synchronize()
+        got = out.cpu().numpy()
+        assert np.array_equal(got.view(np.uint16), c["stitched"].view(np.uint16)), name
+        # banded stitch (what a rank of the sharded path does) must agree bit for bit with the full one
+        if npr >= 2:
+            sub = c["patch"] - 2 * c["margin"]
+            y_split = min(H, 1 * sub - c["margin"])   # rows owned by patch row 0 when it is a band of its own
+            if 0 < y_split < H:
+                top = torch.empty((c["nclass"], y_split, W), dtype=torch.float16, device="cuda")
+                bot = torch.empty((c["nclass"], H - y_split, W), dtype=torch.float16, device="cuda")
+                eng.stitch_dev(probs.data_ptr(), 0, 1, H, W, mode, 0, 0, y_split, top.data_ptr())
+                eng.stitch_dev(probs.data_ptr(), 0, npr, H, W, mode, 0, y_split, H, bot.data_ptr())
+                eng.synchronize()
+                both = np.concatenate([top.cpu().numpy(), bot.cpu().numpy()], axis=1)
+                assert np.array_equal(both.view(np.uint16), c["stitched"].view(np.uint16))
+
+
+def test_end_to_end_reference_sample_data():
+    """umx_infer_image with models/nucleiDAPI on 'UNet sample data' 105.tif vs the reference's bundled outputs."""
+    hp, blob, mean, std = helpers.load_nuclei_dapi()
+    raw, g_cont, g_raw, g_nuc = helpers.load_sample_105()
+    I = helpers.legacy_preprocess(raw)
+    with umx.Engine(hp, blob, max_batch=32) as eng:
+        planes = eng.infer_image(I, mean, std)
+    assert planes.dtype == np.float16 and planes.shape == (3,) + I.shape
+    for k, gold in ((1, g_cont), (2, g_nuc)):
+        pm = np.uint8(255 * planes[k].astype(np.float64))
+        d = np.abs(pm.astype(int) - gold.astype(int))
+        assert d.max() <= 1, (k, d.max())
+        assert (d == 0).mean() > 0.98
+
+
+@pytest.mark.parametrize("name,shape", [("v2_duo_like", (2, 70, 45)), ("v2_solo_like", (53, 90)), ("legacy_k5", (40, 33))])
+def test_infer_image_matches_oracle_loop(name, shape):
+    """Whole-image path (gather+normalise, UNet, stitch) vs the reference-equivalent oracle loop, per class."""
+    from oracle import oracle
+    hp = helpers.small_hps()[name]
+    blob = model.random_blob(hp, seed=3)
+    img = np.random.default_rng(9).random(shape) * 0.6
+    mean, std = 0.21, 0.17
+    with umx.Engine(hp, blob, max_batch=4) as eng:
+        got16 = eng.infer_image(img, mean, std)
+        got32 = eng.infer_image(img, mean, std, stitch=umx.STITCH_FP32)
+        rep = eng.infer_image(img, mean, std, mode=umx.MODE_REPLACE)
+    for k in range(hp.nClasses):
+        ref = oracle.single_image_inference(hp, blob, img, mean, std, "accumulate", k, batch_size=8)
+        assert ref.dtype == np.float16
+        # tile probabilities agree to ~1e-6, so the fp16 planes may differ by one fp16 ulp (4.9e-4 below 1.0)
+        assert np.abs(got16[k].astype(np.float32) - ref.astype(np.float32)).max() <= 1e-3
+        assert (got16[k].view(np.uint16) == ref.view(np.uint16)).mean() > 0.98
+        assert np.abs(got32[k] - ref.astype(np.float32)).max() <= 1e-3
+        refr = oracle.single_image_inference(hp, blob, img, mean, std, "replace", k, batch_size=8)
+        assert np.abs(rep[k].astype(np.float32) - refr.astype(np.float32)).max() <= 1e-3
+
+
+def test_band_sharding_is_bit_equal_to_single_pass(torch_cuda):
+    """Sharded whole-slide path on ONE GPU: two bands of patch rows + halo tiles == single pass, bit for bit."""
+    torch = torch_cuda
+    from unmicst_amd import sharding
+    hp = helpers.small_hps()["v2_duo_like"]
+    blob = model.random_blob(hp, seed=4)
+    img = np.random.default_rng(2).random((2, 150, 61)) * 0.5
+    with umx.Engine(hp, blob, max_batch=8) as eng:
+        full = eng.infer_image(img, 0.2, 0.2)
+        d_img = torch.from_numpy(img).cuda()
+        parts = []
+        for rank in range(3):
+            parts.append(sharding.infer_band_local(eng, d_img, 0.2, 0.2, rank, 3, umx.MODE_ACCUMULATE,
+                                                   umx.STITCH_FP16_COMPAT))
+        got = np.concatenate([p.cpu().numpy() for p in parts], axis=1)
+    assert np.array_equal(got.view(np.uint16), full.view(np.uint16))
+
+
+def test_errors_are_reported_not_raised_in_c():
+    hp = helpers.small_hps()["v2_solo_like"]
+    blob = model.random_blob(hp)
+    with pytest.raises(umx.UmxError) as e:
+        umx.Engine(hp, blob[:-1])
+    assert e.value.code == 2  # UMX_ERR_BLOB, the analogue of tf's NotFoundError on restore
+    with umx.Engine(hp, blob, max_batch=2) as eng:
+        with pytest.raises(umx.UmxError):
+            eng.infer_image(np.zeros((3, 20, 20)), 0.1, 0.1)  # 3 channels into a 1-channel model
+        with pytest.raises(umx.UmxError):
+            eng.infer_image(np.zeros((20, 20)), 0.1, 0.0)     # std == 0

@@ -1,0 +1,882 @@
+// Host side of libumx: graph construction from the reference's hyper-parameters, weight folding / packing,
+// device memory plan, launch sequencing and the C ABI declared in include/umx.h.  gfx950 (MI355X) only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/umx.h"
+#include "umx_kernels.h"
+
+using namespace umx;
+
+namespace {
+
+thread_local std::string g_err;
+
+struct HostTensor {
+    const float* p;
+    int d0, d1, d2, d3;  // [kh,kw,a,b]
+    float at(int i, int j, int a, int b) const { return p[(((size_t)i * d1 + j) * d2 + a) * d3 + b]; }
+};
+
+struct BN {
+    const float *g, *b, *m, *v;
+};
+
+struct Group {           // one operand group of a launch, host description
+    int src;             // buffer id
+    int C;               // channels
+    std::vector<std::pair<int, int>> taps[4];  // per phase: (dy, dx) input offsets
+    std::vector<float> packed[4];              // per phase: [ntaps][Cp][Np]
+};
+
+struct Launch {
+    std::string name;
+    bool head = false;
+    int ngroups = 0;
+    Group g[2];
+    int nphase = 1, o_mul = 1;
+    int oy_off[4] = {0, 0, 0, 0}, ox_off[4] = {0, 0, 0, 0};
+    int H = 0, W = 0, Cout = 0;
+    int dst = -1, outH = 0, outW = 0, pool = 0, act = 0;
+    std::vector<float> pre_s, pre_b, post_s, post_b;  // size Cout or empty
+    // head only
+    std::vector<float> head_w;  // [C][K]
+    int head_C = 0, head_K = 0;
+    // derived
+    int nt = 1, Np = 16, hpix = 2;
+    double flops = 0.0;       // algorithmic FLOPs per tile (per image of the batch)
+    double exec_flops = 0.0;  // executed incl. channel/N padding
+    double bytes = 0.0;       // compulsory HBM bytes per tile: sources + destination (weights excluded)
+    // device
+    ConvParams cp;
+    float* d_head_w = nullptr;
+    float *d_pre_s = nullptr, *d_pre_b = nullptr, *d_post_s = nullptr, *d_post_b = nullptr;
+};
+
+struct Buffer {
+    size_t floats_per_tile = 0;
+    float* d = nullptr;
+};
+
+struct ProfSite {
+    std::string name, kernel;
+    int64_t launches = 0;
+    double total_ms = 0.0, flops = 0.0, bytes = 0.0;
+};
+
+struct PendingEvent {
+    int site;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct umx_ctx {
+    umx_hparams hp;
+    int device = 0;
+    int max_batch = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::vector<Launch> plan;
+    std::vector<Buffer> bufs;   // bufs[0] = input tiles
+    std::vector<void*> allocs;
+    std::string err;
+    // whole-image scratch (grown on demand)
+    double* d_image = nullptr;  size_t image_cap = 0;
+    float* d_probs = nullptr;   size_t probs_cap = 0;
+    void* d_out = nullptr;      size_t out_cap = 0;
+    float* d_io_tiles = nullptr; size_t io_tiles_cap = 0;
+    float* d_io_probs = nullptr; size_t io_probs_cap = 0;
+    // profiling
+    bool prof = false;
+    std::vector<ProfSite> sites;
+    std::vector<PendingEvent> pending;
+    std::vector<hipEvent_t> free_events;
+    int site_gather = -1, site_stitch = -1;
+};
+
+namespace {
+
+int fail(umx_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                  \
+    do {                                                                                                    \
+        hipError_t e__ = (expr);                                                                            \
+        if (e__ != hipSuccess)                                                                              \
+            return fail(ctx, e__ == hipErrorOutOfMemory ? UMX_ERR_OOM : UMX_ERR_HIP, "%s failed: %s", #expr, \
+                        hipGetErrorString(e__));                                                            \
+    } while (0)
+
+int check_hp(const umx_hparams* hp, std::string* why) {
+    if (!hp) { *why = "hp is NULL"; return UMX_ERR_INVALID; }
+    if (hp->graph != UMX_GRAPH_LEGACY && hp->graph != UMX_GRAPH_V2) { *why = "unknown graph kind"; return UMX_ERR_INVALID; }
+    if (hp->nLayers < 1 || hp->nLayers > 8) { *why = "nLayers must be in [1,8]"; return UMX_ERR_INVALID; }
+    if (hp->ks < 1 || hp->ks > 7 || !(hp->ks & 1)) { *why = "ks must be odd and <= 7"; return UMX_ERR_INVALID; }
+    if (hp->nExtraConvs < 0 || hp->nExtraConvs > 4) { *why = "nExtraConvs must be in [0,4]"; return UMX_ERR_INVALID; }
+    if (hp->nClasses < 2 || hp->nClasses > 4) { *why = "nClasses must be 2..4"; return UMX_ERR_INVALID; }
+    if (hp->nChannels < 1 || hp->nOut0 < 1 || hp->featMapsFact < 1) { *why = "bad channel counts"; return UMX_ERR_INVALID; }
+    if (hp->imSize < 8 || (hp->imSize & (hp->imSize - 1))) { *why = "imSize must be a power of two >= 8"; return UMX_ERR_INVALID; }
+    if ((hp->imSize >> hp->nLayers) < 1) { *why = "imSize too small for nLayers"; return UMX_ERR_INVALID; }
+    return UMX_OK;
+}
+
+std::vector<int> widths(const umx_hparams& hp) {
+    std::vector<int> n = {hp.nChannels, hp.nOut0};
+    for (int i = 0; i < hp.nLayers; ++i) n.push_back(n.back() * hp.featMapsFact);
+    return n;
+}
+
+size_t blob_floats_needed(const umx_hparams& hp) {
+    const auto n = widths(hp);
+    const int ks = hp.ks, L = hp.nLayers, nx = hp.nExtraConvs;
+    const bool v2 = hp.graph == UMX_GRAPH_V2;
+    const int kss = v2 ? ks : 1;
+    size_t t = 0;
+    for (int i = 0; i < L; ++i) {
+        t += (size_t)ks * ks * n[i] * n[i + 1] + (size_t)nx * ks * ks * n[i + 1] * n[i + 1] +
+             (size_t)kss * kss * n[i] * n[i + 1] + 4 * (size_t)n[i + 1];
+    }
+    t += (size_t)ks * ks * n[L] * n[L + 1] + (v2 ? 4 * (size_t)n[L + 1] : 0);
+    for (int i = L - 1; i >= 0; --i) {
+        t += (size_t)ks * ks * n[i + 1] * n[i + 2] + (size_t)ks * ks * (n[i] + n[i + 1]) * n[i + 1] +
+             (v2 ? 4 * (size_t)n[i + 1] : 0) + (size_t)nx * ks * ks * n[i + 1] * n[i + 1];
+    }
+    t += (size_t)n[1] * hp.nClasses + (v2 ? 4 * (size_t)hp.nClasses : 0);
+    return t;
+}
+
+int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// choose N tiles per workgroup: minimise padded N, prefer wide tiles
+void choose_nt(int Cout, int* nt, int* Np) {
+    const int t16 = (Cout + 15) / 16;
+    int best = 1, best_pad = 1 << 30;
+    for (int c = 1; c <= kMaxNT; ++c) {
+        const int padded = round_up(t16, c);
+        if (padded < best_pad || (padded == best_pad && c > best)) { best = c; best_pad = padded; }
+    }
+    *nt = best;
+    *Np = best_pad * 16;
+}
+
+void fold_bn(const BN& bn, int C, std::vector<float>* s, std::vector<float>* b) {
+    // tf.layers.batch_normalization(training=False): gamma*(x-mean)/sqrt(var+eps)+beta, eps = 1e-3
+    s->resize(C);
+    b->resize(C);
+    for (int c = 0; c < C; ++c) {
+        const double sc = (double)bn.g[c] / std::sqrt((double)bn.v[c] + 0.001);
+        (*s)[c] = (float)sc;
+        (*b)[c] = (float)((double)bn.b[c] - (double)bn.m[c] * sc);
+    }
+}
+
+struct Builder {
+    const umx_hparams& hp;
+    const float* blob;   // may be NULL (describe only)
+    size_t pos = 0;
+    std::vector<Launch> plan;
+    std::vector<size_t> buf_floats;  // per tile
+
+    explicit Builder(const umx_hparams& h, const float* b) : hp(h), blob(b) {}
+
+    const float* take(size_t n) {
+        const float* r = blob ? blob + pos : nullptr;
+        pos += n;
+        return r;
+    }
+    HostTensor take_filter(int kh, int kw, int a, int b) { return HostTensor{take((size_t)kh * kw * a * b), kh, kw, a, b}; }
+    BN take_bn(int C) { BN r; r.g = take(C); r.b = take(C); r.m = take(C); r.v = take(C); return r; }
+    int new_buf(size_t floats) { buf_floats.push_back(floats); return (int)buf_floats.size() - 1; }
+
+    // pack filter channels [c0, c0+C) of w [kh,kw,Cin,Cout] for the taps of a stride-1 SAME conv
+    void add_conv_group(Launch& L, int src, const HostTensor& w, int c0, int C, const HostTensor* add = nullptr) {
+        Group& g = L.g[L.ngroups++];
+        g.src = src;
+        g.C = C;
+        const int ph = (w.d0 - 1) / 2, pw = (w.d1 - 1) / 2;
+        for (int a = 0; a < w.d0; ++a)
+            for (int b = 0; b < w.d1; ++b) g.taps[0].push_back({a - ph, b - pw});
+        if (!blob) return;
+        const int Cp = round_up(C, 4);
+        g.packed[0].assign((size_t)w.d0 * w.d1 * Cp * L.Np, 0.f);
+        for (int a = 0; a < w.d0; ++a)
+            for (int b = 0; b < w.d1; ++b)
+                for (int c = 0; c < C; ++c)
+                    for (int o = 0; o < L.Cout; ++o) {
+                        float v = w.at(a, b, c0 + c, o);
+                        if (add) {
+                            // same-source shortcut folded into the main filter (exact algebra):
+                            // ks x ks shortcut -> element-wise sum; 1x1 shortcut -> centre tap
+                            if (add->d0 == w.d0) v += add->at(a, b, c0 + c, o);
+                            else if (a == ph && b == pw) v += add->at(0, 0, c0 + c, o);
+                        }
+                        g.packed[0][(((size_t)a * w.d1 + b) * Cp + c) * L.Np + o] = v;
+                    }
+    }
+
+    // stride-2 SAME transposed conv as 4 sub-pixel phases; wt [kh,kw,Cout,Cin] (TF conv2d_transpose layout)
+    void add_convT_group(Launch& L, int src, const HostTensor& wt) {
+        Group& g = L.g[L.ngroups++];
+        g.src = src;
+        g.C = wt.d3;
+        const int Cp = round_up(g.C, 4);
+        const int pbh = (wt.d0 - 2) / 2, pbw = (wt.d1 - 2) / 2;  // pad_before of the forward stride-2 SAME conv
+        L.nphase = 4;
+        L.o_mul = 2;
+        for (int p = 0; p < 4; ++p) {
+            const int pu = p >> 1, pv = p & 1;
+            L.oy_off[p] = pu;
+            L.ox_off[p] = pv;
+            std::vector<std::pair<int, int>> ab;
+            for (int a = 0; a < wt.d0; ++a) {
+                if (((a - pbh - pu) & 1) != 0) continue;
+                for (int b = 0; b < wt.d1; ++b) {
+                    if (((b - pbw - pv) & 1) != 0) continue;
+                    ab.push_back({a, b});
+                    // out[2i'+pu] += in[i] * W[a] with 2i + a - pb = 2i' + pu  ->  i = i' + (pu + pb - a)/2
+                    g.taps[p].push_back({(pu + pbh - a) / 2, (pv + pbw - b) / 2});
+                }
+            }
+            if (!blob) continue;
+            g.packed[p].assign(ab.size() * (size_t)Cp * L.Np, 0.f);
+            for (size_t t = 0; t < ab.size(); ++t)
+                for (int c = 0; c < g.C; ++c)
+                    for (int o = 0; o < L.Cout; ++o)
+                        g.packed[p][(t * Cp + c) * L.Np + o] = wt.at(ab[t].first, ab[t].second, o, c);
+        }
+    }
+
+    Launch make(const std::string& name, int H, int Cout, int dst, int pool, int act) {
+        Launch L;
+        L.name = name;
+        L.H = L.W = H;
+        L.Cout = Cout;
+        L.dst = dst;
+        L.pool = pool;
+        L.act = act;
+        choose_nt(Cout, &L.nt, &L.Np);
+        return L;
+    }
+
+    void finish(Launch& L) {
+        L.outH = L.pool ? L.H / 2 : L.H * L.o_mul;
+        L.outW = L.pool ? L.W / 2 : L.W * L.o_mul;
+        double mac = 0.0, emac = 0.0, src_bytes = 0.0;
+        for (int gi = 0; gi < L.ngroups; ++gi) {
+            size_t nt = 0;
+            for (int p = 0; p < L.nphase; ++p) nt += L.g[gi].taps[p].size();
+            mac += (double)L.H * L.W * nt * L.g[gi].C * L.Cout;
+            emac += (double)L.H * L.W * nt * round_up(L.g[gi].C, 4) * L.Np;
+            src_bytes += 4.0 * L.H * L.W * L.g[gi].C;
+        }
+        L.flops = 2.0 * mac;
+        L.exec_flops = 2.0 * emac;
+        L.bytes = src_bytes + 4.0 * L.outH * L.outW * L.Cout;
+        plan.push_back(std::move(L));
+    }
+
+    int build() {
+        const auto n = widths(hp);
+        const int L = hp.nLayers, ks = hp.ks, nx = hp.nExtraConvs, P = hp.imSize;
+        const bool v2 = hp.graph == UMX_GRAPH_V2;
+        const int kss = v2 ? ks : 1;
+        const int act = v2 ? ACT_LEAKY : ACT_RELU;
+        std::vector<int> ds(L + 1);
+        ds[0] = new_buf((size_t)P * P * n[0]);  // buffer 0: normalised input tiles
+        int S = P;
+        char nm[64];
+        for (int i = 0; i < L; ++i) {
+            const int Ci = n[i], Co = n[i + 1];
+            HostTensor w1 = take_filter(ks, ks, Ci, Co);
+            std::vector<HostTensor> wx;
+            for (int e = 0; e < nx; ++e) wx.push_back(take_filter(ks, ks, Co, Co));
+            HostTensor wsc = take_filter(kss, kss, Ci, Co);
+            BN bn = take_bn(Co);
+            ds[i + 1] = new_buf((size_t)(S / 2) * (S / 2) * Co);
+            auto epilogue = [&](Launch& Lh) {
+                // v2: leaky(BN(sum)) (UnMicst1-5.py:114);  legacy: BN(relu(sum)) (UnMicst.py:99); then 2x2 max-pool
+                if (!blob) return;
+                if (v2) fold_bn(bn, Co, &Lh.pre_s, &Lh.pre_b);
+                else fold_bn(bn, Co, &Lh.post_s, &Lh.post_b);
+            };
+            if (nx == 0) {
+                snprintf(nm, sizeof nm, "ld%d.conv", i);
+                Launch Lh = make(nm, S, Co, ds[i + 1], 1, act);
+                add_conv_group(Lh, ds[i], w1, 0, Ci, &wsc);
+                epilogue(Lh);
+                finish(Lh);
+            } else {
+                int t = new_buf((size_t)S * S * Co), t2 = nx > 1 ? new_buf((size_t)S * S * Co) : -1;
+                snprintf(nm, sizeof nm, "ld%d.conv1", i);
+                Launch L1 = make(nm, S, Co, t, 0, act);  // act fused: the next conv consumes act(c00)
+                add_conv_group(L1, ds[i], w1, 0, Ci);
+                finish(L1);
+                for (int e = 0; e < nx; ++e) {
+                    const bool last = e == nx - 1;
+                    snprintf(nm, sizeof nm, "ld%d.extra%d", i, e);
+                    Launch Le = make(nm, S, Co, last ? ds[i + 1] : t2, last ? 1 : 0, act);
+                    add_conv_group(Le, t, wx[e], 0, Co);
+                    if (last) {
+                        add_conv_group(Le, ds[i], wsc, 0, Ci);  // shortcut of the block input as a second K slab
+                        epilogue(Le);
+                    }
+                    finish(Le);
+                    std::swap(t, t2);
+                }
+            }
+            S /= 2;
+        }
+        int cur;
+        {
+            const int Ci = n[L], Co = n[L + 1];
+            HostTensor w = take_filter(ks, ks, Ci, Co);
+            cur = new_buf((size_t)S * S * Co);
+            Launch Lb = make("lb.conv", S, Co, cur, 0, act);
+            add_conv_group(Lb, ds[L], w, 0, Ci);
+            if (v2) {
+                BN bn = take_bn(Co);
+                if (blob) fold_bn(bn, Co, &Lb.pre_s, &Lb.pre_b);
+            }
+            finish(Lb);
+        }
+        for (int idx = L - 1; idx >= 0; --idx) {
+            const int Cskip = n[idx], Cup = n[idx + 1], Cin = n[idx + 2];
+            HostTensor wt = take_filter(ks, ks, Cup, Cin);
+            HostTensor w2 = take_filter(ks, ks, Cskip + Cup, Cup);
+            BN bn{};
+            if (v2) bn = take_bn(Cup);
+            std::vector<HostTensor> wx;
+            for (int e = 0; e < nx; ++e) wx.push_back(take_filter(ks, ks, Cup, Cup));
+            const int S2 = S * 2;
+            const int us = new_buf((size_t)S2 * S2 * Cup);
+            snprintf(nm, sizeof nm, "lu%d.convT", idx);
+            Launch Lt = make(nm, S, Cup, us, 0, act);
+            add_convT_group(Lt, cur, wt);
+            finish(Lt);
+            int cv = new_buf((size_t)S2 * S2 * Cup);
+            snprintf(nm, sizeof nm, "lu%d.conv", idx);
+            Launch Lc = make(nm, S2, Cup, cv, 0, act);
+            add_conv_group(Lc, ds[idx], w2, 0, Cskip);   // concat3([dsX[index], us]): skip channels first
+            add_conv_group(Lc, us, w2, Cskip, Cup);
+            if (v2 && blob) fold_bn(bn, Cup, &Lc.pre_s, &Lc.pre_b);
+            finish(Lc);
+            int other = nx > 0 ? new_buf((size_t)S2 * S2 * Cup) : -1;
+            for (int e = 0; e < nx; ++e) {
+                snprintf(nm, sizeof nm, "lu%d.extra%d", idx, e);
+                Launch Le = make(nm, S2, Cup, other, 0, act);
+                add_conv_group(Le, cv, wx[e], 0, Cup);
+                finish(Le);
+                std::swap(cv, other);
+            }
+            cur = cv;
+            S = S2;
+        }
+        {
+            Launch Lh;
+            Lh.name = "lt.head";
+            Lh.head = true;
+            Lh.H = Lh.W = S;
+            Lh.head_C = n[1];
+            Lh.head_K = hp.nClasses;
+            Lh.ngroups = 1;
+            Lh.g[0].src = cur;
+            Lh.g[0].C = n[1];
+            const float* w = take((size_t)n[1] * hp.nClasses);
+            if (blob) Lh.head_w.assign(w, w + (size_t)n[1] * hp.nClasses);
+            if (v2) {
+                BN bn = take_bn(hp.nClasses);
+                if (blob) fold_bn(bn, hp.nClasses, &Lh.pre_s, &Lh.pre_b);
+            }
+            Lh.flops = Lh.exec_flops = 2.0 * S * S * n[1] * hp.nClasses;
+            Lh.bytes = 4.0 * S * S * (n[1] + hp.nClasses);
+            plan.push_back(std::move(Lh));
+        }
+        return UMX_OK;
+    }
+};
+
+// conv geometry (tile shape, LDS halo) for one launch; returns false if unsupported
+bool conv_geometry(Launch& L, std::string* why) {
+    ConvParams& p = L.cp;
+    memset(&p, 0, sizeof p);
+    int ymin = 0, ymax = 0, xmin = 0, xmax = 0, ntaps_total = 0;
+    for (int gi = 0; gi < L.ngroups; ++gi)
+        for (int ph = 0; ph < L.nphase; ++ph)
+            for (auto& t : L.g[gi].taps[ph]) {
+                ymin = std::min(ymin, t.first); ymax = std::max(ymax, t.first);
+                xmin = std::min(xmin, t.second); xmax = std::max(xmax, t.second);
+                ++ntaps_total;
+            }
+    if (ntaps_total > kMaxTaps) { *why = "too many filter taps"; return false; }
+    auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    const int TWm = std::min(16, L.W), TH = std::min(16, L.H);
+    if ((TWm & (TWm - 1)) || (TH & (TH - 1))) { *why = "layer size must be a power of two"; return false; }
+    p.twm_log2 = lg2(TWm);
+    p.th_log2 = lg2(TH);
+    p.nimg_m = 16 / TWm;
+    p.imgs = p.nimg_m * (16 / TH);
+    p.hh = TH + ymax - ymin;
+    p.hw = TWm + xmax - xmin;
+    p.imgplane = p.hh * p.hw;
+    int plane = p.imgs * p.imgplane;
+    plane = round_up(plane, 32) + 16;  // = 16 (mod 32): conflict-free A-fragment reads
+    if (plane - 32 >= p.imgs * p.imgplane) plane -= 32;
+    p.plane = plane;
+    p.ymin = ymin;
+    p.xmin = xmin;
+    p.tiles_y = L.H / TH;
+    p.tiles_x = L.W / TWm;
+    L.hpix = (p.imgs * p.imgplane + 255) / 256;
+    if (L.hpix > 4) { *why = "halo too large for the staging registers"; return false; }
+    L.hpix = L.hpix <= 2 ? 2 : 4;
+    if (L.pool && (TH < 2 || TWm < 2)) { *why = "cannot pool a 1-pixel layer"; return false; }
+    p.ngroups = L.ngroups;
+    p.H = L.H; p.W = L.W; p.Cout = L.Cout; p.Np = L.Np;
+    p.nphase = L.nphase; p.o_mul = L.o_mul;
+    p.outH = L.outH; p.outW = L.outW; p.pool = L.pool; p.act = L.act;
+    int tpos = 0;
+    for (int ph = 0; ph < L.nphase; ++ph) {
+        p.ph[ph].oy_off = L.oy_off[ph];
+        p.ph[ph].ox_off = L.ox_off[ph];
+        for (int gi = 0; gi < L.ngroups; ++gi) {
+            p.ph[ph].tap0[gi] = tpos;
+            p.ph[ph].ntaps[gi] = (int)L.g[gi].taps[ph].size();
+            for (auto& t : L.g[gi].taps[ph]) p.tapoff[tpos++] = (short)((t.first - ymin) * p.hw + (t.second - xmin));
+        }
+    }
+    for (int gi = 0; gi < L.ngroups; ++gi) {
+        p.C[gi] = L.g[gi].C;
+        p.Cp[gi] = round_up(L.g[gi].C, 4);
+        p.vec4[gi] = (L.g[gi].C % 4) == 0;
+    }
+    if (conv_lds_bytes(L.nt, p.plane) > 160 * 1024) { *why = "LDS footprint too large"; return false; }
+    return true;
+}
+
+int dev_alloc(umx_ctx* ctx, void** out, size_t bytes) {
+    void* d = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d, bytes ? bytes : 16));
+    ctx->allocs.push_back(d);
+    *out = d;
+    return UMX_OK;
+}
+
+int upload(umx_ctx* ctx, const std::vector<float>& h, float** out) {
+    *out = nullptr;
+    if (h.empty()) return UMX_OK;
+    void* d = nullptr;
+    int rc = dev_alloc(ctx, &d, h.size() * sizeof(float));
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    *out = (float*)d;
+    return UMX_OK;
+}
+
+int grow(umx_ctx* ctx, void** buf, size_t* cap, size_t bytes) {
+    if (*cap >= bytes) return UMX_OK;
+    if (*buf) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(*buf));
+        *buf = nullptr;
+        *cap = 0;
+    }
+    HIP_TRY(ctx, hipMalloc(buf, bytes));
+    *cap = bytes;
+    return UMX_OK;
+}
+
+int site_of(umx_ctx* ctx, const std::string& name, const std::string& kernel) {
+    for (size_t i = 0; i < ctx->sites.size(); ++i)
+        if (ctx->sites[i].name == name) return (int)i;
+    ProfSite s;
+    s.name = name;
+    s.kernel = kernel;
+    ctx->sites.push_back(s);
+    return (int)ctx->sites.size() - 1;
+}
+
+int prof_fold(umx_ctx* ctx) {
+    if (ctx->pending.empty()) return UMX_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& pe : ctx->pending) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, pe.a, pe.b));
+        ctx->sites[pe.site].total_ms += ms;
+        ctx->free_events.push_back(pe.a);
+        ctx->free_events.push_back(pe.b);
+    }
+    ctx->pending.clear();
+    return UMX_OK;
+}
+
+struct ProfScope {
+    umx_ctx* ctx;
+    int site;
+    hipEvent_t a = nullptr, b = nullptr;
+    bool on;
+    ProfScope(umx_ctx* c, int s, double flops, double bytes) : ctx(c), site(s), on(c->prof && s >= 0) {
+        if (!on) return;
+        auto get = [&](hipEvent_t* e) {
+            if (!ctx->free_events.empty()) { *e = ctx->free_events.back(); ctx->free_events.pop_back(); }
+            else if (hipEventCreate(e) != hipSuccess) *e = nullptr;
+        };
+        get(&a);
+        get(&b);
+        if (!a || !b) { on = false; return; }
+        ctx->sites[site].launches += 1;
+        ctx->sites[site].flops += flops;
+        ctx->sites[site].bytes += bytes;
+        hipEventRecord(a, ctx->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        hipEventRecord(b, ctx->stream);
+        ctx->pending.push_back({site, a, b});
+    }
+};
+
+// run the UNet on n tiles already in bufs[0] layout at `tiles` -> probs
+int run_unet(umx_ctx* ctx, const float* tiles, int n, float* probs) {
+    const umx_hparams& hp = ctx->hp;
+    for (auto& L : ctx->plan) {
+        const float* src0 = L.g[0].src == 0 ? tiles : ctx->bufs[L.g[0].src].d;
+        if (L.head) {
+            const size_t npix = (size_t)n * L.H * L.W;
+            ProfScope ps(ctx, site_of(ctx, L.name, "head_softmax"), L.flops * n, L.bytes * n);
+            HIP_TRY(ctx, launch_head_softmax(src0, npix, L.head_C, L.head_K, L.d_head_w, L.d_pre_s, L.d_pre_b, probs,
+                                             ctx->stream));
+            continue;
+        }
+        ConvParams p = L.cp;
+        p.B = n;
+        p.src[0] = src0;
+        if (L.ngroups > 1) p.src[1] = L.g[1].src == 0 ? tiles : ctx->bufs[L.g[1].src].d;
+        p.dst = ctx->bufs[L.dst].d;
+        char kn[48];
+        snprintf(kn, sizeof kn, "conv_mfma_f32<NT=%d,HPIX=%d>", L.nt, L.hpix);
+        ProfScope ps(ctx, site_of(ctx, L.name, kn), L.flops * n, L.bytes * n);
+        HIP_TRY(ctx, launch_conv(p, L.nt, L.hpix, ctx->stream));
+    }
+    if (ctx->prof && ctx->pending.size() > 4096) return prof_fold(ctx);
+    (void)hp;
+    return UMX_OK;
+}
+
+TileGeom geom_of(const umx_hparams& hp, int H, int W) {
+    TileGeom g;
+    g.H = H; g.W = W;
+    g.P = hp.imSize;
+    g.margin = hp.imSize / 8;              // int(imSize/8), UnMicst1-5.py:694
+    g.sub = g.P - 2 * g.margin;
+    g.npr = (H + g.sub - 1) / g.sub;       // ceil, PartitionOfImage.py:49-50
+    g.npc = (W + g.sub - 1) / g.sub;
+    return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* umx_version(void) { return "umx 0.1 (gfx950)"; }
+
+int umx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* umx_last_error(const umx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+void umx_test_double_to_half(const double* in, uint16_t* out, size_t n) {
+    for (size_t i = 0; i < n; ++i) out[i] = double_to_half_rne(in[i]);
+}
+
+int umx_describe(const umx_hparams* hp, int* n_launches, double* flops_per_tile, double* executed_flops_per_tile) {
+    std::string why;
+    int rc = check_hp(hp, &why);
+    if (rc) return fail(nullptr, rc, "%s", why.c_str());
+    Builder b(*hp, nullptr);
+    b.build();
+    double f = 0, e = 0;
+    for (auto& L : b.plan) { f += L.flops; e += L.exec_flops; }
+    if (n_launches) *n_launches = (int)b.plan.size();
+    if (flops_per_tile) *flops_per_tile = f;
+    if (executed_flops_per_tile) *executed_flops_per_tile = e;
+    return UMX_OK;
+}
+
+int umx_create(const umx_hparams* hp, const float* weight_blob, size_t blob_floats, int device_ordinal, int max_batch,
+               umx_ctx** out) {
+    if (!out) return fail(nullptr, UMX_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    std::string why;
+    int rc = check_hp(hp, &why);
+    if (rc) return fail(nullptr, rc, "%s", why.c_str());
+    if (!weight_blob) return fail(nullptr, UMX_ERR_INVALID, "weight_blob is NULL");
+    if (max_batch < 1) return fail(nullptr, UMX_ERR_INVALID, "max_batch must be >= 1");
+    const size_t need = blob_floats_needed(*hp);
+    if (need != blob_floats)
+        return fail(nullptr, UMX_ERR_BLOB, "weight blob has %zu floats, the graph needs %zu", blob_floats, need);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, UMX_ERR_NO_DEVICE, "no HIP device available (libumx has no CPU fallback)");
+    if (device_ordinal < 0 || device_ordinal >= ndev)
+        return fail(nullptr, UMX_ERR_INVALID, "device ordinal %d out of range (%d devices)", device_ordinal, ndev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess)
+        return fail(nullptr, UMX_ERR_HIP, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, UMX_ERR_NO_DEVICE, "device %d is %s; libumx is built for gfx950 only", device_ordinal,
+                    prop.gcnArchName);
+
+    std::unique_ptr<umx_ctx> ctx(new umx_ctx());
+    ctx->hp = *hp;
+    ctx->device = device_ordinal;
+    ctx->max_batch = max_batch;
+    umx_ctx* c = ctx.get();
+    HIP_TRY(nullptr, hipSetDevice(device_ordinal));
+    HIP_TRY(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+
+    Builder b(*hp, weight_blob);
+    b.build();
+    if (b.pos != blob_floats) { umx_destroy(ctx.release()); return fail(nullptr, UMX_ERR_BLOB, "internal blob walk mismatch"); }
+    c->plan = std::move(b.plan);
+    c->bufs.resize(b.buf_floats.size());
+    auto bail = [&](int code) { std::string m = c->err; umx_destroy(ctx.release()); g_err = m; return code; };
+    for (size_t i = 0; i < c->bufs.size(); ++i) {
+        c->bufs[i].floats_per_tile = b.buf_floats[i];
+        void* d = nullptr;
+        if ((rc = dev_alloc(c, &d, b.buf_floats[i] * sizeof(float) * (size_t)max_batch))) return bail(rc);
+        c->bufs[i].d = (float*)d;
+    }
+    for (auto& L : c->plan) {
+        if ((rc = upload(c, L.pre_s, &L.d_pre_s)) || (rc = upload(c, L.pre_b, &L.d_pre_b)) ||
+            (rc = upload(c, L.post_s, &L.d_post_s)) || (rc = upload(c, L.post_b, &L.d_post_b)))
+            return bail(rc);
+        if (L.head) {
+            if ((rc = upload(c, L.head_w, &L.d_head_w))) return bail(rc);
+            continue;
+        }
+        if (!conv_geometry(L, &why)) { c->err = L.name + ": " + why; return bail(UMX_ERR_INVALID); }
+        for (int ph = 0; ph < L.nphase; ++ph)
+            for (int gi = 0; gi < L.ngroups; ++gi) {
+                float* d = nullptr;
+                if ((rc = upload(c, L.g[gi].packed[ph], &d))) return bail(rc);
+                L.cp.ph[ph].w[gi] = d;
+                std::vector<float>().swap(L.g[gi].packed[ph]);
+            }
+        L.cp.pre_s = L.d_pre_s; L.cp.pre_b = L.d_pre_b; L.cp.post_s = L.d_post_s; L.cp.post_b = L.d_post_b;
+    }
+    *out = ctx.release();
+    return UMX_OK;
+}
+
+void umx_destroy(umx_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (auto& pe : ctx->pending) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
+    for (auto e : ctx->free_events) hipEventDestroy(e);
+    for (void* d : ctx->allocs) hipFree(d);
+    if (ctx->d_image) hipFree(ctx->d_image);
+    if (ctx->d_probs) hipFree(ctx->d_probs);
+    if (ctx->d_out) hipFree(ctx->d_out);
+    if (ctx->d_io_tiles) hipFree(ctx->d_io_tiles);
+    if (ctx->d_io_probs) hipFree(ctx->d_io_probs);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int umx_set_stream(umx_ctx* ctx, void* hip_stream) {
+    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return UMX_OK;
+}
+
+int umx_synchronize(umx_ctx* ctx) {
+    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return UMX_OK;
+}
+
+int umx_forward_tiles_dev(umx_ctx* ctx, const float* tiles_dev, int n, float* probs_dev) {
+    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    if (n < 0 || (n > 0 && (!tiles_dev || !probs_dev))) return fail(ctx, UMX_ERR_INVALID, "bad tiles/probs/n");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t P = ctx->hp.imSize;
+    const size_t tile_f = P * P * ctx->hp.nChannels, prob_f = P * P * ctx->hp.nClasses;
+    for (int i = 0; i < n; i += ctx->max_batch) {
+        const int nb = std::min(ctx->max_batch, n - i);
+        int rc = run_unet(ctx, tiles_dev + (size_t)i * tile_f, nb, probs_dev + (size_t)i * prob_f);
+        if (rc) return rc;
+    }
+    return UMX_OK;
+}
+
+int umx_forward_tiles(umx_ctx* ctx, const float* tiles_host, int n, float* probs_host) {
+    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    if (n < 0 || (n > 0 && (!tiles_host || !probs_host))) return fail(ctx, UMX_ERR_INVALID, "bad tiles/probs/n");
+    if (n == 0) return UMX_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t P = ctx->hp.imSize;
+    const size_t tile_b = P * P * ctx->hp.nChannels * sizeof(float), prob_b = P * P * ctx->hp.nClasses * sizeof(float);
+    int rc;
+    if ((rc = grow(ctx, (void**)&ctx->d_io_tiles, &ctx->io_tiles_cap, tile_b * n))) return rc;
+    if ((rc = grow(ctx, (void**)&ctx->d_io_probs, &ctx->io_probs_cap, prob_b * n))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_io_tiles, tiles_host, tile_b * n, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = umx_forward_tiles_dev(ctx, ctx->d_io_tiles, n, ctx->d_io_probs))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(probs_host, ctx->d_io_probs, prob_b * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return UMX_OK;
+}
+
+int umx_tile_grid(const umx_ctx* ctx, int H, int W, int* patch_rows, int* patch_cols, int* padded_rows,
+                  int* padded_cols) {
+    if (!ctx || H < 1 || W < 1) return fail(nullptr, UMX_ERR_INVALID, "bad ctx/H/W");
+    const TileGeom g = geom_of(ctx->hp, H, W);
+    if (patch_rows) *patch_rows = g.npr;
+    if (patch_cols) *patch_cols = g.npc;
+    if (padded_rows) *padded_rows = g.npr * g.sub + 2 * g.margin;
+    if (padded_cols) *padded_cols = g.npc * g.sub + 2 * g.margin;
+    return UMX_OK;
+}
+
+int umx_band_tiles_dev(umx_ctx* ctx, const double* image_dev, int C_img, int H, int W, int band_row0, int band_rows,
+                       double mean, double stdv, int pr0, int pr1, float* probs_dev) {
+    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    if (!image_dev || !probs_dev || H < 1 || W < 1) return fail(ctx, UMX_ERR_INVALID, "bad image/probs/H/W");
+    if (C_img != 1 && C_img != ctx->hp.nChannels)
+        return fail(ctx, UMX_ERR_INVALID, "image has %d channels, model wants 1 or %d", C_img, ctx->hp.nChannels);
+    if (!(stdv != 0.0)) return fail(ctx, UMX_ERR_INVALID, "std must be non-zero");
+    const TileGeom g = geom_of(ctx->hp, H, W);
+    if (pr0 < 0 || pr1 > g.npr || pr0 > pr1) return fail(ctx, UMX_ERR_INVALID, "patch rows [%d,%d) outside [0,%d)", pr0, pr1, g.npr);
+    if (pr0 == pr1) return UMX_OK;
+    // image rows the patch rows touch: [pr0*sub - m, (pr1-1)*sub + P - m) clipped to the image
+    const int need0 = std::max(0, pr0 * g.sub - g.margin), need1 = std::min(H, (pr1 - 1) * g.sub + g.P - g.margin);
+    if (band_row0 < 0 || band_rows < 0 || (need1 > need0 && (band_row0 > need0 || band_row0 + band_rows < need1)))
+        return fail(ctx, UMX_ERR_INVALID, "band rows [%d,%d) do not cover the rows [%d,%d) the patch rows need",
+                    band_row0, band_row0 + band_rows, need0, need1);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int t0 = pr0 * g.npc, t1 = pr1 * g.npc;
+    const size_t prob_f = (size_t)g.P * g.P * ctx->hp.nClasses;
+    if (ctx->site_gather < 0) ctx->site_gather = site_of(ctx, "pi2d.gather_normalise", "gather_normalise");
+    for (int t = t0; t < t1; t += ctx->max_batch) {
+        const int nb = std::min(ctx->max_batch, t1 - t);
+        {
+            ProfScope ps(ctx, ctx->site_gather, 0.0, (double)nb * g.P * g.P * (8.0 + 4.0 * ctx->hp.nChannels));
+            HIP_TRY(ctx, launch_gather_normalise(image_dev, C_img, band_row0, band_rows, g, ctx->hp.nChannels, mean, stdv, t,
+                                                 nb, ctx->bufs[0].d, ctx->stream));
+        }
+        int rc = run_unet(ctx, ctx->bufs[0].d, nb, probs_dev + (size_t)(t - t0) * prob_f);
+        if (rc) return rc;
+    }
+    return UMX_OK;
+}
+
+int umx_stitch_dev(umx_ctx* ctx, const float* probs_dev, int tpr0, int tpr1, int H, int W, int mode, int stitch, int y0,
+                   int y1, void* out_dev) {
+    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    if (!probs_dev || !out_dev || H < 1 || W < 1) return fail(ctx, UMX_ERR_INVALID, "bad probs/out/H/W");
+    if (mode != UMX_MODE_ACCUMULATE && mode != UMX_MODE_REPLACE) return fail(ctx, UMX_ERR_INVALID, "bad mode %d", mode);
+    if (stitch != UMX_STITCH_FP16_COMPAT && stitch != UMX_STITCH_FP32) return fail(ctx, UMX_ERR_INVALID, "bad stitch %d", stitch);
+    const TileGeom g = geom_of(ctx->hp, H, W);
+    if (y0 < 0 || y1 > H || y0 > y1) return fail(ctx, UMX_ERR_INVALID, "rows [%d,%d) outside the image", y0, y1);
+    if (y0 == y1) return UMX_OK;
+    // patch rows touching image rows [y0,y1): padded rows R = y + m; pr*sub <= R < pr*sub + P
+    const int R0 = y0 + g.margin, R1 = y1 - 1 + g.margin;
+    const int need_lo = (R0 - g.P + 1 <= 0) ? 0 : (R0 - g.P + g.sub) / g.sub;  // ceil((R0-P+1)/sub)
+    const int need_hi = std::min(g.npr - 1, R1 / g.sub);
+    if (tpr0 > need_lo || tpr1 <= need_hi || tpr0 < 0 || tpr1 > g.npr)
+        return fail(ctx, UMX_ERR_INVALID, "tile rows [%d,%d) do not cover the patch rows [%d,%d] touching image rows [%d,%d)",
+                    tpr0, tpr1, need_lo, need_hi, y0, y1);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->site_stitch < 0) ctx->site_stitch = site_of(ctx, "pi2d.stitch", "stitch");
+    const int K = ctx->hp.nClasses;
+    ProfScope ps(ctx, ctx->site_stitch, 0.0,
+                 (double)(y1 - y0) * W * K * (4.0 * ((double)g.P / g.sub) * ((double)g.P / g.sub) + (stitch == 0 ? 2.0 : 4.0)));
+    HIP_TRY(ctx, launch_stitch(probs_dev, tpr0, tpr1, g, K, mode, stitch, y0, y1, out_dev, ctx->stream));
+    return UMX_OK;
+}
+
+int umx_infer_image_dev(umx_ctx* ctx, const double* image_dev, int C_img, int H, int W, double mean, double stdv,
+                        int mode, int stitch, void* out_dev) {
+    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    if (H < 1 || W < 1) return fail(ctx, UMX_ERR_INVALID, "bad H/W");
+    const TileGeom g = geom_of(ctx->hp, H, W);
+    const size_t prob_b = (size_t)g.npr * g.npc * g.P * g.P * ctx->hp.nClasses * sizeof(float);
+    int rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if ((rc = grow(ctx, (void**)&ctx->d_probs, &ctx->probs_cap, prob_b))) return rc;
+    if ((rc = umx_band_tiles_dev(ctx, image_dev, C_img, H, W, 0, H, mean, stdv, 0, g.npr, ctx->d_probs))) return rc;
+    return umx_stitch_dev(ctx, ctx->d_probs, 0, g.npr, H, W, mode, stitch, 0, H, out_dev);
+}
+
+int umx_infer_image(umx_ctx* ctx, const double* image_host, int C_img, int H, int W, double mean, double stdv, int mode,
+                    int stitch, void* out_host) {
+    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    if (!image_host || !out_host || H < 1 || W < 1 || C_img < 1) return fail(ctx, UMX_ERR_INVALID, "bad image/out/H/W");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t img_b = (size_t)C_img * H * W * sizeof(double);
+    const size_t out_b = (size_t)ctx->hp.nClasses * H * W * (stitch == UMX_STITCH_FP32 ? 4 : 2);
+    int rc;
+    if ((rc = grow(ctx, (void**)&ctx->d_image, &ctx->image_cap, img_b))) return rc;
+    if ((rc = grow(ctx, &ctx->d_out, &ctx->out_cap, out_b))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_image, image_host, img_b, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = umx_infer_image_dev(ctx, ctx->d_image, C_img, H, W, mean, stdv, mode, stitch, ctx->d_out))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out_host, ctx->d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return UMX_OK;
+}
+
+int umx_profile_enable(umx_ctx* ctx, int on) {
+    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    int rc = prof_fold(ctx);
+    if (rc) return rc;
+    ctx->prof = on != 0;
+    for (auto& s : ctx->sites) { s.launches = 0; s.total_ms = 0; s.flops = 0; s.bytes = 0; }
+    return UMX_OK;
+}
+
+int umx_profile_read(umx_ctx* ctx, umx_prof_entry* entries, int max_entries, int* n_entries) {
+    if (!ctx || !n_entries) return fail(ctx, UMX_ERR_INVALID, "bad arguments");
+    int rc = prof_fold(ctx);
+    if (rc) return rc;
+    int n = 0;
+    for (auto& s : ctx->sites) {
+        if (s.launches == 0) continue;
+        if (entries && n < max_entries) {
+            umx_prof_entry& e = entries[n];
+            memset(&e, 0, sizeof e);
+            snprintf(e.name, sizeof e.name, "%s", s.name.c_str());
+            snprintf(e.kernel, sizeof e.kernel, "%s", s.kernel.c_str());
+            e.launches = s.launches;
+            e.total_ms = s.total_ms;
+            e.flops_per_launch_sum = s.flops;
+            e.bytes_per_launch_sum = s.bytes;
+        }
+        ++n;
+    }
+    *n_entries = n;
+    return UMX_OK;
+}
+
+}  // extern "C"

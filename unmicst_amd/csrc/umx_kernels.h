@@ -1,0 +1,105 @@
+// Internal kernel interface of libumx (gfx950 only). See DESIGN.md for the data layout and roofline of each kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace umx {
+
+constexpr int kWaves = 4;        // waves per workgroup (256 threads)
+constexpr int kMT = 4;           // 16-pixel M-tiles per wave
+constexpr int kMW = kWaves * kMT;  // 16 M-tiles (256 output pixels) per workgroup
+constexpr int kCC = 8;           // input channels staged per K-chunk
+constexpr int kTapG = 9;         // filter taps staged per weight stage
+constexpr int kMaxTaps = 100;    // flat tap table: two groups of <= 7x7, or 4 transposed-conv phases
+constexpr int kMaxNT = 6;        // 16-wide N-tiles per workgroup
+
+struct ConvPhase {
+    const float* w[2];   // packed weights per operand group: [ntaps][Cp][Np], zero padded
+    int tap0[2];         // first entry of this (phase, group) in ConvParams::tapoff
+    int ntaps[2];
+    int oy_off, ox_off;  // output offset (transposed-conv sub-pixel phase)
+};
+
+// One launch = one convolution-like layer: up to two operand groups (concat-free skip connection, or the
+// legacy 1x1 shortcut as an extra K slab), 1 or 4 output phases, fused epilogue.
+struct ConvParams {
+    const float* src[2];  // NHWC float32 [B,H,W,C]
+    int C[2], Cp[2];      // real channels, channels padded to a multiple of 4 (packed-weight K extent)
+    int vec4[2];          // 1: C % 4 == 0 -> 16-byte loads
+    int ngroups;
+    int B, H, W;          // compute grid == source grid
+    int Cout, Np;         // real output channels; padded width of the packed weights (multiple of 16)
+    int twm_log2, th_log2, nimg_m, imgs;  // M-tile = nimg_m images x 1 row x 2^twm_log2 cols; tile = imgs x TH x TWm
+    int hh, hw, imgplane, plane;         // LDS halo geometry (floats); plane = 16 (mod 32)
+    int ymin, xmin;                      // halo origin relative to the tile origin
+    int tiles_y, tiles_x;                // spatial tiles per image group
+    int nphase, o_mul;                   // 1 phase / o_mul 1 (conv) or 4 phases / o_mul 2 (stride-2 transposed conv)
+    ConvPhase ph[4];
+    short tapoff[kMaxTaps];              // LDS halo offset of each tap: (dy-ymin)*hw + (dx-xmin)
+    float* dst;                          // NHWC [B,outH,outW,Cout]
+    int outH, outW, pool;                // pool: fused 2x2/2 max-pool (outH = H/2)
+    const float* pre_s;                  // epilogue: v = acc*pre_s+pre_b ; act ; v = v*post_s+post_b (NULL = skip)
+    const float* pre_b;
+    const float* post_s;
+    const float* post_b;
+    int act;                             // 0 none, 1 ReLU, 2 LeakyReLU(0.2)
+};
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
+constexpr int kModeReplace = 1;   // == UMX_MODE_REPLACE
+
+size_t conv_lds_bytes(int nt, int plane);
+hipError_t launch_conv(const ConvParams& p, int nt, int hpix, hipStream_t stream);
+
+struct TileGeom {
+    int H, W;            // full image size
+    int P, margin, sub;  // patch size, margin, sub-patch
+    int npr, npc;        // patch rows / cols
+};
+
+hipError_t launch_gather_normalise(const double* image, int C_img, int band_row0, int band_rows, const TileGeom& g,
+                                   int Cn, double mean, double stdv, int tile0, int ntiles, float* tiles,
+                                   hipStream_t stream);
+
+hipError_t launch_head_softmax(const float* x, size_t npix, int C, int K, const float* w /*[C][K]*/,
+                               const float* scale, const float* bias, float* probs, hipStream_t stream);
+
+hipError_t launch_stitch(const float* probs, int tpr0, int tpr1, const TileGeom& g, int K, int mode, int stitch,
+                         int y0, int y1, void* out, hipStream_t stream);
+
+__host__ __device__ inline uint16_t double_to_half_rne(double d);
+
+}  // namespace umx
+
+// ---- correctly rounded (round-to-nearest-even) double -> IEEE binary16, the conversion numpy performs when a
+// float64 result is stored into a float16 array (reference PartitionOfImage.py:95-98: `Output[...] += P*W`).
+__host__ __device__ inline uint16_t umx::double_to_half_rne(double d) {
+    union { double f; uint64_t u; } v;
+    v.f = d;
+    const uint64_t u = v.u;
+    const uint16_t sign = (uint16_t)((u >> 48) & 0x8000u);
+    const int e = (int)((u >> 52) & 0x7FF);
+    const uint64_t mant = u & 0xFFFFFFFFFFFFFull;
+    if (e == 0x7FF) return (uint16_t)(sign | 0x7C00u | (mant ? 0x200u : 0u));  // inf / nan
+    const int eh = e - 1023 + 15;  // biased half exponent
+    if (eh >= 31) return (uint16_t)(sign | 0x7C00u);  // overflow -> inf (values >= 65520 after rounding handled below)
+    if (eh <= 0) {
+        // subnormal half or zero: value = 1.mant * 2^(e-1023); half subnormal unit = 2^-24
+        if (eh < -10) return sign;  // < 2^-25: rounds to zero (2^-25 exactly is a tie -> even = 0; slightly above handled below)
+        const uint64_t full = mant | (1ull << 52);  // 53-bit significand
+        const int shift = 52 - 10 + (1 - eh);       // bits to drop so that the unit becomes 2^-24
+        const uint64_t kept = full >> shift;
+        const uint64_t rem = full & ((1ull << shift) - 1);
+        const uint64_t half = 1ull << (shift - 1);
+        uint64_t r = kept;
+        if (rem > half || (rem == half && (kept & 1))) r += 1;
+        return (uint16_t)(sign | (uint16_t)r);  // may carry into the exponent field: that is the correct normal
+    }
+    uint64_t kept = mant >> 42;  // top 10 mantissa bits
+    const uint64_t rem = mant & ((1ull << 42) - 1);
+    const uint64_t half = 1ull << 41;
+    uint32_t h = ((uint32_t)eh << 10) | (uint32_t)kept;
+    if (rem > half || (rem == half && (kept & 1))) h += 1;  // carry propagates into the exponent correctly
+    if (h >= 0x7C00u) h = 0x7C00u;
+    return (uint16_t)(sign | h);
+}

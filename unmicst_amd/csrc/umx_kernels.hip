@@ -1,0 +1,542 @@
+// HIP kernels of libumx -- written for gfx950 (MI355X, CDNA4) only: 64-wide waves, v_mfma_f32_16x16x4_f32,
+// 160 KiB LDS per CU.  No other target is supported.
+#include "umx_kernels.h"
+
+#include <hip/hip_fp16.h>
+
+#include <algorithm>
+
+namespace umx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// LDS row pitch (floats) of the staged weight tile: NT*16 real columns, padded so that pitch = 16 (mod 32):
+// lanes (j, kq) of a B-fragment read hit bank j + 16*kq -> conflict-free ds_read_b32.
+__host__ __device__ constexpr int npl_of(int nt) { return (nt & 1) ? nt * 16 : nt * 16 + 16; }
+__host__ __device__ constexpr int wreg_of(int nt) { return (kTapG * kCC * nt * 4 + 255) / 256; }
+
+size_t conv_lds_bytes(int nt, int plane) {
+    return sizeof(float) * ((size_t)kCC * plane + (size_t)kTapG * kCC * npl_of(nt));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution on the fp32 matrix cores.
+//   GEMM view: M = output pixels (16 per M-tile, 256 per workgroup), N = output channels (NT tiles of 16 per
+//   workgroup), K = (tap, input channel).  No im2col buffer exists anywhere: the A operand is read straight out
+//   of an LDS-staged input halo at a per-tap offset.
+//   LDS: halo [kCC channel planes][plane] (channel-planar so that an A-fragment read -- 16 pixels x 2 channels per
+//   32-lane half -- is bank-conflict free), weights [tap][channel][npl].
+//   Pipeline: single LDS buffer; the next stage's global loads are issued into registers before the MFMA block
+//   of the current stage and written to LDS after it (issue-early / write-late); two workgroups per CU cover each
+//   other's barriers.
+// ------------------------------------------------------------------------------------------------------------
+template <int NT, int HPIX>
+__global__ void __launch_bounds__(256, 2) conv_mfma_f32(const ConvParams p) {
+    constexpr int NPL = npl_of(NT);
+    constexpr int WREG = wreg_of(NT);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const Hl = smem;                       // [kCC][plane]
+    float* const Wl = smem + kCC * p.plane;       // [kTapG*kCC][NPL]   (plane is a multiple of 16 -> 64 B aligned)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = lane >> 4;     // k index inside one 16x16x4 MFMA step
+    const int li = lane & 15;     // pixel (A) / output channel (B, C/D) index inside the tile
+
+    // ---- workgroup -> (image group, spatial tile), N block, phase
+    const int TWm = 1 << p.twm_log2, TH = 1 << p.th_log2;
+    int bid = blockIdx.x;
+    const int tx_i = bid % p.tiles_x; bid /= p.tiles_x;
+    const int ty_i = bid % p.tiles_y; bid /= p.tiles_y;
+    const int img0 = bid * p.imgs;
+    const int y0 = ty_i * TH, x0 = tx_i * TWm;
+    const int nblk = blockIdx.y;
+    const ConvPhase& ph = p.ph[blockIdx.z];
+
+    // ---- per-thread halo staging slots (constant for the whole kernel)
+    const int npix = p.imgs * p.imgplane;
+    int hpix[HPIX];   // source pixel index (img*H + y)*W + x, or -1 (zero fill)
+    int hlds[HPIX];   // LDS offset inside a channel plane, or -1 (slot unused)
+#pragma unroll
+    for (int s = 0; s < HPIX; ++s) {
+        const int e = s * 256 + tid;
+        hpix[s] = -1;
+        hlds[s] = -1;
+        if (e < npix) {
+            const int il = e / p.imgplane;
+            const int r = e - il * p.imgplane;
+            const int hy = r / p.hw;
+            const int hx = r - hy * p.hw;
+            const int gy = y0 + p.ymin + hy, gx = x0 + p.xmin + hx, img = img0 + il;
+            hlds[s] = e;
+            if (img < p.B && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) hpix[s] = (img * p.H + gy) * p.W + gx;
+        }
+    }
+
+    // ---- per-lane fragment base addresses
+    int abase[kMT];
+#pragma unroll
+    for (int m = 0; m < kMT; ++m) {
+        const int t = wave * kMT + m;
+        const int ig = t >> p.th_log2, ty = t & (TH - 1);
+        abase[m] = kq * p.plane + (ig * p.nimg_m + (li >> p.twm_log2)) * p.imgplane + ty * p.hw + (li & (TWm - 1));
+    }
+    const int bbase = kq * NPL + li;
+
+    f32x4 acc[kMT][NT];
+#pragma unroll
+    for (int m = 0; m < kMT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- stage iterator: (group, channel chunk, tap group)
+    struct Stage { int g, c0, t0; };
+    auto stage_valid = [&](const Stage& s) { return s.g < p.ngroups; };
+    auto stage_next = [&](Stage s) {
+        s.t0 += kTapG;
+        if (s.t0 >= ph.ntaps[s.g]) {
+            s.t0 = 0;
+            s.c0 += kCC;
+            if (s.c0 >= p.Cp[s.g]) { s.c0 = 0; s.g += 1; }
+        }
+        return s;
+    };
+
+    float4 hreg[HPIX][2];
+    float4 wreg[WREG];
+
+    auto load_stage = [&](const Stage& s) {
+        const int g = s.g;
+        const int nk4 = (p.Cp[g] - s.c0) >= kCC ? 2 : 1;
+        if (s.t0 == 0) {  // new channel chunk: (re)load the halo
+            const float* __restrict__ src = p.src[g];
+            const int C = p.C[g];
+#pragma unroll
+            for (int sl = 0; sl < HPIX; ++sl) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int c = s.c0 + 4 * q;
+                    if (q < nk4 && hpix[sl] >= 0) {
+                        const float* ptr = src + (size_t)hpix[sl] * C + c;
+                        if (p.vec4[g]) {
+                            if (c < C) v = *reinterpret_cast<const float4*>(ptr);
+                        } else {
+                            if (c + 0 < C) v.x = ptr[0];
+                            if (c + 1 < C) v.y = ptr[1];
+                            if (c + 2 < C) v.z = ptr[2];
+                            if (c + 3 < C) v.w = ptr[3];
+                        }
+                    }
+                    hreg[sl][q] = v;
+                }
+            }
+        }
+        // weights of taps [t0, t0+nt) x channels [c0, c0+4*nk4) x this N block
+        const int nt = min(kTapG, ph.ntaps[g] - s.t0);
+        const int ncs = nk4 + 1;  // log2(channels in chunk) : 4 -> 2, 8 -> 3
+        const int rows = nt << ncs;
+        const float* __restrict__ wsrc = ph.w[g] + ((size_t)(s.t0) * p.Cp[g] + s.c0) * p.Np + nblk * (NT * 16);
+#pragma unroll
+        for (int it = 0; it < WREG; ++it) {
+            const int e = it * 256 + tid;
+            const int row = e / (NT * 4);
+            const int n4 = e - row * (NT * 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < rows) {
+                const int tl = row >> ncs, c = row & ((1 << ncs) - 1);
+                v = *reinterpret_cast<const float4*>(wsrc + ((size_t)tl * p.Cp[g] + c) * p.Np + n4 * 4);
+            }
+            wreg[it] = v;
+        }
+    };
+
+    auto store_stage = [&](const Stage& s) {
+        const int g = s.g;
+        const int nk4 = (p.Cp[g] - s.c0) >= kCC ? 2 : 1;
+        if (s.t0 == 0) {
+#pragma unroll
+            for (int sl = 0; sl < HPIX; ++sl) {
+                if (hlds[sl] >= 0) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (q < nk4) {
+                            float* d = Hl + (4 * q) * p.plane + hlds[sl];
+                            d[0] = hreg[sl][q].x;
+                            d[p.plane] = hreg[sl][q].y;
+                            d[2 * p.plane] = hreg[sl][q].z;
+                            d[3 * p.plane] = hreg[sl][q].w;
+                        }
+                    }
+                }
+            }
+        }
+        const int nt = min(kTapG, ph.ntaps[g] - s.t0);
+        const int ncs = nk4 + 1;
+        const int rows = nt << ncs;
+#pragma unroll
+        for (int it = 0; it < WREG; ++it) {
+            const int e = it * 256 + tid;
+            const int row = e / (NT * 4);
+            const int n4 = e - row * (NT * 4);
+            if (row < rows) {
+                const int tl = row >> ncs, c = row & ((1 << ncs) - 1);
+                *reinterpret_cast<float4*>(Wl + (tl * kCC + c) * NPL + n4 * 4) = wreg[it];
+            }
+        }
+    };
+
+    Stage cur = {0, 0, 0};
+    while (stage_valid(cur) && ph.ntaps[cur.g] == 0) { cur.g += 1; }  // (a phase may have no taps in a group)
+    if (stage_valid(cur)) load_stage(cur);
+    while (stage_valid(cur)) {
+        __syncthreads();  // previous stage's LDS reads are done
+        store_stage(cur);
+        __syncthreads();
+        Stage nxt = stage_next(cur);
+        while (stage_valid(nxt) && ph.ntaps[nxt.g] == 0) { nxt.g += 1; }
+        if (stage_valid(nxt)) load_stage(nxt);  // in flight during the MFMA block below
+
+        const int g = cur.g;
+        const int nk4 = (p.Cp[g] - cur.c0) >= kCC ? 2 : 1;
+        const int nt = min(kTapG, ph.ntaps[g] - cur.t0);
+        const int tapbase = ph.tap0[g] + cur.t0;
+        for (int tl = 0; tl < nt; ++tl) {
+            const int aoff = p.tapoff[tapbase + tl];
+            for (int k4 = 0; k4 < nk4; ++k4) {
+                const float* ap = Hl + aoff + k4 * 4 * p.plane;
+                const float* bp = Wl + (tl * kCC + k4 * 4) * NPL + bbase;
+                float a[kMT], b[NT];
+#pragma unroll
+                for (int m = 0; m < kMT; ++m) a[m] = ap[abase[m]];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) b[n] = bp[n * 16];
+#pragma unroll
+                for (int m = 0; m < kMT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
+            }
+        }
+        cur = nxt;
+    }
+
+    // ---- epilogue: affine / activation / affine / (2x2 max-pool) / NHWC store
+    // C/D layout of the 16x16 tile: column (output channel) = lane & 15, row (pixel) = 4*(lane>>4) + reg.
+    const int ncol0 = nblk * (NT * 16) + li;
+    float ps[NT], pb[NT], qs[NT], qb[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = ncol0 + n * 16;
+        const bool ok = co < p.Cout;
+        ps[n] = (p.pre_s && ok) ? p.pre_s[co] : 1.f;
+        pb[n] = (p.pre_b && ok) ? p.pre_b[co] : 0.f;
+        qs[n] = (p.post_s && ok) ? p.post_s[co] : 1.f;
+        qb[n] = (p.post_b && ok) ? p.post_b[co] : 0.f;
+    }
+#pragma unroll
+    for (int m = 0; m < kMT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[m][n][r] * ps[n] + pb[n];
+                if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                else if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.2f * v;
+                acc[m][n][r] = v * qs[n] + qb[n];
+            }
+
+    if (p.pool) {
+#pragma unroll
+        for (int m = 0; m < kMT; m += 2) {
+            const int t = wave * kMT + m;
+            const int ig = t >> p.th_log2, ty = t & (TH - 1);
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                const int i = 4 * kq + r;
+                const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
+                const int oy = (y0 + ty) >> 1, ox = (x0 + (i & (TWm - 1))) >> 1;
+                if (img < p.B) {
+                    float* d = p.dst + ((size_t)(img * p.outH + oy) * p.outW + ox) * p.Cout;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int co = ncol0 + n * 16;
+                        const float v = fmaxf(fmaxf(acc[m][n][r], acc[m][n][r + 1]),
+                                              fmaxf(acc[m + 1][n][r], acc[m + 1][n][r + 1]));
+                        if (co < p.Cout) d[co] = v;
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) {
+            const int t = wave * kMT + m;
+            const int ig = t >> p.th_log2, ty = t & (TH - 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 4 * kq + r;
+                const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
+                const int oy = (y0 + ty) * p.o_mul + ph.oy_off, ox = (x0 + (i & (TWm - 1))) * p.o_mul + ph.ox_off;
+                if (img < p.B) {
+                    float* d = p.dst + ((size_t)(img * p.outH + oy) * p.outW + ox) * p.Cout;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int co = ncol0 + n * 16;
+                        if (co < p.Cout) d[co] = acc[m][n][r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NT>
+static hipError_t launch_conv_nt(const ConvParams& p, int hpix, hipStream_t stream) {
+    const int img_groups = (p.B + p.imgs - 1) / p.imgs;
+    dim3 grid((unsigned)(img_groups * p.tiles_y * p.tiles_x), (unsigned)((p.Np / 16 + NT - 1) / NT), (unsigned)p.nphase);
+    const size_t lds = conv_lds_bytes(NT, p.plane);
+    auto go = [&](auto kern) -> hipError_t {
+        if (lds > 48 * 1024) {  // opt in to large dynamic LDS (160 KiB per CU on gfx950)
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+        return hipSuccess;
+    };
+    hipError_t e;
+    if (hpix <= 2) e = go(conv_mfma_f32<NT, 2>);
+    else if (hpix <= 4) e = go(conv_mfma_f32<NT, 4>);
+    else return hipErrorInvalidValue;
+    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+hipError_t launch_conv(const ConvParams& p, int nt, int hpix, hipStream_t stream) {
+    switch (nt) {
+        case 1: return launch_conv_nt<1>(p, hpix, stream);
+        case 2: return launch_conv_nt<2>(p, hpix, stream);
+        case 3: return launch_conv_nt<3>(p, hpix, stream);
+        case 4: return launch_conv_nt<4>(p, hpix, stream);
+        case 5: return launch_conv_nt<5>(p, hpix, stream);
+        case 6: return launch_conv_nt<6>(p, hpix, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// PI2D.getPatch + per-tile normalisation + batch fill (reference PartitionOfImage.py:58-63,77-82 and
+// UnMicst1-5.py:700-702 / UnMicst2.py:679-681 / UnMicst.py:533): tiles[n,y,x,c] = float((padded[c][r][q] - mean)/std),
+// padded = image at offset (margin, margin) in a zero canvas.  The padded float64 canvas is never materialised.
+// HBM streaming: 8 B read + 4*Cn B written per tile pixel.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gather_normalise_kernel(const double* __restrict__ image, int C_img,
+                                                              int band_row0, int band_rows, TileGeom g, int Cn,
+                                                              double mean, double stdv, int tile0, int ntiles,
+                                                              float* __restrict__ tiles) {
+    const size_t total = (size_t)ntiles * g.P * g.P;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(e % g.P);
+        const size_t r1 = e / g.P;
+        const int y = (int)(r1 % g.P);
+        const int tl = (int)(r1 / g.P);
+        const int t = tile0 + tl;
+        const int pr = t / g.npc, pc = t - pr * g.npc;
+        const int iy = pr * g.sub + y - g.margin;   // image row
+        const int ix = pc * g.sub + x - g.margin;
+        const bool inside = iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+        float* d = tiles + e * Cn;
+        for (int c = 0; c < Cn; ++c) {
+            double v = 0.0;
+            if (inside) {
+                const int ci = C_img == 1 ? 0 : c;
+                v = image[((size_t)ci * band_rows + (iy - band_row0)) * g.W + ix];
+            }
+            d[c] = (float)((v - mean) / stdv);
+        }
+    }
+}
+
+hipError_t launch_gather_normalise(const double* image, int C_img, int band_row0, int band_rows, const TileGeom& g,
+                                   int Cn, double mean, double stdv, int tile0, int ntiles, float* tiles,
+                                   hipStream_t stream) {
+    if (ntiles <= 0) return hipSuccess;
+    const size_t total = (size_t)ntiles * g.P * g.P;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(gather_normalise_kernel, dim3(blocks), dim3(256), 0, stream, image, C_img, band_row0, band_rows,
+                       g, Cn, mean, stdv, tile0, ntiles, tiles);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Top layer: 1x1 conv (C -> K) + optional BN affine + softmax (reference UnMicst1-5.py:212-222,236-237;
+// UnMicst.py:167-171,186).  HBM streaming: 4*C B read + 4*K B written per pixel.
+// ------------------------------------------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(256) head_softmax_kernel(const float* __restrict__ x, size_t npix, int C,
+                                                          const float* __restrict__ w, const float* __restrict__ scale,
+                                                          const float* __restrict__ bias, float* __restrict__ probs) {
+    extern __shared__ float wl[];  // [C][K]
+    for (int i = threadIdx.x; i < C * K; i += blockDim.x) wl[i] = w[i];
+    __syncthreads();
+    for (size_t px = (size_t)blockIdx.x * blockDim.x + threadIdx.x; px < npix; px += (size_t)gridDim.x * blockDim.x) {
+        const float* xp = x + px * C;
+        float acc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[k] = 0.f;
+        if ((C & 3) == 0) {
+            for (int c = 0; c < C; c += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(xp + c);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    acc[k] = fmaf(v.x, wl[(c + 0) * K + k], acc[k]);
+                    acc[k] = fmaf(v.y, wl[(c + 1) * K + k], acc[k]);
+                    acc[k] = fmaf(v.z, wl[(c + 2) * K + k], acc[k]);
+                    acc[k] = fmaf(v.w, wl[(c + 3) * K + k], acc[k]);
+                }
+            }
+        } else {
+            for (int c = 0; c < C; ++c) {
+                const float v = xp[c];
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc[k] = fmaf(v, wl[c * K + k], acc[k]);
+            }
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (scale) acc[k] = acc[k] * scale[k] + bias[k];
+            m = fmaxf(m, acc[k]);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            acc[k] = expf(acc[k] - m);
+            s += acc[k];
+        }
+        const float inv = 1.f / s;
+#pragma unroll
+        for (int k = 0; k < K; ++k) probs[px * K + k] = acc[k] * inv;
+    }
+}
+
+hipError_t launch_head_softmax(const float* x, size_t npix, int C, int K, const float* w, const float* scale,
+                               const float* bias, float* probs, hipStream_t stream) {
+    if (npix == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>((npix + 255) / 256, 256 * 16);
+    const size_t lds = sizeof(float) * (size_t)C * K;
+    switch (K) {
+        case 2: hipLaunchKernelGGL(head_softmax_kernel<2>, dim3(blocks), dim3(256), lds, stream, x, npix, C, w, scale, bias, probs); break;
+        case 3: hipLaunchKernelGGL(head_softmax_kernel<3>, dim3(blocks), dim3(256), lds, stream, x, npix, C, w, scale, bias, probs); break;
+        case 4: hipLaunchKernelGGL(head_softmax_kernel<4>, dim3(blocks), dim3(256), lds, stream, x, npix, C, w, scale, bias, probs); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// PI2D.patchOutput + getValidOutput as a gather (reference PartitionOfImage.py:92-122): every output pixel visits
+// its <= 4 covering tiles in ascending tile index -- the order of the reference's sequential `+=` loop -- so the
+// float16 accumulators see the same sequence of roundings.  fp16-compat: Count = fp16(double(Count) + W),
+// Output = fp16(double(Output) + double(P)*W) per tile, result = fp16(float(Output)/float(Count)) (numpy's
+// float16 divide runs in float32).  fp32 mode: blend in double, one rounding to float32.
+// HBM streaming: <= 4*K*4 B read per pixel (1.78*K*4 on average), 2*K (or 4*K) B written.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double blend_weight(int r, int c, int P, int two_m) {
+    const int d = min(min(r, c), min(P - 1 - r, P - 1 - c));   // ring index, reference PartitionOfImage.py:30-38
+    if (d == 0) return 0.0;
+    if (d >= two_m) return 1.0;
+    return (double)d / (double)two_m;
+}
+
+template <int K>
+__global__ void __launch_bounds__(256) stitch_kernel(const float* __restrict__ probs, int tpr0, int tpr1, TileGeom g,
+                                                    int mode, int stitch, int y0, int y1, void* __restrict__ out) {
+    const int rows = y1 - y0;
+    const size_t total = (size_t)rows * g.W;
+    const int two_m = 2 * g.margin;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(e % g.W);
+        const int y = y0 + (int)(e / g.W);
+        const int R = y + g.margin, Cc = x + g.margin;  // padded coordinates
+        // covering patch rows: pr*sub <= R < pr*sub + P
+        int pr_hi = R / g.sub;
+        if (pr_hi > g.npr - 1) pr_hi = g.npr - 1;
+        int pr_lo = (R - g.P + g.sub) / g.sub;  // ceil((R-P+1)/sub) for R-P+1 possibly negative
+        if (R - g.P + 1 <= 0) pr_lo = 0;
+        int pc_hi = Cc / g.sub;
+        if (pc_hi > g.npc - 1) pc_hi = g.npc - 1;
+        int pc_lo = (Cc - g.P + g.sub) / g.sub;
+        if (Cc - g.P + 1 <= 0) pc_lo = 0;
+
+        if (mode == kModeReplace) {
+            // last tile in index order wins: Output[tile] = P (float32 -> float16 store), no Count
+            const int pr = pr_hi, pc = pc_hi;
+            const int r = R - pr * g.sub, c = Cc - pc * g.sub;
+            const float* pp = probs + ((((size_t)(pr - tpr0) * g.npc + pc) * g.P + r) * g.P + c) * K;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (stitch == 0) ((__half*)out)[((size_t)k * rows + (y - y0)) * g.W + x] = __float2half_rn(pp[k]);
+                else ((float*)out)[((size_t)k * rows + (y - y0)) * g.W + x] = pp[k];
+            }
+            continue;
+        }
+
+        if (stitch == 0) {
+            uint16_t cnt = 0;
+            uint16_t o[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) o[k] = 0;
+            for (int pr = pr_lo; pr <= pr_hi; ++pr)
+                for (int pc = pc_lo; pc <= pc_hi; ++pc) {
+                    const int r = R - pr * g.sub, c = Cc - pc * g.sub;
+                    const double w = blend_weight(r, c, g.P, two_m);
+                    const float* pp = probs + ((((size_t)(pr - tpr0) * g.npc + pc) * g.P + r) * g.P + c) * K;
+                    cnt = double_to_half_rne((double)__half2float(__ushort_as_half(cnt)) + w);
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+                        o[k] = double_to_half_rne((double)__half2float(__ushort_as_half(o[k])) + (double)pp[k] * w);
+                }
+            const float cf = __half2float(__ushort_as_half(cnt));
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float q = __half2float(__ushort_as_half(o[k])) / cf;   // IEEE float32 division
+                ((__half*)out)[((size_t)k * rows + (y - y0)) * g.W + x] = __float2half_rn(q);
+            }
+        } else {
+            double cnt = 0.0;
+            double o[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) o[k] = 0.0;
+            for (int pr = pr_lo; pr <= pr_hi; ++pr)
+                for (int pc = pc_lo; pc <= pc_hi; ++pc) {
+                    const int r = R - pr * g.sub, c = Cc - pc * g.sub;
+                    const double w = blend_weight(r, c, g.P, two_m);
+                    const float* pp = probs + ((((size_t)(pr - tpr0) * g.npc + pc) * g.P + r) * g.P + c) * K;
+                    cnt += w;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) o[k] += (double)pp[k] * w;
+                }
+#pragma unroll
+            for (int k = 0; k < K; ++k) ((float*)out)[((size_t)k * rows + (y - y0)) * g.W + x] = (float)(o[k] / cnt);
+        }
+    }
+}
+
+hipError_t launch_stitch(const float* probs, int tpr0, int tpr1, const TileGeom& g, int K, int mode, int stitch,
+                         int y0, int y1, void* out, hipStream_t stream) {
+    if (y1 <= y0) return hipSuccess;
+    const size_t total = (size_t)(y1 - y0) * g.W;
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 16);
+    switch (K) {
+        case 2: hipLaunchKernelGGL(stitch_kernel<2>, dim3(blocks), dim3(256), 0, stream, probs, tpr0, tpr1, g, mode, stitch, y0, y1, out); break;
+        case 3: hipLaunchKernelGGL(stitch_kernel<3>, dim3(blocks), dim3(256), 0, stream, probs, tpr0, tpr1, g, mode, stitch, y0, y1, out); break;
+        case 4: hipLaunchKernelGGL(stitch_kernel<4>, dim3(blocks), dim3(256), 0, stream, probs, tpr0, tpr1, g, mode, stitch, y0, y1, out); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace umx

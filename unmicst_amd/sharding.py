@@ -1,0 +1,150 @@
+"""Whole-slide inference sharded over the GPUs of one node: one process per GPU, torch.distributed (RCCL over xGMI).
+
+The reference has no multi-device path at all (one process, one device: UnMicst1-5.py:769).  Tiles are independent
+units; the only coupling is the overlap-add stitch (each output pixel is covered by <= 4 tiles), so:
+
+* patch rows are split into contiguous bands, one per rank (``band_partition``);
+* rank r computes the tile probabilities of its patch rows [pa, pb) from the image rows it holds;
+* ONE exchange step: rank r sends the probabilities of its LAST patch row to rank r+1 (the 2*margin image rows
+  below a band boundary are covered by patch rows pb-1 and pb);
+* rank r stitches the image rows it owns -- padded rows [pa*sub, pb*sub) -- visiting covering tiles in ascending
+  global tile index, exactly like the single-GPU kernel, so the float16 result is bit-identical to a 1-GPU run;
+* the stitched bands are all-gathered (``dist.all_gather_into_tensor`` on equal-size padded bands).
+
+The engine object only needs ``hp``, ``tile_grid``, ``band_tiles_dev``, ``stitch_dev`` -- tests drive the same host
+logic on CPU (gloo) with an oracle-backed stand-in.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+from . import umx
+
+
+def band_partition(npr: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous, balanced split of patch rows [0, npr) over ``world`` ranks (ranks >= npr get empty bands)."""
+    active = min(world, npr)
+    base, extra = divmod(npr, active) if active else (0, 0)
+    out = []
+    start = 0
+    for r in range(world):
+        n = (base + (1 if r < extra else 0)) if r < active else 0
+        out.append((start, start + n))
+        start += n
+    return out
+
+
+def owned_rows(pa: int, pb: int, npr: int, sub: int, margin: int, H: int) -> Tuple[int, int]:
+    """Image rows stitched by the rank holding patch rows [pa, pb): padded rows [pa*sub, pb*sub) minus the margin,
+    the first band starting at row 0 and the last one running to H."""
+    if pa >= pb:
+        return (0, 0)
+    y0 = 0 if pa == 0 else min(H, max(0, pa * sub - margin))
+    y1 = H if pb == npr else min(H, max(0, pb * sub - margin))
+    return (y0, y1)
+
+
+def needed_image_rows(pa: int, pb: int, sub: int, margin: int, patch: int, H: int) -> Tuple[int, int]:
+    """Image rows that the tiles of patch rows [pa, pb) read (what a rank must hold in HBM)."""
+    if pa >= pb:
+        return (0, 0)
+    return (max(0, pa * sub - margin), min(H, (pb - 1) * sub + patch - margin))
+
+
+def _geometry(eng, H: int, W: int):
+    hp = eng.hp
+    npr, npc, _, _ = eng.tile_grid(H, W)
+    margin = int(hp.imSize / 8)
+    return npr, npc, margin, hp.imSize - 2 * margin
+
+
+def infer_band_local(eng, d_image, mean: float, std: float, rank: int, world: int, mode: int, stitch: int):
+    """What rank ``rank`` of ``world`` produces, computed stand-alone (the previous band's last patch row is
+    recomputed instead of received).  Used by the 1-GPU bit-equality test and as the world_size == 1 path."""
+    import torch
+    hp = eng.hp
+    C, H, W = d_image.shape
+    npr, npc, margin, sub = _geometry(eng, H, W)
+    pa, pb = band_partition(npr, world)[rank]
+    y0, y1 = owned_rows(pa, pb, npr, sub, margin, H)
+    out_dtype = torch.float32 if stitch == umx.STITCH_FP32 else torch.float16
+    out = torch.empty((hp.nClasses, y1 - y0, W), dtype=out_dtype, device=d_image.device)
+    if pa >= pb or y1 <= y0:
+        return out
+    lo = max(0, pa - 1)
+    probs = torch.empty(((pb - lo) * npc, hp.imSize, hp.imSize, hp.nClasses), dtype=torch.float32,
+                        device=d_image.device)
+    eng.band_tiles_dev(d_image.data_ptr(), C, H, W, 0, H, mean, std, lo, pb, probs.data_ptr())
+    eng.stitch_dev(probs.data_ptr(), lo, pb, H, W, mode, stitch, y0, y1, out.data_ptr())
+    eng.synchronize()
+    return out
+
+
+def infer_image_sharded(eng, d_band, band_row0: int, H: int, W: int, mean: float, std: float, mode: int, stitch: int,
+                        group=None, gather: bool = True):
+    """Distributed whole-slide inference.  Every rank calls this with the image rows it holds.
+
+    d_band: float64 tensor [C, band_rows, W] = image rows [band_row0, band_row0+band_rows) (must cover
+    ``needed_image_rows`` of this rank's patch rows).  Returns the full [K, H, W] result on every rank
+    (``gather=True``) or this rank's stitched band and its (y0, y1).
+    """
+    import torch
+    import torch.distributed as dist
+    hp = eng.hp
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    C, band_rows, _ = d_band.shape
+    npr, npc, margin, sub = _geometry(eng, H, W)
+    bands = band_partition(npr, world)
+    pa, pb = bands[rank]
+    active = [r for r in range(world) if bands[r][0] < bands[r][1]]
+    y0, y1 = owned_rows(pa, pb, npr, sub, margin, H)
+    dev = d_band.device
+    out_dtype = torch.float32 if stitch == umx.STITCH_FP32 else torch.float16
+    P, K = hp.imSize, hp.nClasses
+
+    has_prev = pa < pb and pa > 0
+    has_next = pa < pb and pb < npr
+    lo = pa - 1 if has_prev else pa
+    probs = torch.empty((max(pb - lo, 0) * npc, P, P, K), dtype=torch.float32, device=dev)
+    if pa < pb:
+        own = probs[(pa - lo) * npc:]
+        eng.band_tiles_dev(d_band.data_ptr(), C, H, W, band_row0, band_rows, mean, std, pa, pb, own.data_ptr())
+        eng.synchronize()
+    # the one exchange step of the path: last patch row of rank r -> rank r+1 (point-to-point over xGMI)
+    reqs = []
+    if has_next:
+        nxt = active[active.index(rank) + 1]
+        reqs.append(dist.isend(probs[-npc:].contiguous(), dst=dist.get_global_rank(group, nxt) if group else nxt,
+                               group=group))
+    if has_prev:
+        prv = active[active.index(rank) - 1]
+        reqs.append(dist.irecv(probs[:npc], src=dist.get_global_rank(group, prv) if group else prv, group=group))
+    for r in reqs:
+        r.wait()
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()
+
+    band = torch.empty((K, y1 - y0, W), dtype=out_dtype, device=dev)
+    if y1 > y0:
+        eng.stitch_dev(probs.data_ptr(), lo, pb, H, W, mode, stitch, y0, y1, band.data_ptr())
+        eng.synchronize()
+    if not gather:
+        return band, (y0, y1)
+
+    # all-gather of equal-size (padded) stitched bands, then drop the padding
+    rows = [owned_rows(a, b, npr, sub, margin, H) for a, b in bands]
+    max_rows = max(1, max(b - a for a, b in rows))
+    padded = torch.zeros((K, max_rows, W), dtype=out_dtype, device=dev)
+    padded[:, :y1 - y0] = band
+    gathered = torch.empty((world, K, max_rows, W), dtype=out_dtype, device=dev)
+    if out_dtype == torch.float16 and dev.type == "cpu":
+        # gloo has no float16 all_gather on every build: move the bit patterns as int16
+        dist.all_gather_into_tensor(gathered.view(torch.int16), padded.view(torch.int16), group=group)
+    else:
+        dist.all_gather_into_tensor(gathered, padded, group=group)
+    full = torch.empty((K, H, W), dtype=out_dtype, device=dev)
+    for r, (a, b) in enumerate(rows):
+        if b > a:
+            full[:, a:b] = gathered[r, :, :b - a]
+    return full

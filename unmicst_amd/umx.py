@@ -1,0 +1,256 @@
+"""ctypes binding of libumx.so (include/umx.h) -- the thin shim between Python and the HIP engine.
+
+There is deliberately no fallback: if the shared library is missing or no gfx950 device is present the calls
+raise, they never route to a CPU path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import List, Optional
+
+import numpy as np
+
+from . import build as _build
+from .model import HParams
+
+UMX_OK = 0
+MODE_ACCUMULATE, MODE_REPLACE = 0, 1
+STITCH_FP16_COMPAT, STITCH_FP32 = 0, 1
+
+# every symbol include/umx.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "umx_device_count", "umx_create", "umx_destroy", "umx_last_error", "umx_set_stream", "umx_synchronize",
+    "umx_forward_tiles", "umx_forward_tiles_dev", "umx_tile_grid", "umx_infer_image", "umx_infer_image_dev",
+    "umx_band_tiles_dev", "umx_stitch_dev", "umx_profile_enable", "umx_profile_read", "umx_test_double_to_half",
+    "umx_describe", "umx_version",
+]
+
+
+class UmxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("libumx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class _HP(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("graph", "imSize", "nChannels", "nClasses", "nOut0", "nLayers", "ks", "nExtraConvs", "featMapsFact")]
+
+
+class ProfEntry(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 48), ("kernel", ctypes.c_char * 48), ("launches", ctypes.c_int64),
+                ("total_ms", ctypes.c_double), ("flops", ctypes.c_double), ("bytes", ctypes.c_double)]
+
+
+_lib = None
+
+
+def _bind_hip_runtime() -> str:
+    """Make exactly one HIP runtime (libamdhip64) global in this process before libumx is dlopen'ed.
+
+    libumx.so is linked without a HIP runtime dependency.  PyTorch wheels bundle their own libamdhip64 +
+    libhsa-runtime64; a second copy (e.g. /opt/rocm's) initialised in the same process leaves one of the two
+    without a GPU.  Policy (UMX_HIP_RUNTIME = auto | torch | system, default auto): use PyTorch's copy whenever
+    PyTorch is importable -- the multi-GPU path and bench.py need torch.distributed in the same process -- else
+    the system ROCm runtime.
+    """
+    mode = os.environ.get("UMX_HIP_RUNTIME", "auto")
+    if mode in ("auto", "torch"):
+        try:
+            import torch  # noqa: F401  (loads its bundled libamdhip64.so)
+            cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+                return cand
+        except ImportError:
+            if mode == "torch":
+                raise
+    for cand in (os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "libamdhip64.so"), "libamdhip64.so.7",
+                 "libamdhip64.so"):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+            return cand
+        except OSError:
+            continue
+    raise OSError("no HIP runtime (libamdhip64) found; libumx has no CPU fallback")
+
+
+def load(path: Optional[str] = None):
+    """dlopen libumx.so (built in-tree by unmicst_amd.build); raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or _build.lib_path()
+    if not os.path.exists(path):
+        raise FileNotFoundError("%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(libumx has no CPU fallback)" % path)
+    _bind_hip_runtime()
+    L = ctypes.CDLL(path)
+    c_int, c_void_p, c_double = ctypes.c_int, ctypes.c_void_p, ctypes.c_double
+    ip = ctypes.POINTER(c_int)
+    L.umx_device_count.restype = c_int
+    L.umx_create.restype = c_int
+    L.umx_create.argtypes = [ctypes.POINTER(_HP), c_void_p, ctypes.c_size_t, c_int, c_int, ctypes.POINTER(c_void_p)]
+    L.umx_destroy.restype = None
+    L.umx_destroy.argtypes = [c_void_p]
+    L.umx_last_error.restype = ctypes.c_char_p
+    L.umx_last_error.argtypes = [c_void_p]
+    L.umx_set_stream.argtypes = [c_void_p, c_void_p]
+    L.umx_synchronize.argtypes = [c_void_p]
+    L.umx_forward_tiles.argtypes = [c_void_p, c_void_p, c_int, c_void_p]
+    L.umx_forward_tiles_dev.argtypes = [c_void_p, c_void_p, c_int, c_void_p]
+    L.umx_tile_grid.argtypes = [c_void_p, c_int, c_int, ip, ip, ip, ip]
+    L.umx_infer_image.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_int, c_int, c_void_p]
+    L.umx_infer_image_dev.argtypes = L.umx_infer_image.argtypes
+    L.umx_band_tiles_dev.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_double,
+                                     c_int, c_int, c_void_p]
+    L.umx_stitch_dev.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    L.umx_profile_enable.argtypes = [c_void_p, c_int]
+    L.umx_profile_read.argtypes = [c_void_p, ctypes.POINTER(ProfEntry), c_int, ip]
+    L.umx_test_double_to_half.restype = None
+    L.umx_test_double_to_half.argtypes = [c_void_p, c_void_p, ctypes.c_size_t]
+    L.umx_describe.argtypes = [ctypes.POINTER(_HP), ip, ctypes.POINTER(c_double), ctypes.POINTER(c_double)]
+    L.umx_version.restype = ctypes.c_char_p
+    for name in ("umx_set_stream", "umx_synchronize", "umx_forward_tiles", "umx_forward_tiles_dev", "umx_tile_grid",
+                 "umx_infer_image", "umx_infer_image_dev", "umx_band_tiles_dev", "umx_stitch_dev",
+                 "umx_profile_enable", "umx_profile_read", "umx_describe"):
+        getattr(L, name).restype = c_int
+    _lib = L
+    return L
+
+
+def _hp_struct(hp: HParams) -> _HP:
+    return _HP(hp.graph, hp.imSize, hp.nChannels, hp.nClasses, hp.nOut0, hp.nLayers, hp.ks, hp.nExtraConvs,
+               hp.featMapsFact)
+
+
+def device_count() -> int:
+    return int(load().umx_device_count())
+
+
+def describe(hp: HParams) -> dict:
+    n, f, e = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+    h = _hp_struct(hp)
+    rc = load().umx_describe(ctypes.byref(h), ctypes.byref(n), ctypes.byref(f), ctypes.byref(e))
+    if rc:
+        raise UmxError(rc, load().umx_last_error(None).decode())
+    return {"launches": n.value, "flops_per_tile": f.value, "executed_flops_per_tile": e.value}
+
+
+def double_to_half(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.empty(x.shape, np.uint16)
+    load().umx_test_double_to_half(x.ctypes.data, out.ctypes.data, x.size)
+    return out.view(np.float16)
+
+
+class Engine:
+    """One umx_ctx: a model resident on one MI355X."""
+
+    def __init__(self, hp: HParams, blob: np.ndarray, device: int = 0, max_batch: int = 32):
+        self._L = load()
+        self.hp = hp
+        self._ctx = ctypes.c_void_p()
+        blob = np.ascontiguousarray(blob, dtype="<f4")
+        h = _hp_struct(hp)
+        rc = self._L.umx_create(ctypes.byref(h), blob.ctypes.data, blob.size, int(device), int(max_batch),
+                                ctypes.byref(self._ctx))
+        if rc:
+            raise UmxError(rc, self._L.umx_last_error(None).decode())
+        self.device = device
+        self.max_batch = max_batch
+
+    # -- lifetime
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._L.umx_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc: int) -> None:
+        if rc:
+            raise UmxError(rc, self._L.umx_last_error(self._ctx).decode())
+
+    # -- plumbing
+    def set_stream(self, hip_stream: int) -> None:
+        self._check(self._L.umx_set_stream(self._ctx, ctypes.c_void_p(hip_stream)))
+
+    def synchronize(self) -> None:
+        self._check(self._L.umx_synchronize(self._ctx))
+
+    def tile_grid(self, H: int, W: int):
+        a, b, c, d = (ctypes.c_int() for _ in range(4))
+        self._check(self._L.umx_tile_grid(self._ctx, H, W, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c),
+                                          ctypes.byref(d)))
+        return a.value, b.value, c.value, d.value
+
+    # -- host-pointer API
+    def forward_tiles(self, tiles: np.ndarray) -> np.ndarray:
+        """== Session.run(UNet2D.nn, {tfData: tiles, tfTraining: 0}) (reference UnMicst1-5.py:704)."""
+        hp = self.hp
+        tiles = np.ascontiguousarray(tiles, dtype=np.float32)
+        if tiles.ndim != 4 or tiles.shape[1:] != (hp.imSize, hp.imSize, hp.nChannels):
+            raise ValueError("tiles must be [n,%d,%d,%d]" % (hp.imSize, hp.imSize, hp.nChannels))
+        out = np.empty((tiles.shape[0], hp.imSize, hp.imSize, hp.nClasses), np.float32)
+        self._check(self._L.umx_forward_tiles(self._ctx, tiles.ctypes.data, tiles.shape[0], out.ctypes.data))
+        return out
+
+    def infer_image(self, image: np.ndarray, mean: float, std: float, mode: int = MODE_ACCUMULATE,
+                    stitch: int = STITCH_FP16_COMPAT) -> np.ndarray:
+        """All-class whole-image inference: image float64 (H,W) or (C,H,W) -> [K,H,W] float16 / float32."""
+        image = np.ascontiguousarray(image, dtype=np.float64)
+        if image.ndim == 2:
+            image = image[None]
+        if image.ndim != 3:
+            raise ValueError("image must be (H,W) or (C,H,W)")
+        C, H, W = image.shape
+        out = np.empty((self.hp.nClasses, H, W), np.float32 if stitch == STITCH_FP32 else np.float16)
+        self._check(self._L.umx_infer_image(self._ctx, image.ctypes.data, C, H, W, float(mean), float(std), int(mode),
+                                            int(stitch), out.ctypes.data))
+        return out
+
+    # -- device-pointer API (pointers are plain ints, e.g. torch.Tensor.data_ptr())
+    def forward_tiles_dev(self, tiles_ptr: int, n: int, probs_ptr: int) -> None:
+        self._check(self._L.umx_forward_tiles_dev(self._ctx, ctypes.c_void_p(tiles_ptr), n, ctypes.c_void_p(probs_ptr)))
+
+    def infer_image_dev(self, image_ptr: int, C: int, H: int, W: int, mean: float, std: float, mode: int, stitch: int,
+                        out_ptr: int) -> None:
+        self._check(self._L.umx_infer_image_dev(self._ctx, ctypes.c_void_p(image_ptr), C, H, W, float(mean),
+                                                float(std), mode, stitch, ctypes.c_void_p(out_ptr)))
+
+    def band_tiles_dev(self, image_ptr: int, C: int, H: int, W: int, band_row0: int, band_rows: int, mean: float,
+                       std: float, pr0: int, pr1: int, probs_ptr: int) -> None:
+        self._check(self._L.umx_band_tiles_dev(self._ctx, ctypes.c_void_p(image_ptr), C, H, W, band_row0, band_rows,
+                                               float(mean), float(std), pr0, pr1, ctypes.c_void_p(probs_ptr)))
+
+    def stitch_dev(self, probs_ptr: int, tpr0: int, tpr1: int, H: int, W: int, mode: int, stitch: int, y0: int,
+                   y1: int, out_ptr: int) -> None:
+        self._check(self._L.umx_stitch_dev(self._ctx, ctypes.c_void_p(probs_ptr), tpr0, tpr1, H, W, mode, stitch, y0,
+                                           y1, ctypes.c_void_p(out_ptr)))
+
+    # -- profiling
+    def profile_enable(self, on: bool) -> None:
+        self._check(self._L.umx_profile_enable(self._ctx, 1 if on else 0))
+
+    def profile_read(self) -> List[dict]:
+        n = ctypes.c_int()
+        arr = (ProfEntry * 256)()
+        self._check(self._L.umx_profile_read(self._ctx, arr, 256, ctypes.byref(n)))
+        out = []
+        for i in range(min(n.value, 256)):
+            e = arr[i]
+            out.append({"name": e.name.decode(), "kernel": e.kernel.decode(), "launches": int(e.launches),
+                        "total_ms": float(e.total_ms), "flops": float(e.flops), "bytes": float(e.bytes)})
+        return out
