@@ -19,6 +19,8 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
+    if os.path.getmtime(os.path.abspath(__file__)) > t:
+        return True
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 

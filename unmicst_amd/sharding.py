@@ -137,12 +137,13 @@ def infer_image_sharded(eng, d_band, band_row0: int, H: int, W: int, mean: float
     max_rows = max(1, max(b - a for a, b in rows))
     padded = torch.zeros((K, max_rows, W), dtype=out_dtype, device=dev)
     padded[:, :y1 - y0] = band
-    gathered = torch.empty((world, K, max_rows, W), dtype=out_dtype, device=dev)
-    if out_dtype == torch.float16 and dev.type == "cpu":
-        # gloo has no float16 all_gather on every build: move the bit patterns as int16
-        dist.all_gather_into_tensor(gathered.view(torch.int16), padded.view(torch.int16), group=group)
+    gathered = torch.empty((world * K, max_rows, W), dtype=out_dtype, device=dev)   # concatenation along dim 0
+    if dev.type == "cpu":
+        # gloo (CPU tests): move the raw bytes, whatever the element type
+        dist.all_gather_into_tensor(gathered.view(torch.uint8), padded.view(torch.uint8), group=group)
     else:
         dist.all_gather_into_tensor(gathered, padded, group=group)
+    gathered = gathered.view(world, K, max_rows, W)
     full = torch.empty((K, H, W), dtype=out_dtype, device=dev)
     for r, (a, b) in enumerate(rows):
         if b > a:
