@@ -1,0 +1,11 @@
+#!/usr/bin/env python3
+"""unmicst-duo entry point: same command line as the reference's UnMicst2.py:692-835, served by the HIP engine
+(unmicst_amd.driver / unmicst_amd.unet2d.UNet2D -> libumx)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.realpath(__file__)))
+
+if __name__ == "__main__":
+    from unmicst_amd import driver
+    driver.main("unmicst-duo", __file__)

@@ -67,6 +67,10 @@ enum umx_stitch { UMX_STITCH_FP16_COMPAT = 0, UMX_STITCH_FP32 = 1 }; /* fp16-com
 /* Replaces the nvidia-smi / NVML device probing of reference UnMicst1-5.py:750-769, toolbox/GPUselect.py:4-22. */
 UMX_API int umx_device_count(void);
 
+/* Free / total HBM bytes of one device -- what toolbox/GPUselect.py:4-22 (pick_gpu_lowest_memory, via NVML) reads to
+ * choose a device when --GPU is not given (UnMicst1-5.py:751-754).  Either pointer may be NULL. */
+UMX_API int umx_device_mem_info(int device_ordinal, size_t* free_bytes, size_t* total_bytes);
+
 /* Replaces UNet2D.singleImageInferenceSetup's graph build + Saver.restore (UnMicst1-5.py:656-682).
  * max_batch = tiles per UNet launch group (activation arena is sized for it; any n is accepted later). */
 UMX_API int umx_create(const umx_hparams* hp, const float* weight_blob, size_t blob_floats, int device_ordinal,

@@ -1,39 +1,102 @@
 #!/usr/bin/env python3
-"""Condense a rocprofv3 --kernel-trace CSV into a per-(kernel, grid) table.
+"""Condense rocprofv3 output into a per-(kernel, grid) table.
 
-`rocprofv3 --stats` groups by kernel NAME, and one conv_mfma_f32<NT,HPIX> instantiation serves several UNet layers,
-so the stock *_kernel_stats.csv mixes layers.  Grid size identifies the layer (bench.py --breakdown prints the same
-layers from the in-library HIP events), so this groups by (name, grid) and prints calls / avg / total.
-usage: summarize_rocprof.py <kernel_trace.csv> [out.csv]
+`rocprofv3 --stats` groups by kernel NAME, and one conv kernel instantiation serves several UNet layers, so the stock
+*_kernel_stats.csv mixes layers.  Grid size identifies the layer (bench.py --breakdown prints the same layers from
+the in-library HIP events), so this groups by (name, grid) and prints calls / avg / total.
+
+Inputs: a --kernel-trace CSV (``*_kernel_trace.csv``) or a rocpd database (``*_results.db``, the default output
+format of rocprofv3 on ROCm 7.2).  With ``--pmc DB [DB ...]`` the per-dispatch counter values of separate counter
+passes (FETCH_SIZE, WRITE_SIZE: KiB per dispatch) are averaged per (kernel, grid) and appended as columns; the
+gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE reports half the bytes of wide coalesced
+reads) is applied in the ``hbm_read_MB_corrected`` column.
+
+usage: summarize_rocprof.py <kernel_trace.csv | results.db> [--pmc results.db ...] [-o out.csv]
 """
+import argparse
 import csv
+import sqlite3
 import sys
 from collections import OrderedDict
 
 
-def main():
-    rows = OrderedDict()
-    with open(sys.argv[1], newline="") as f:
+def short(name):
+    return name.replace("void ", "").split("(")[0]
+
+
+def rows_from_csv(path):
+    with open(path, newline="") as f:
         for r in csv.DictReader(f):
-            name = r["Kernel_Name"]
-            if "umx::" not in name:
-                continue
-            name = name.replace("void ", "").split("(")[0]
-            key = (name, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]),
-                   int(r["LDS_Block_Size"]), int(r["VGPR_Count"]) + int(r.get("Accum_VGPR_Count", 0) or 0))
-            d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-            e = rows.setdefault(key, [0, 0, 1 << 62, 0])
-            e[0] += 1
-            e[1] += d
-            e[2] = min(e[2], d)
-            e[3] = max(e[3], d)
-    out = open(sys.argv[2], "w", newline="") if len(sys.argv) > 2 else sys.stdout
+            yield (r["Kernel_Name"], int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]),
+                   int(r["Grid_Size_Z"]), int(r["LDS_Block_Size"]),
+                   int(r["VGPR_Count"]) + int(r.get("Accum_VGPR_Count", 0) or 0),
+                   int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+
+
+def rows_from_db(path):
+    c = sqlite3.connect(path)
+    q = ("select name, grid_x / workgroup_x, grid_y, grid_z, lds_size, vgpr_count + accum_vgpr_count, duration "
+         "from kernels")
+    for r in c.execute(q):
+        yield r
+
+
+def pmc_from_db(path):
+    """-> {counter: {(kernel, wg_x, grid_y, grid_z): [sum, n]}}"""
+    c = sqlite3.connect(path)
+    out = {}
+    q = ("select counter_name, kernel_name, grid_size_x / workgroup_size_x, grid_size_y, grid_size_z, value "
+         "from counters_collection")
+    for cn, kn, gx, gy, gz, v in c.execute(q):
+        e = out.setdefault(cn, {}).setdefault((short(kn), gx, gy, gz), [0.0, 0])
+        e[0] += v
+        e[1] += 1
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("trace")
+    ap.add_argument("--pmc", nargs="*", default=[])
+    ap.add_argument("-o", "--out")
+    ap.add_argument("--all", action="store_true", help="keep kernels outside the umx:: namespace")
+    a = ap.parse_args()
+    src = rows_from_db(a.trace) if a.trace.endswith(".db") else rows_from_csv(a.trace)
+    rows = OrderedDict()
+    for name, gx, gy, gz, lds, vg, d in src:
+        if "umx::" not in name and not a.all:
+            continue
+        e = rows.setdefault((short(name), gx, gy, gz, lds, vg), [0, 0, 1 << 62, 0])
+        e[0] += 1
+        e[1] += d
+        e[2] = min(e[2], d)
+        e[3] = max(e[3], d)
+    pmc = {}
+    for p in a.pmc:
+        pmc.update(pmc_from_db(p))
+    counters = sorted(pmc)
+    out = open(a.out, "w", newline="") if a.out else sys.stdout
     w = csv.writer(out)
-    w.writerow(["kernel", "workgroups_x", "grid_y", "grid_z", "lds_bytes", "vgprs", "calls", "avg_us", "min_us", "max_us",
-                "total_ms"])
+    head = ["kernel", "workgroups_x", "grid_y", "grid_z", "lds_bytes", "vgprs", "calls", "avg_us", "min_us", "max_us",
+            "total_ms"] + ["%s_avg_KiB" % c for c in counters]
+    if "FETCH_SIZE" in pmc:
+        head.append("hbm_read_MB_corrected")
+    if "WRITE_SIZE" in pmc:
+        head.append("hbm_write_MB")
+    w.writerow(head)
     for k, e in sorted(rows.items(), key=lambda kv: -kv[1][1]):
-        w.writerow(list(k) + [e[0], round(e[1] / e[0] / 1e3, 2), round(e[2] / 1e3, 2), round(e[3] / 1e3, 2),
-                              round(e[1] / 1e6, 3)])
+        line = list(k) + [e[0], round(e[1] / e[0] / 1e3, 2), round(e[2] / 1e3, 2), round(e[3] / 1e3, 2),
+                          round(e[1] / 1e6, 3)]
+        vals = {}
+        for c in counters:
+            s = pmc[c].get(k[:4])
+            vals[c] = s[0] / s[1] if s else None
+            line.append(round(vals[c], 1) if s else "")
+        if "FETCH_SIZE" in pmc:
+            line.append(round(2 * vals["FETCH_SIZE"] * 1024 / 1e6, 2) if vals["FETCH_SIZE"] is not None else "")
+        if "WRITE_SIZE" in pmc:
+            line.append(round(vals["WRITE_SIZE"] * 1024 / 1e6, 2) if vals["WRITE_SIZE"] is not None else "")
+        w.writerow(line)
 
 
 if __name__ == "__main__":

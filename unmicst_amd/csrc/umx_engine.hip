@@ -602,6 +602,24 @@ int umx_device_count(void) {
     return n;
 }
 
+int umx_device_mem_info(int device_ordinal, size_t* free_bytes, size_t* total_bytes) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, UMX_ERR_NO_DEVICE, "no HIP device available (libumx has no CPU fallback)");
+    if (device_ordinal < 0 || device_ordinal >= ndev)
+        return fail(nullptr, UMX_ERR_INVALID, "device ordinal %d out of range (%d devices)", device_ordinal, ndev);
+    int prev = 0;
+    HIP_TRY(nullptr, hipGetDevice(&prev));
+    HIP_TRY(nullptr, hipSetDevice(device_ordinal));
+    size_t f = 0, t = 0;
+    hipError_t e = hipMemGetInfo(&f, &t);
+    hipSetDevice(prev);
+    if (e != hipSuccess) return fail(nullptr, UMX_ERR_HIP, "hipMemGetInfo failed: %s", hipGetErrorString(e));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return UMX_OK;
+}
+
 const char* umx_last_error(const umx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
 void umx_test_double_to_half(const double* in, uint16_t* out, size_t n) {

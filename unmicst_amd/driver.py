@@ -1,0 +1,188 @@
+"""One command-line driver for every UnMicst tool.
+
+The reference ships the same ``__main__`` block five times with small per-tool differences (UnMicst1-5.py:713-876 solo,
+UnMicst2.py:692-835 duo, UnMicst.py:544-678 legacy, UnMicstCyto2.py:679-827).  Here the differences are data
+(``TOOLS``) and the flow is written once: read page(s) -> resize -> intensity rescale -> ONE pass of the HIP engine for
+all classes -> uint8 recipe -> BigTIFF pages with the reference's names and page order.
+
+Kept identical on purpose (file-level parity): argparse surfaces; 0-based channels in the scripts / 1-based in the
+wrapper; the file-type switch on the text after the first dot (solo: after the last dots, with the ``ome.`` special
+case); float32 input cast to uint16; the solo quirk that the network sees the *un-rescaled* image (``cells = I`` is
+bound before the rescale, UnMicst1-5.py:816-821) while legacy/duo/cyto feed the rescaled one; uint8 truncation twice
+(UnMicst1-5.py:848-854); ``_Probabilities_`` pages in reversed class order; ``qc/<stem>_Preview_`` = [contours, raw/max];
+default output directory ``<parent of parent>/probability_maps``.
+
+Not kept: ``.czi`` / ``.nd2`` (proprietary readers absent: NotImplementedError, which is what the reference raises for
+types it cannot read, UnMicst1-5.py:806); the NVML device probe (replaced by umx_device_mem_info).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import imtools, tiffio
+from .unet2d import UNet2D
+
+
+@dataclass(frozen=True)
+class ToolSpec:
+    script: str              # reference script this spec mirrors
+    default_model: str
+    graph: object            # model.GRAPH_* or None (detect)
+    multi_channel: bool      # --channel nargs='+' (solo, duo) vs a single int (legacy, cyto)
+    n_inputs: int            # image planes fed to the network (duo: 2)
+    split_last: bool         # solo derives stem/type from the LAST dots; the others split at the first dot
+    tiff_types: tuple        # extensions read as OME/BigTIFF pages
+    infer_rescaled: bool     # False: solo's `cells = I` quirk
+    cast_float32: bool
+    has_verbose: bool
+    qc_dir: bool             # Preview goes to <out>/qc
+    suffix_plus_one: bool    # file-name suffix is channel+1 (cyto writes the raw 0-based channel)
+
+
+TOOLS = {
+    "unmicst-solo": ToolSpec("UnMicst1-5.py", "nucleiDAPI1-5", 1, True, 1, True, ("ome.tif", "ome.tiff", "btf"), False,
+                             True, True, True, True),
+    "unmicst-duo": ToolSpec("UnMicst2.py", "nucleiDAPILAMIN", 1, True, 2, False, ("ome.tif", "ome.tiff", "btf"), True,
+                            True, True, True, True),
+    "unmicst-legacy": ToolSpec("UnMicst.py", "nucleiDAPI", 0, False, 1, False, ("ome.tif", "ome.tiff", "btf"), True,
+                               True, True, True, True),
+    "UnMicstCyto2": ToolSpec("UnMicstCyto2.py", "nucleiDAPI", 1, False, 1, False, ("ome.tif", "btf"), True, False,
+                             False, False, False),
+}
+
+
+def build_parser(spec: ToolSpec) -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(prog=spec.script)
+    p.add_argument("imagePath", help="path to the .tif file")
+    p.add_argument("--model", help="type of model. For example, nuclei vs cytoplasm", default=spec.default_model)
+    p.add_argument("--outputPath", help="output path of probability map")
+    if spec.multi_channel:
+        p.add_argument("--channel", help="channel to perform inference on", nargs="+", default=[0])
+    else:
+        p.add_argument("--channel", help="channel to perform inference on", type=int, default=0)
+    p.add_argument("--classOrder", help="background, contours, foreground", type=int, nargs="+", default=-1)
+    p.add_argument("--mean", help="mean intensity of input image. Use -1 to use model", type=float, default=-1)
+    p.add_argument("--std", help="mean standard deviation of input image. Use -1 to use model", type=float, default=-1)
+    p.add_argument("--scalingFactor", help="factor by which to increase/decrease image size by", type=float, default=1)
+    p.add_argument("--stackOutput", help="save probability maps as separate files", action="store_true")
+    p.add_argument("--GPU", help="explicitly select GPU", type=int, default=-1)
+    p.add_argument("--outlier", help="map percentile intensity to max when rescaling intensity values. "
+                                     "Max intensity as default", type=float, default=-1)
+    if spec.has_verbose:
+        p.add_argument("--verbose", help="display error messages for debugging", action="store_true")
+    return p
+
+
+def models_root(script_dir: str) -> str:
+    """``<script dir>/models`` like the reference (UnMicst1-5.py:744), overridable with UMX_MODELS_DIR."""
+    return os.environ.get("UMX_MODELS_DIR") or os.path.join(script_dir, "models")
+
+
+def split_name(file_name: str, spec: ToolSpec):
+    """-> (stem, type) the way the tool's reference script derives them."""
+    if spec.split_last:
+        parts = file_name.split(os.extsep)
+        if len(parts) < 2:
+            raise NotImplementedError("Input filename has no extension")
+        if parts[-2] == "ome":
+            return os.extsep.join(parts[:-2]), os.extsep.join(parts[-2:])
+        return os.extsep.join(parts[:-1]), parts[-1]
+    parts = file_name.split(os.extsep, 1)
+    if len(parts) < 2:
+        raise NotImplementedError("Input filename has no extension")
+    return parts[0], parts[1]
+
+
+def read_plane(path: str, file_type: str, channel: int, spec: ToolSpec) -> np.ndarray:
+    if file_type in spec.tiff_types or file_type == "tif":
+        I = tiffio.imread(path, key=int(channel))
+    else:
+        raise NotImplementedError("Don't know how to read image with extension .%s" % file_type)
+    if spec.cast_float32 and I.dtype == np.float32:
+        I = np.uint16(I)
+    return I
+
+
+def preprocess(I: np.ndarray, scaling: float, outlier: float):
+    """resize by --scalingFactor, then rescale intensities to (0, 0.983) -> (resized float image, rescaled image)."""
+    hsize = int(float(I.shape[0]) * float(scaling))
+    vsize = int(float(I.shape[1]) * float(scaling))
+    R = imtools.resize(I, (hsize, vsize))
+    max_limit = np.max(R) if outlier == -1 else np.percentile(R, outlier)
+    S = imtools.im2double(imtools.rescale_intensity(R, (np.min(R), max_limit), (0, 0.983)))
+    return R, S
+
+
+def run(tool: str, argv=None, script_dir: str = None) -> int:
+    spec = TOOLS[tool]
+    args = build_parser(spec).parse_args(argv)
+    script_dir = script_dir or os.path.dirname(os.path.dirname(os.path.realpath(__file__)))
+    model_path = args.model if os.path.isdir(args.model) else os.path.join(models_root(script_dir), args.model)
+
+    if args.GPU == -1:
+        print("automatically choosing GPU")
+    UNet2D.singleImageInferenceSetup(model_path, args.GPU, args.mean, args.std, graph=None)
+    print("Using GPU " + str(UNet2D.Engine.device))
+    try:
+        n_class = UNet2D.hp["nClasses"]
+        image_path = args.imagePath
+        channels = [int(c) for c in args.channel] if spec.multi_channel else [int(args.channel)]
+        first = channels[0]
+        if spec.n_inputs == 2:
+            channels = [first, first] if len(channels) == 1 else channels[:2]
+            print("Using channels %d and %d" % (channels[0] + 1, channels[1] + 1))
+        else:
+            channels = [first]
+            if spec.multi_channel:
+                print("Using channel " + str(first + 1))
+        parent = os.path.dirname(os.path.dirname(image_path))
+        stem, file_type = split_name(os.path.basename(image_path), spec)
+
+        planes_in = []
+        raw = None
+        for ch in channels:
+            raw = read_plane(image_path, file_type, ch, spec)
+            resized, rescaled = preprocess(raw, args.scalingFactor, args.outlier)
+            planes_in.append(rescaled if spec.infer_rescaled else resized)
+        raw_shape = raw.shape[:2]
+        cells = np.stack(planes_in) if spec.n_inputs == 2 else planes_in[0]
+        class_order = range(n_class) if args.classOrder == -1 else args.classOrder
+        rawI = imtools.im2double(raw)
+        rawI = rawI / np.max(rawI)
+
+        out_dir = args.outputPath if args.outputPath else parent + "//probability_maps"
+        os.makedirs(out_dir, exist_ok=True)
+        qc_dir = out_dir + "//qc" if spec.qc_dir else out_dir
+        if spec.qc_dir:
+            os.makedirs(qc_dir, exist_ok=True)
+        suffix = str(first + 1) if spec.suffix_plus_one else str(first)
+
+        def plane_u8(k):
+            return imtools.to_uint8_via_resize(UNet2D.singleImageInference(cells, "accumulate", k), raw_shape)
+
+        if args.stackOutput:
+            stack = out_dir + "//" + stem + "_Probabilities_" + suffix + ".tif"
+            preview = qc_dir + "//" + stem + "_Preview_" + suffix + ".tif"
+            for page, k in enumerate(class_order[::-1]):   # reversed "to align with ilastik" (UnMicst1-5.py:848)
+                pm = plane_u8(k)
+                tiffio.imsave(stack, pm, append=page > 0)
+                if page == 1:
+                    tiffio.imsave(preview, pm, append=False)
+                    tiffio.imsave(preview, np.uint8(255 * rawI), append=True)
+        else:
+            cont = out_dir + "//" + stem + "_ContoursPM_" + suffix + ".tif"
+            tiffio.imsave(cont, plane_u8(class_order[1]), append=False)
+            tiffio.imsave(cont, np.uint8(255 * rawI), append=True)
+            tiffio.imsave(out_dir + "//" + stem + "_NucleiPM_" + suffix + ".tif", plane_u8(class_order[2]), append=False)
+    finally:
+        UNet2D.singleImageInferenceCleanup()
+    return 0
+
+
+def main(tool: str, script_file: str) -> None:
+    sys.exit(run(tool, None, os.path.dirname(os.path.realpath(script_file))))

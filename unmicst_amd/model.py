@@ -258,10 +258,68 @@ class ModelArtefacts:
     std: float
 
 
-def load_model_dir(model_path: str, graph: int) -> ModelArtefacts:
-    """Read hp.data, datasetMean/StDev and model.ckpt from a reference-format model directory."""
+CONVERTED_NAME = "umx_model.npz"   # written by tools/convert_model.py: the "converted once" form of a model directory
+
+
+def detect_graph(model_path: str) -> int:
+    """Which graph builder wrote this model directory, from the checkpoint's variable names: the legacy script names
+    its first filter ``downsampling/ld0/kernel1`` (reference UnMicst.py:84), the v2 scripts ``.../kernelD0``
+    (UnMicst1-5.py:89)."""
+    conv = os.path.join(model_path, CONVERTED_NAME)
+    if os.path.exists(conv):
+        with np.load(conv) as z:
+            return int(z["hp"][0])
+    names = tfckpt.read_index(os.path.join(model_path, "model.ckpt.index"))
+    if "downsampling/ld0/kernelD0" in names:
+        return GRAPH_V2
+    if "downsampling/ld0/kernel1" in names:
+        return GRAPH_LEGACY
+    raise KeyError("%s: neither a legacy nor a v2 UnMicst checkpoint" % model_path)
+
+
+def _hp_vector(hp: HParams) -> np.ndarray:
+    return np.array([hp.graph, hp.imSize, hp.nChannels, hp.nClasses, hp.nOut0, hp.nLayers, hp.ks, hp.nExtraConvs,
+                     hp.featMapsFact, hp.downSampFact, hp.batchSize], dtype=np.int64)
+
+
+def hparams_from_vector(h) -> HParams:
+    h = [int(v) for v in h]
+    hp = HParams(graph=h[0], imSize=h[1], nChannels=h[2], nClasses=h[3], nOut0=h[4], nLayers=h[5], ks=h[6],
+                 nExtraConvs=h[7], featMapsFact=h[8], downSampFact=h[9], batchSize=h[10])
+    hp.validate()
+    return hp
+
+
+def save_converted(art: "ModelArtefacts", model_path: str) -> str:
+    """Write the one-time conversion of a model directory (canonical blob + hp + normalisation scalars)."""
+    os.makedirs(model_path, exist_ok=True)
+    out = os.path.join(model_path, CONVERTED_NAME)
+    np.savez(out, blob=np.ascontiguousarray(art.blob, dtype="<f4"), hp=_hp_vector(art.hp),
+             mean=np.float64(art.mean), std=np.float64(art.std))
+    return out
+
+
+def load_model_dir(model_path: str, graph: int = None, synthetic_if_missing: bool = False) -> ModelArtefacts:
+    """Read a model directory: the converted ``umx_model.npz`` if present, else the reference's own artefacts
+    (hp.data, datasetMean/StDev pickles, model.ckpt -- reference UnMicst1-5.py:656-681).  ``graph`` None = detect.
+
+    ``synthetic_if_missing``: when the directory has hyper-parameters but no weight shard (the reference ships
+    nucleiDAPI1-5 / nucleiDAPILAMIN that way and downloads the shards at image-build time, Dockerfile:5-6), use
+    seeded synthetic weights instead of failing -- for plumbing tests only, never silently."""
+    conv = os.path.join(model_path, CONVERTED_NAME)
+    if os.path.exists(conv):
+        with np.load(conv) as z:
+            return ModelArtefacts(hparams_from_vector(z["hp"]), np.array(z["blob"]), float(z["mean"]), float(z["std"]))
+    if graph is None:
+        graph = detect_graph(model_path)
     hp = hparams_from_dict(load_pickle(os.path.join(model_path, "hp.data")), graph)
     mean = float(load_pickle(os.path.join(model_path, "datasetMean.data")))
     std = float(load_pickle(os.path.join(model_path, "datasetStDev.data")))
+    shard = os.path.join(model_path, "model.ckpt.data-00000-of-00001")
+    if not os.path.exists(shard):
+        if not synthetic_if_missing:
+            raise FileNotFoundError("%s is missing (the reference downloads it separately, Dockerfile:5-6); "
+                                    "set UMX_SYNTHETIC_WEIGHTS=1 to run with seeded synthetic weights" % shard)
+        return ModelArtefacts(hp, random_blob(hp), mean, std)
     blob = blob_from_checkpoint(hp, os.path.join(model_path, "model.ckpt"))
     return ModelArtefacts(hp, blob, mean, std)

@@ -20,7 +20,7 @@ STITCH_FP16_COMPAT, STITCH_FP32 = 0, 1
 
 # every symbol include/umx.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "umx_device_count", "umx_create", "umx_destroy", "umx_last_error", "umx_set_stream", "umx_synchronize",
+    "umx_device_count", "umx_device_mem_info", "umx_create", "umx_destroy", "umx_last_error", "umx_set_stream", "umx_synchronize",
     "umx_forward_tiles", "umx_forward_tiles_dev", "umx_tile_grid", "umx_infer_image", "umx_infer_image_dev",
     "umx_band_tiles_dev", "umx_stitch_dev", "umx_profile_enable", "umx_profile_read", "umx_test_double_to_half",
     "umx_describe", "umx_version",
@@ -90,6 +90,8 @@ def load(path: Optional[str] = None):
     c_int, c_void_p, c_double = ctypes.c_int, ctypes.c_void_p, ctypes.c_double
     ip = ctypes.POINTER(c_int)
     L.umx_device_count.restype = c_int
+    L.umx_device_mem_info.restype = c_int
+    L.umx_device_mem_info.argtypes = [c_int, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
     L.umx_create.restype = c_int
     L.umx_create.argtypes = [ctypes.POINTER(_HP), c_void_p, ctypes.c_size_t, c_int, c_int, ctypes.POINTER(c_void_p)]
     L.umx_destroy.restype = None
@@ -127,6 +129,23 @@ def _hp_struct(hp: HParams) -> _HP:
 
 def device_count() -> int:
     return int(load().umx_device_count())
+
+
+def device_mem_info(device: int):
+    """(free_bytes, total_bytes) of one device -- the quantity toolbox/GPUselect.py reads through NVML."""
+    f, t = ctypes.c_size_t(), ctypes.c_size_t()
+    rc = load().umx_device_mem_info(int(device), ctypes.byref(f), ctypes.byref(t))
+    if rc:
+        raise UmxError(rc, load().umx_last_error(None).decode())
+    return f.value, t.value
+
+
+def pick_device_most_free_memory() -> int:
+    """HIP analogue of GPUselect.pick_gpu_lowest_memory (reference toolbox/GPUselect.py:4-22)."""
+    n = device_count()
+    if n < 1:
+        raise UmxError(3, "no HIP device available (libumx has no CPU fallback)")
+    return max(range(n), key=lambda d: device_mem_info(d)[0])
 
 
 def describe(hp: HParams) -> dict:
