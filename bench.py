@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: bf16/f16 MFMA dense peak (~2.5 PF; 16x the fp32 matrix rate)
 PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {
@@ -51,7 +52,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="wsi-synth256", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=64, help="tiles per UNet launch group")
+    ap.add_argument("--batch", type=int, default=256, help="tiles per UNet launch group")
+    ap.add_argument("--precision", default="default", choices=["default", "f32", "f16x3"],
+                    help="conv arithmetic: exact fp32 MFMA, or 3 binary16 MFMA products per fp32 product (default)")
     ap.add_argument("--band-rows", type=int, default=0, help="override rows per GPU")
     ap.add_argument("--cols", type=int, default=0, help="override slide width")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-baseline sample (0 = skip)")
@@ -89,7 +92,7 @@ def main():
                  "nucleiDAPI": (0.19808, 0.16236)}[key]
     H = band_rows * world
 
-    eng = umx.Engine(hp, blob, device=local_rank, max_batch=args.batch)
+    eng = umx.Engine(hp, blob, device=local_rank, max_batch=args.batch, precision=args.precision)
     eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     npr, npc, _, _ = eng.tile_grid(H, W)
     tiles_total = npr * npc
@@ -134,19 +137,26 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = tiles_total * args.steps / elapsed
         # ---- roofline of the dominant kernel (largest share of the timed region), from the in-library HIP events
-        convs = [p for p in prof if p["kernel"].startswith("conv_mfma")]
+        convs = [p for p in prof if p["kernel"].startswith("conv_")]
         dom = max(convs, key=lambda p: p["total_ms"])
         dom_tflops = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
         all_flops = sum(p["flops"] for p in convs)
+        all_exec = sum(p["exec_flops"] for p in convs)
         all_ms = sum(p["total_ms"] for p in convs)
+        peak = PEAK_F16_MFMA_TFLOPS if eng.precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
         roofline = {
-            "bound": "mfma", "achieved": round(dom_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(dom_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            # achieved = ALGORITHMIC fp32 FLOPs of the layer / HIP-event time of its launches; peak = dense MFMA peak of
+            # the dtype the matrix cores run (f16x3 issues 3 binary16 MFMA FLOPs per algorithmic FLOP: "mfma_issued")
+            "bound": "mfma", "achieved": round(dom_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(dom_tflops / peak, 4), "traffic": None,
             "kernel": dom["kernel"], "layer": dom["name"],
             "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
             "flop_per_launch": dom["flops"] / dom["launches"],
+            "mfma_issued": {"tflops": round(dom["exec_flops"] / (dom["total_ms"] * 1e-3) / 1e12, 2),
+                            "frac": round(dom["exec_flops"] / (dom["total_ms"] * 1e-3) / 1e12 / peak, 4)},
             "all_conv_launches": {"achieved": round(all_flops / (all_ms * 1e-3) / 1e12, 2),
-                                  "frac": round(all_flops / (all_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                  "frac": round(all_flops / (all_ms * 1e-3) / 1e12 / peak, 4),
+                                  "mfma_issued_frac": round(all_exec / (all_ms * 1e-3) / 1e12 / peak, 4),
                                   "share_of_step": round(all_ms / (1e3 * elapsed), 4)},
         }
         if args.breakdown:
@@ -164,7 +174,8 @@ def main():
             "metric": "tiles/sec (%dx%dx%d) whole-slide inference" % (hp.imSize, hp.imSize, hp.nChannels),
             "value": round(value, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": {"f32": "f32", "f16x3": "f16x3 (fp32 products as 3 binary16 MFMA products, fp32 accumulate)"}[
+                eng.precision], "data": "synthetic",
             "config": {"workload": "%s: %s hp (%s graph, seeded weights), %d-channel synthetic slide %dx%d, "
                                    "%d tiles/step, batch %d, fp16-compat stitch%s" % (
                                        args.workload, key, "v2" if hp.graph else "legacy", C_img, H, W, tiles_total,

@@ -34,8 +34,24 @@ enum umx_status {
     UMX_ERR_BLOB = 2,        /* weight blob size does not match the graph (reference: tf NotFoundError on restore) */
     UMX_ERR_NO_DEVICE = 3,   /* no usable HIP device */
     UMX_ERR_HIP = 4,         /* a HIP runtime call failed */
-    UMX_ERR_OOM = 5
+    UMX_ERR_OOM = 5,
+    UMX_ERR_RANGE = 6        /* split-precision path only: an activation left the binary16 range (|v| >= 6e4) */
 };
+
+/* Arithmetic of the convolutions.  Both hold the 1e-4 tolerance on the probability maps.
+ *   UMX_PREC_F32    exact fp32 products on v_mfma_f32_16x16x4_f32 (bit-for-bit an fp32 fma chain).
+ *   UMX_PREC_F16X3  every fp32 product as three binary16 MFMA products of a (hi, lo) split of both operands with fp32
+ *                   accumulation (~2^-21 relative error per product; 16/3 of the fp32 matrix rate).  Default.
+ *   UMX_PREC_DEFAULT  = UMX_PREC_F16X3 unless the environment says UMX_PRECISION=f32. */
+enum umx_precision { UMX_PREC_DEFAULT = 0, UMX_PREC_F32 = 1, UMX_PREC_F16X3 = 2 };
+
+typedef struct umx_options {
+    int32_t device_ordinal;
+    int32_t max_batch;       /* tiles per UNet launch group */
+    int32_t precision;       /* enum umx_precision */
+    int32_t act_shift;       /* F16X3: activations stored times 2^act_shift (0..8); -1 = default (0) */
+    int32_t reserved[12];    /* must be zero */
+} umx_options;
 
 enum umx_graph {
     UMX_GRAPH_LEGACY = 0,    /* reference UnMicst.py:51-187 (ReLU, 1x1 shortcut, BN after ReLU, no BN elsewhere) */
@@ -75,6 +91,12 @@ UMX_API int umx_device_mem_info(int device_ordinal, size_t* free_bytes, size_t* 
  * max_batch = tiles per UNet launch group (activation arena is sized for it; any n is accepted later). */
 UMX_API int umx_create(const umx_hparams* hp, const float* weight_blob, size_t blob_floats, int device_ordinal,
                int max_batch, umx_ctx** out);
+
+/* umx_create with explicit options (precision, ...). */
+UMX_API int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob_floats, const umx_options* opts,
+                    umx_ctx** out);
+/* The precision a ctx actually runs (enum umx_precision). */
+UMX_API int umx_precision_of(const umx_ctx* ctx);
 
 /* Replaces UNet2D.singleImageInferenceCleanup (UnMicst1-5.py:684-685). NULL is a no-op. */
 UMX_API void umx_destroy(umx_ctx* ctx);
@@ -124,6 +146,8 @@ typedef struct umx_prof_entry {
     double total_ms;
     double flops_per_launch_sum;  /* sum over launches of algorithmic FLOPs (no padded work counted) */
     double bytes_per_launch_sum;  /* sum over launches of compulsory HBM bytes */
+    double exec_flops_sum;        /* sum over launches of FLOPs issued to the matrix cores (padding and, for
+                                     UMX_PREC_F16X3, the three products per fp32 product included) */
 } umx_prof_entry;
 UMX_API int umx_profile_enable(umx_ctx* ctx, int on);          /* on: bracket every launch with events; resets counters */
 UMX_API int umx_profile_read(umx_ctx* ctx, umx_prof_entry* entries, int max_entries, int* n_entries);

@@ -37,7 +37,7 @@ def _check_planes(cont, nuc, prev_raw):
     _, g_cont, g_raw, g_nuc = helpers.load_sample_105()
     for got, gold in ((cont, g_cont), (nuc, g_nuc)):
         d = np.abs(got.astype(int) - gold.astype(int))
-        assert d.max() <= 2 and (d <= 1).mean() > 0.9999 and (d == 0).mean() > 0.88, (d.max(), (d == 0).mean())
+        assert d.max() <= 2 and (d <= 1).mean() > 0.999 and (d == 0).mean() > 0.88, (d.max(), (d == 0).mean())
     assert np.array_equal(prev_raw, g_raw)     # raw/max preview plane: bit-exact
 
 

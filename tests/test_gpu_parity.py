@@ -22,8 +22,12 @@ def torch_cuda():
     return torch
 
 
+PRECS = ["f32", "f16x3"]
+
+
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("name", sorted(helpers.small_hps()))
-def test_forward_tiles_matches_oracle(name):
+def test_forward_tiles_matches_oracle(name, prec):
     from oracle import oracle
     hp = helpers.small_hps()[name]
     blob = model.random_blob(hp, seed=11)
@@ -31,7 +35,8 @@ def test_forward_tiles_matches_oracle(name):
     n = 5  # not a multiple of any tile-group size: exercises the image predicate
     x = rng.normal(size=(n, hp.imSize, hp.imSize, hp.nChannels)).astype(np.float32)
     ref = oracle.forward(hp, blob, x)
-    with umx.Engine(hp, blob, max_batch=3) as eng:   # 5 tiles through batches of 3 + 2
+    with umx.Engine(hp, blob, max_batch=3, precision=prec) as eng:   # 5 tiles through batches of 3 + 2
+        assert eng.precision == prec
         got = eng.forward_tiles(x)
     assert got.shape == ref.shape
     err = np.abs(got - ref).max()
@@ -39,7 +44,8 @@ def test_forward_tiles_matches_oracle(name):
     assert np.allclose(got.sum(-1), 1.0, atol=1e-5)
 
 
-def test_forward_tiles_real_weights_nucleiDAPI():
+@pytest.mark.parametrize("prec", PRECS)
+def test_forward_tiles_real_weights_nucleiDAPI(prec):
     """Legacy graph with the reference's shipped models/nucleiDAPI weights (5x5 kernels) on real sample tiles."""
     from oracle import oracle, pi2d_oracle
     hp, blob, mean, std = helpers.load_nuclei_dapi()
@@ -48,7 +54,7 @@ def test_forward_tiles_real_weights_nucleiDAPI():
     pi = pi2d_oracle.PI2DOracle(I, hp.imSize, hp.margin, "accumulate")
     x = pi2d_oracle.normalised_batch(pi, 33, 6, 1, mean, std, False)
     ref = oracle.forward(hp, blob, x)
-    with umx.Engine(hp, blob, max_batch=4) as eng:
+    with umx.Engine(hp, blob, max_batch=4, precision=prec) as eng:
         got = eng.forward_tiles(x)
     assert np.abs(got - ref).max() <= TILE_TOL
 
@@ -87,12 +93,13 @@ def test_stitch_bit_exact_vs_reference_pi2d(name, torch_cuda):
                 assert np.array_equal(both.view(np.uint16), c["stitched"].view(np.uint16))
 
 
-def test_end_to_end_reference_sample_data():
+@pytest.mark.parametrize("prec", PRECS)
+def test_end_to_end_reference_sample_data(prec):
     """umx_infer_image with models/nucleiDAPI on 'UNet sample data' 105.tif vs the reference's bundled outputs."""
     hp, blob, mean, std = helpers.load_nuclei_dapi()
     raw, g_cont, g_raw, g_nuc = helpers.load_sample_105()
     I = helpers.legacy_preprocess(raw)
-    with umx.Engine(hp, blob, max_batch=32) as eng:
+    with umx.Engine(hp, blob, max_batch=32, precision=prec) as eng:
         planes = eng.infer_image(I, mean, std)
     assert planes.dtype == np.float16 and planes.shape == (3,) + I.shape
     for k, gold in ((1, g_cont), (2, g_nuc)):
@@ -102,15 +109,16 @@ def test_end_to_end_reference_sample_data():
         assert (d == 0).mean() > 0.98
 
 
+@pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("name,shape", [("v2_duo_like", (2, 70, 45)), ("v2_solo_like", (53, 90)), ("legacy_k5", (40, 33))])
-def test_infer_image_matches_oracle_loop(name, shape):
+def test_infer_image_matches_oracle_loop(name, shape, prec):
     """Whole-image path (gather+normalise, UNet, stitch) vs the reference-equivalent oracle loop, per class."""
     from oracle import oracle
     hp = helpers.small_hps()[name]
     blob = model.random_blob(hp, seed=3)
     img = np.random.default_rng(9).random(shape) * 0.6
     mean, std = 0.21, 0.17
-    with umx.Engine(hp, blob, max_batch=4) as eng:
+    with umx.Engine(hp, blob, max_batch=4, precision=prec) as eng:
         got16 = eng.infer_image(img, mean, std)
         got32 = eng.infer_image(img, mean, std, stitch=umx.STITCH_FP32)
         rep = eng.infer_image(img, mean, std, mode=umx.MODE_REPLACE)

@@ -58,19 +58,27 @@ struct Launch {
     double bytes = 0.0;       // compulsory HBM bytes per tile: sources + destination (weights excluded)
     // device
     ConvParams cp;
+    // split-precision plan (UMX_PREC_F16X3)
+    HConvParams hcp;
+    int wshift = 0;           // weights are stored times 2^wshift
+    int n_ksteps = 0;         // K-slots of 32 executed per output tile, all phases (for the executed-FLOP figure)
+    float* d_pre_s16 = nullptr;
     float* d_head_w = nullptr;
     float *d_pre_s = nullptr, *d_pre_b = nullptr, *d_post_s = nullptr, *d_post_b = nullptr;
 };
 
 struct Buffer {
     size_t floats_per_tile = 0;
+    int S = 0, C = 0;        // spatial size and real channels of the tensor
+    int Cs = 0;              // stored channels of the (hi, lo) binary16 form
+    bool as_f32 = true;      // fp32 NHWC (f32 path, and the head's input in the f16 path) or (hi, lo) binary16 planes
     float* d = nullptr;
 };
 
 struct ProfSite {
     std::string name, kernel;
     int64_t launches = 0;
-    double total_ms = 0.0, flops = 0.0, bytes = 0.0;
+    double total_ms = 0.0, flops = 0.0, bytes = 0.0, exec = 0.0;
 };
 
 struct PendingEvent {
@@ -100,7 +108,13 @@ struct umx_ctx {
     std::vector<ProfSite> sites;
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> free_events;
-    int site_gather = -1, site_stitch = -1;
+    int site_gather = -1, site_stitch = -1, site_split = -1;
+    // precision
+    int precision = UMX_PREC_F16X3;
+    int act_shift = 0;          // activations are stored times 2^act_shift in the (hi, lo) binary16 form
+    float* d_tiles32 = nullptr; // fp32 staging of gathered tiles before the split (f16 path)
+    int* d_flag = nullptr;      // binary16 range overflow flag
+    uint4* d_zeros = nullptr;
 };
 
 namespace {
@@ -193,6 +207,7 @@ struct Builder {
     size_t pos = 0;
     std::vector<Launch> plan;
     std::vector<size_t> buf_floats;  // per tile
+    std::vector<std::pair<int, int>> buf_geom;  // (spatial size, channels) per buffer
 
     explicit Builder(const umx_hparams& h, const float* b) : hp(h), blob(b) {}
 
@@ -203,7 +218,11 @@ struct Builder {
     }
     HostTensor take_filter(int kh, int kw, int a, int b) { return HostTensor{take((size_t)kh * kw * a * b), kh, kw, a, b}; }
     BN take_bn(int C) { BN r; r.g = take(C); r.b = take(C); r.m = take(C); r.v = take(C); return r; }
-    int new_buf(size_t floats) { buf_floats.push_back(floats); return (int)buf_floats.size() - 1; }
+    int new_buf(int S, int C) {
+        buf_floats.push_back((size_t)S * S * C);
+        buf_geom.push_back({S, C});
+        return (int)buf_floats.size() - 1;
+    }
 
     // pack filter channels [c0, c0+C) of w [kh,kw,Cin,Cout] for the taps of a stride-1 SAME conv
     void add_conv_group(Launch& L, int src, const HostTensor& w, int c0, int C, const HostTensor* add = nullptr) {
@@ -299,7 +318,7 @@ struct Builder {
         const int kss = v2 ? ks : 1;
         const int act = v2 ? ACT_LEAKY : ACT_RELU;
         std::vector<int> ds(L + 1);
-        ds[0] = new_buf((size_t)P * P * n[0]);  // buffer 0: normalised input tiles
+        ds[0] = new_buf(P, n[0]);  // buffer 0: normalised input tiles
         int S = P;
         char nm[64];
         for (int i = 0; i < L; ++i) {
@@ -309,7 +328,7 @@ struct Builder {
             for (int e = 0; e < nx; ++e) wx.push_back(take_filter(ks, ks, Co, Co));
             HostTensor wsc = take_filter(kss, kss, Ci, Co);
             BN bn = take_bn(Co);
-            ds[i + 1] = new_buf((size_t)(S / 2) * (S / 2) * Co);
+            ds[i + 1] = new_buf(S / 2, Co);
             auto epilogue = [&](Launch& Lh) {
                 // v2: leaky(BN(sum)) (UnMicst1-5.py:114);  legacy: BN(relu(sum)) (UnMicst.py:99); then 2x2 max-pool
                 if (!blob) return;
@@ -323,7 +342,7 @@ struct Builder {
                 epilogue(Lh);
                 finish(Lh);
             } else {
-                int t = new_buf((size_t)S * S * Co), t2 = nx > 1 ? new_buf((size_t)S * S * Co) : -1;
+                int t = new_buf(S, Co), t2 = nx > 1 ? new_buf(S, Co) : -1;
                 snprintf(nm, sizeof nm, "ld%d.conv1", i);
                 Launch L1 = make(nm, S, Co, t, 0, act);  // act fused: the next conv consumes act(c00)
                 add_conv_group(L1, ds[i], w1, 0, Ci);
@@ -347,7 +366,7 @@ struct Builder {
         {
             const int Ci = n[L], Co = n[L + 1];
             HostTensor w = take_filter(ks, ks, Ci, Co);
-            cur = new_buf((size_t)S * S * Co);
+            cur = new_buf(S, Co);
             Launch Lb = make("lb.conv", S, Co, cur, 0, act);
             add_conv_group(Lb, ds[L], w, 0, Ci);
             if (v2) {
@@ -365,25 +384,29 @@ struct Builder {
             std::vector<HostTensor> wx;
             for (int e = 0; e < nx; ++e) wx.push_back(take_filter(ks, ks, Cup, Cup));
             const int S2 = S * 2;
-            const int us = new_buf((size_t)S2 * S2 * Cup);
+            const int us = new_buf(S2, Cup);
             snprintf(nm, sizeof nm, "lu%d.convT", idx);
             Launch Lt = make(nm, S, Cup, us, 0, act);
             add_convT_group(Lt, cur, wt);
             finish(Lt);
-            int cv = new_buf((size_t)S2 * S2 * Cup);
+            int cv = new_buf(S2, Cup);
             snprintf(nm, sizeof nm, "lu%d.conv", idx);
             Launch Lc = make(nm, S2, Cup, cv, 0, act);
             add_conv_group(Lc, ds[idx], w2, 0, Cskip);   // concat3([dsX[index], us]): skip channels first
             add_conv_group(Lc, us, w2, Cskip, Cup);
             if (v2 && blob) fold_bn(bn, Cup, &Lc.pre_s, &Lc.pre_b);
             finish(Lc);
-            int other = nx > 0 ? new_buf((size_t)S2 * S2 * Cup) : -1;
+            int other = nx > 0 ? new_buf(S2, Cup) : -1;
             for (int e = 0; e < nx; ++e) {
                 snprintf(nm, sizeof nm, "lu%d.extra%d", idx, e);
-                Launch Le = make(nm, S2, Cup, other, 0, act);
+                // the tensor the softmax head reads gets a buffer of its own: it is never an intermediate, so the
+                // split-precision path can keep it fp32 while every other tensor is a (hi, lo) binary16 pair
+                const int dstb = (idx == 0 && e == nx - 1) ? new_buf(S2, Cup) : other;
+                Launch Le = make(nm, S2, Cup, dstb, 0, act);
                 add_conv_group(Le, cv, wx[e], 0, Cup);
                 finish(Le);
-                std::swap(cv, other);
+                other = cv;
+                cv = dstb;
             }
             cur = cv;
             S = S2;
@@ -489,6 +512,184 @@ int upload(umx_ctx* ctx, const std::vector<float>& h, float** out) {
     return UMX_OK;
 }
 
+
+template <typename T>
+int upload_raw(umx_ctx* ctx, const std::vector<T>& h, T** out) {
+    *out = nullptr;
+    if (h.empty()) return UMX_OK;
+    void* d = nullptr;
+    int rc = dev_alloc(ctx, &d, h.size() * sizeof(T));
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (T*)d;
+    return UMX_OK;
+}
+
+// ---- split-precision plan of one conv launch: chunking of the input octets, k-step table, stage table, weight images
+// (layout documented in umx_conv_f16.hip).  Reads the fp32 packing [tap][Cp][Np] produced by the Builder.
+int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, std::string* why) {
+    const ConvParams& g = L.cp;   // tile geometry shared with the fp32 kernel
+    HConvParams& h = L.hcp;
+    memset(&h, 0, sizeof h);
+    h.twm_log2 = g.twm_log2; h.th_log2 = g.th_log2; h.nimg_m = g.nimg_m; h.imgs = g.imgs;
+    h.hh = g.hh; h.hw = g.hw; h.imgplane = g.imgplane; h.nhalo = g.imgs * g.imgplane;
+    h.ymin = g.ymin; h.xmin = g.xmin; h.tiles_y = g.tiles_y; h.tiles_x = g.tiles_x;
+    h.nphase = L.nphase; h.o_mul = L.o_mul;
+    h.H = L.H; h.W = L.W; h.Cout = L.Cout; h.Cds = round_up(L.Cout, 8);
+    h.NT = L.nt; h.nblocks = L.Np / (16 * L.nt);
+    h.outH = L.outH; h.outW = L.outW; h.pool = L.pool; h.act = L.act;
+    if (h.nhalo > kHaloChunks * 64) { *why = "halo too large for the split-precision kernel"; return UMX_ERR_INVALID; }
+    h.plane_slots = round_up(h.nhalo, 16);
+    const int plane_pair = h.plane_slots * 16 * 2;   // hi + lo bytes of one octet plane
+
+    // weight shift: largest |w| lands in [2^13, 2^14) so that the lo parts stay in binary16's normal range
+    float maxabs = 0.f;
+    for (int ph = 0; ph < L.nphase; ++ph)
+        for (int gi = 0; gi < L.ngroups; ++gi)
+            for (float v : L.g[gi].packed[ph]) maxabs = std::max(maxabs, std::fabs(v));
+    L.wshift = 0;
+    if (maxabs > 0.f && std::isfinite(maxabs)) {
+        int e;
+        std::frexp(maxabs, &e);           // maxabs = m * 2^e, m in [0.5, 1)
+        L.wshift = std::max(-24, std::min(30, 14 - e));
+    }
+    const float wscale = std::ldexp(1.f, L.wshift);
+
+    // choose octets per chunk (OC) and k-steps per stage (S): minimise executed k-steps, then maximise S
+    int noct[2] = {0, 0};
+    for (int gi = 0; gi < L.ngroups; ++gi) noct[gi] = round_up(L.g[gi].C, 8) / 8;
+    auto ksteps_for = [&](int OC) {
+        int total = 0;
+        for (int ph = 0; ph < L.nphase; ++ph)
+            for (int gi = 0; gi < L.ngroups; ++gi) {
+                const int nt = (int)L.g[gi].taps[ph].size();
+                if (!nt) continue;
+                const int nchunk = (noct[gi] + OC - 1) / OC;
+                for (int c = 0; c < nchunk; ++c) {
+                    const int o0 = c * noct[gi] / nchunk, o1 = (c + 1) * noct[gi] / nchunk;
+                    total += (nt * (o1 - o0) + 3) / 4;
+                }
+            }
+        return total;
+    };
+    int bestOC = 0, bestS = 0, bestK = 1 << 30;
+    for (int OC = 1; OC <= 8; ++OC) {
+        const int room = kMaxLdsPerWG - OC * plane_pair;
+        if (room < L.nt * 2048) continue;
+        const int S = std::min(kStageK, room / (L.nt * 2048));
+        const int k = ksteps_for(OC);
+        // prefer fewer k-steps; among near-equal (within 2%) prefer the conflict-free OC = 4 and larger stages
+        const bool better = k * 100 < bestK * 98 || (k * 100 <= bestK * 102 && (S > bestS || (S == bestS && OC == 4)));
+        if (bestOC == 0 || better) { bestOC = OC; bestS = S; bestK = k; }
+    }
+    if (!bestOC) { *why = "LDS footprint too large for the split-precision kernel"; return UMX_ERR_INVALID; }
+    const int OC = bestOC, S = bestS;
+    h.lo_off = OC * h.plane_slots * 16;
+    h.b_off = 2 * h.lo_off;
+    h.lds_bytes = h.b_off + S * L.nt * 2048;
+
+    std::vector<HStage> stages;
+    std::vector<unsigned short> kmap;
+    std::vector<std::vector<_Float16>> wimg(L.nphase);   // per phase: [nblk][...] halves
+    L.n_ksteps = 0;
+    for (int ph = 0; ph < L.nphase; ++ph) {
+        h.ph[ph].oy_off = L.oy_off[ph];
+        h.ph[ph].ox_off = L.ox_off[ph];
+        h.ph[ph].stage0 = (int)stages.size();
+        struct Pair { int gi, tap, oct, plane; };
+        std::vector<std::vector<Pair>> steps;   // k-steps of this phase, each 4 pairs (padded ones have tap = -1)
+        for (int gi = 0; gi < L.ngroups; ++gi) {
+            const int nt = (int)L.g[gi].taps[ph].size();
+            if (!nt) continue;
+            const int nchunk = (noct[gi] + OC - 1) / OC;
+            for (int c = 0; c < nchunk; ++c) {
+                const int o0 = c * noct[gi] / nchunk, o1 = (c + 1) * noct[gi] / nchunk;
+                std::vector<Pair> pairs;
+                for (int t = 0; t < nt; ++t)
+                    for (int o = o0; o < o1; ++o) pairs.push_back({gi, t, o, o - o0});
+                while (pairs.size() % 4) pairs.push_back({gi, -1, o0, 0});   // zero-weight filler, reads a loaded slot
+                const int nk_chunk = (int)pairs.size() / 4;
+                for (int k = 0; k < nk_chunk; k += S) {
+                    HStage st;
+                    st.woff = 0;  // filled below
+                    st.group = k == 0 ? (short)gi : (short)-1;
+                    st.oct0 = (short)o0;
+                    st.noct = (short)(o1 - o0);
+                    st.nk = (short)std::min(S, nk_chunk - k);
+                    st.k0 = (int)kmap.size() / 4;
+                    for (int j = 0; j < st.nk; ++j) {
+                        std::vector<Pair> four(pairs.begin() + (k + j) * 4, pairs.begin() + (k + j) * 4 + 4);
+                        for (auto& pr : four) {
+                            const auto& tp = L.g[gi].taps[ph][pr.tap < 0 ? 0 : pr.tap];
+                            const int tapoff = (tp.first - g.ymin) * g.hw + (tp.second - g.xmin);
+                            kmap.push_back((unsigned short)(pr.plane * h.plane_slots + tapoff));
+                        }
+                        steps.push_back(four);
+                    }
+                    stages.push_back(st);
+                }
+            }
+        }
+        h.ph[ph].nstages = (int)stages.size() - h.ph[ph].stage0;
+        L.n_ksteps += (int)steps.size();
+        // weight images: [nblk][k-step][n][hi|lo][lane][8]; stage woff = running k-step offset
+        const size_t per_blk = steps.size() * (size_t)L.nt * 2 * 64 * 8;
+        h.ph[ph].wblk_stride = (int)(per_blk / 8);
+        {
+            int kofs = 0;
+            for (int si = h.ph[ph].stage0; si < (int)stages.size(); ++si) {
+                stages[si].woff = kofs * L.nt * 2 * 64;
+                kofs += stages[si].nk;
+            }
+        }
+        std::vector<_Float16>& W = wimg[ph];
+        W.assign(per_blk * h.nblocks, (_Float16)0.f);
+        for (int nb = 0; nb < h.nblocks; ++nb)
+            for (size_t ks = 0; ks < steps.size(); ++ks)
+                for (int n = 0; n < L.nt; ++n)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const Pair& pr = steps[ks][lane >> 4];
+                        if (pr.tap < 0) continue;
+                        const Group& G = L.g[pr.gi];
+                        const int Cp = round_up(G.C, 4);
+                        const int co = nb * L.nt * 16 + n * 16 + (lane & 15);
+                        const size_t base = nb * per_blk + ((ks * L.nt + n) * 2) * 512 + (size_t)lane * 8;
+                        for (int j = 0; j < 8; ++j) {
+                            const int c = pr.oct * 8 + j;
+                            if (c >= G.C || co >= L.Cout) continue;
+                            const float v = G.packed[ph][((size_t)pr.tap * Cp + c) * L.Np + co] * wscale;
+                            const _Float16 hi = (_Float16)v;
+                            W[base + j] = hi;
+                            W[base + 512 + j] = (_Float16)(v - (float)hi);
+                        }
+                    }
+    }
+    if (kmap.size() / 4 > 60000) { *why = "too many k-steps"; return UMX_ERR_INVALID; }
+    for (unsigned short v : kmap)
+        if ((int)v >= OC * h.plane_slots) { *why = "internal: k-map slot out of range"; return UMX_ERR_INVALID; }
+
+    // epilogue constants: pre_s absorbs 2^-(weight shift + input activation shift)
+    std::vector<float> ps(L.Cout);
+    const float unshift = std::ldexp(1.f, -(L.wshift + act_shift));
+    for (int c = 0; c < L.Cout; ++c) ps[c] = (L.pre_s.empty() ? 1.f : L.pre_s[c]) * unshift;
+    int rc;
+    if ((rc = upload(ctx, ps, &L.d_pre_s16))) return rc;
+    h.pre_s = L.d_pre_s16; h.pre_b = L.d_pre_b; h.post_s = L.d_post_s; h.post_b = L.d_post_b;
+    h.out_scale = out_f32 ? 1.f : std::ldexp(1.f, act_shift);
+    HStage* d_st = nullptr;
+    unsigned short* d_km = nullptr;
+    if ((rc = upload_raw(ctx, stages, &d_st)) || (rc = upload_raw(ctx, kmap, &d_km))) return rc;
+    h.stages = d_st;
+    h.kmap = d_km;
+    for (int ph = 0; ph < L.nphase; ++ph) {
+        _Float16* d = nullptr;
+        if ((rc = upload_raw(ctx, wimg[ph], &d))) return rc;
+        h.ph[ph].w = reinterpret_cast<const uint4*>(d);
+    }
+    L.exec_flops = 2.0 * 3.0 * (double)L.n_ksteps * 32.0 * (L.Np) * L.H * L.W;   // MFMA work incl. split and padding
+    return UMX_OK;
+}
+
 int grow(umx_ctx* ctx, void** buf, size_t* cap, size_t bytes) {
     if (*cap >= bytes) return UMX_OK;
     if (*buf) {
@@ -531,7 +732,7 @@ struct ProfScope {
     int site;
     hipEvent_t a = nullptr, b = nullptr;
     bool on;
-    ProfScope(umx_ctx* c, int s, double flops, double bytes) : ctx(c), site(s), on(c->prof && s >= 0) {
+    ProfScope(umx_ctx* c, int s, double flops, double bytes, double exec = 0.0) : ctx(c), site(s), on(c->prof && s >= 0) {
         if (!on) return;
         auto get = [&](hipEvent_t* e) {
             if (!ctx->free_events.empty()) { *e = ctx->free_events.back(); ctx->free_events.pop_back(); }
@@ -543,6 +744,7 @@ struct ProfScope {
         ctx->sites[site].launches += 1;
         ctx->sites[site].flops += flops;
         ctx->sites[site].bytes += bytes;
+        ctx->sites[site].exec += exec;
         hipEventRecord(a, ctx->stream);
     }
     ~ProfScope() {
@@ -553,7 +755,58 @@ struct ProfScope {
 };
 
 // run the UNet on n tiles already in bufs[0] layout at `tiles` -> probs
+// the (hi, lo) planes of buffer b for a batch of n tiles
+inline _Float16* hi_of(const Buffer& b) { return reinterpret_cast<_Float16*>(b.d); }
+inline _Float16* lo_of(const Buffer& b, int n) { return reinterpret_cast<_Float16*>(b.d) + (size_t)n * b.S * b.S * b.Cs; }
+
+int run_unet_f16(umx_ctx* ctx, const float* tiles, int n, float* probs) {
+    {   // fp32 tiles -> (hi, lo) input planes (2 -> 8 channels, scaled by 2^act_shift)
+        const Buffer& b0 = ctx->bufs[0];
+        if (ctx->site_split < 0) ctx->site_split = site_of(ctx, "input.split", "split_f32");
+        ProfScope ps(ctx, ctx->site_split, 0.0, (double)n * b0.S * b0.S * (4.0 * b0.C + 4.0 * b0.Cs));
+        HIP_TRY(ctx, launch_split_f32(tiles, (size_t)n * b0.S * b0.S, b0.C, b0.Cs, std::ldexp(1.f, ctx->act_shift), hi_of(b0),
+                                      lo_of(b0, n), ctx->stream));
+    }
+    for (auto& L : ctx->plan) {
+        if (L.head) {
+            const size_t npix = (size_t)n * L.H * L.W;
+            ProfScope ps(ctx, site_of(ctx, L.name, "head_softmax"), L.flops * n, L.bytes * n);
+            HIP_TRY(ctx, launch_head_softmax(ctx->bufs[L.g[0].src].d, npix, L.head_C, L.head_K, L.d_head_w, L.d_pre_s,
+                                             L.d_pre_b, probs, ctx->stream));
+            continue;
+        }
+        HConvParams p = L.hcp;
+        p.B = n;
+        for (int gi = 0; gi < L.ngroups; ++gi) {
+            const Buffer& sb = ctx->bufs[L.g[gi].src];
+            p.src_hi[gi] = hi_of(sb);
+            p.src_lo[gi] = lo_of(sb, n);
+            p.Cs[gi] = sb.Cs;
+        }
+        const Buffer& db = ctx->bufs[L.dst];
+        if (db.as_f32) p.dst_f32 = db.d;
+        else { p.dst_hi = hi_of(db); p.dst_lo = lo_of(db, n); }
+        char kn[48];
+        snprintf(kn, sizeof kn, "conv_f16x3<NT=%d>", L.nt);
+        ProfScope ps(ctx, site_of(ctx, L.name, kn), L.flops * n, L.bytes * n, L.exec_flops * n);
+        HIP_TRY(ctx, launch_conv_f16(p, ctx->stream));
+    }
+    if (ctx->prof && ctx->pending.size() > 4096) return prof_fold(ctx);
+    return UMX_OK;
+}
+
+int check_range_flag(umx_ctx* ctx) {   // call with the stream idle
+    if (!ctx->d_flag) return UMX_OK;
+    int f = 0;
+    HIP_TRY(ctx, hipMemcpy(&f, ctx->d_flag, sizeof f, hipMemcpyDeviceToHost));
+    if (!f) return UMX_OK;
+    HIP_TRY(ctx, hipMemset(ctx->d_flag, 0, sizeof f));
+    return fail(ctx, UMX_ERR_RANGE, "an activation left the binary16 range of the split-precision path; "
+                                    "create the context with UMX_PREC_F32 (or UMX_PRECISION=f32)");
+}
+
 int run_unet(umx_ctx* ctx, const float* tiles, int n, float* probs) {
+    if (ctx->precision == UMX_PREC_F16X3) return run_unet_f16(ctx, tiles, n, probs);
     const umx_hparams& hp = ctx->hp;
     for (auto& L : ctx->plan) {
         const float* src0 = L.g[0].src == 0 ? tiles : ctx->bufs[L.g[0].src].d;
@@ -571,7 +824,7 @@ int run_unet(umx_ctx* ctx, const float* tiles, int n, float* probs) {
         p.dst = ctx->bufs[L.dst].d;
         char kn[48];
         snprintf(kn, sizeof kn, "conv_mfma_f32<NT=%d,HPIX=%d>", L.nt, L.hpix);
-        ProfScope ps(ctx, site_of(ctx, L.name, kn), L.flops * n, L.bytes * n);
+        ProfScope ps(ctx, site_of(ctx, L.name, kn), L.flops * n, L.bytes * n, L.exec_flops * n);
         HIP_TRY(ctx, launch_conv(p, L.nt, L.hpix, ctx->stream));
     }
     if (ctx->prof && ctx->pending.size() > 4096) return prof_fold(ctx);
@@ -642,8 +895,34 @@ int umx_describe(const umx_hparams* hp, int* n_launches, double* flops_per_tile,
 
 int umx_create(const umx_hparams* hp, const float* weight_blob, size_t blob_floats, int device_ordinal, int max_batch,
                umx_ctx** out) {
+    umx_options o;
+    memset(&o, 0, sizeof o);
+    o.device_ordinal = device_ordinal;
+    o.max_batch = max_batch;
+    o.precision = UMX_PREC_DEFAULT;
+    o.act_shift = -1;
+    return umx_create_opts(hp, weight_blob, blob_floats, &o, out);
+}
+
+int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob_floats, const umx_options* opts,
+                    umx_ctx** out) {
     if (!out) return fail(nullptr, UMX_ERR_INVALID, "out is NULL");
     *out = nullptr;
+    if (!opts) return fail(nullptr, UMX_ERR_INVALID, "opts is NULL");
+    const int device_ordinal = opts->device_ordinal, max_batch = opts->max_batch;
+    int precision = opts->precision;
+    if (precision == UMX_PREC_DEFAULT) {
+        const char* e = getenv("UMX_PRECISION");
+        precision = (e && !strcmp(e, "f32")) ? UMX_PREC_F32 : UMX_PREC_F16X3;
+    }
+    if (precision != UMX_PREC_F32 && precision != UMX_PREC_F16X3)
+        return fail(nullptr, UMX_ERR_INVALID, "unknown precision %d", precision);
+    int act_shift = opts->act_shift;
+    if (act_shift < 0) {
+        const char* e = getenv("UMX_ACT_SHIFT");
+        act_shift = e ? atoi(e) : 0;
+    }
+    if (act_shift < 0 || act_shift > 8) return fail(nullptr, UMX_ERR_INVALID, "act_shift must be in [0,8]");
     std::string why;
     int rc = check_hp(hp, &why);
     if (rc) return fail(nullptr, rc, "%s", why.c_str());
@@ -668,6 +947,8 @@ int umx_create(const umx_hparams* hp, const float* weight_blob, size_t blob_floa
     ctx->hp = *hp;
     ctx->device = device_ordinal;
     ctx->max_batch = max_batch;
+    ctx->precision = precision;
+    ctx->act_shift = act_shift;
     umx_ctx* c = ctx.get();
     HIP_TRY(nullptr, hipSetDevice(device_ordinal));
     HIP_TRY(nullptr, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -679,11 +960,33 @@ int umx_create(const umx_hparams* hp, const float* weight_blob, size_t blob_floa
     c->plan = std::move(b.plan);
     c->bufs.resize(b.buf_floats.size());
     auto bail = [&](int code) { std::string m = c->err; umx_destroy(ctx.release()); g_err = m; return code; };
+    const bool f16 = precision == UMX_PREC_F16X3;
+    const int head_src = c->plan.back().g[0].src;   // the tensor the softmax head reads stays fp32
     for (size_t i = 0; i < c->bufs.size(); ++i) {
-        c->bufs[i].floats_per_tile = b.buf_floats[i];
+        Buffer& B = c->bufs[i];
+        B.floats_per_tile = b.buf_floats[i];
+        B.S = b.buf_geom[i].first;
+        B.C = b.buf_geom[i].second;
+        B.Cs = round_up(B.C, 8);
+        B.as_f32 = !f16 || (int)i == head_src;
+        // (hi, lo) binary16 planes with Cs channels take 4*Cs bytes per pixel
+        const size_t bytes_per_tile = B.as_f32 ? B.floats_per_tile * sizeof(float) : (size_t)B.S * B.S * B.Cs * 4;
         void* d = nullptr;
-        if ((rc = dev_alloc(c, &d, b.buf_floats[i] * sizeof(float) * (size_t)max_batch))) return bail(rc);
-        c->bufs[i].d = (float*)d;
+        if ((rc = dev_alloc(c, &d, bytes_per_tile * (size_t)max_batch))) return bail(rc);
+        B.d = (float*)d;
+    }
+    if (f16) {
+        void* d = nullptr;
+        if ((rc = dev_alloc(c, &d, c->bufs[0].floats_per_tile * sizeof(float) * (size_t)max_batch))) return bail(rc);
+        c->d_tiles32 = (float*)d;
+        if ((rc = dev_alloc(c, &d, 256))) return bail(rc);
+        c->d_zeros = (uint4*)d;
+        if ((rc = dev_alloc(c, &d, 256))) return bail(rc);
+        c->d_flag = (int*)d;
+        if (hipMemset(c->d_zeros, 0, 256) != hipSuccess || hipMemset(c->d_flag, 0, 256) != hipSuccess) {
+            c->err = "hipMemset failed";
+            return bail(UMX_ERR_HIP);
+        }
     }
     for (auto& L : c->plan) {
         if ((rc = upload(c, L.pre_s, &L.d_pre_s)) || (rc = upload(c, L.pre_b, &L.d_pre_b)) ||
@@ -694,6 +997,17 @@ int umx_create(const umx_hparams* hp, const float* weight_blob, size_t blob_floa
             continue;
         }
         if (!conv_geometry(L, &why)) { c->err = L.name + ": " + why; return bail(UMX_ERR_INVALID); }
+        if (f16) {
+            if ((rc = plan_f16(c, L, act_shift, L.dst == head_src, &why))) {
+                if (c->err.empty() || !why.empty()) c->err = L.name + ": " + why;
+                return bail(rc);
+            }
+            L.hcp.zeros = c->d_zeros;
+            L.hcp.overflow_flag = c->d_flag;
+            for (int ph = 0; ph < L.nphase; ++ph)
+                for (int gi = 0; gi < L.ngroups; ++gi) std::vector<float>().swap(L.g[gi].packed[ph]);
+            continue;
+        }
         for (int ph = 0; ph < L.nphase; ++ph)
             for (int gi = 0; gi < L.ngroups; ++gi) {
                 float* d = nullptr;
@@ -706,6 +1020,8 @@ int umx_create(const umx_hparams* hp, const float* weight_blob, size_t blob_floa
     *out = ctx.release();
     return UMX_OK;
 }
+
+int umx_precision_of(const umx_ctx* ctx) { return ctx ? ctx->precision : UMX_PREC_DEFAULT; }
 
 void umx_destroy(umx_ctx* ctx) {
     if (!ctx) return;
@@ -733,7 +1049,7 @@ int umx_set_stream(umx_ctx* ctx, void* hip_stream) {
 int umx_synchronize(umx_ctx* ctx) {
     if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return UMX_OK;
+    return check_range_flag(ctx);
 }
 
 int umx_forward_tiles_dev(umx_ctx* ctx, const float* tiles_dev, int n, float* probs_dev) {
@@ -764,7 +1080,7 @@ int umx_forward_tiles(umx_ctx* ctx, const float* tiles_host, int n, float* probs
     if ((rc = umx_forward_tiles_dev(ctx, ctx->d_io_tiles, n, ctx->d_io_probs))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(probs_host, ctx->d_io_probs, prob_b * n, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return UMX_OK;
+    return check_range_flag(ctx);
 }
 
 int umx_tile_grid(const umx_ctx* ctx, int H, int W, int* patch_rows, int* patch_cols, int* padded_rows,
@@ -797,14 +1113,15 @@ int umx_band_tiles_dev(umx_ctx* ctx, const double* image_dev, int C_img, int H, 
     const int t0 = pr0 * g.npc, t1 = pr1 * g.npc;
     const size_t prob_f = (size_t)g.P * g.P * ctx->hp.nClasses;
     if (ctx->site_gather < 0) ctx->site_gather = site_of(ctx, "pi2d.gather_normalise", "gather_normalise");
+    float* const tiles32 = ctx->precision == UMX_PREC_F16X3 ? ctx->d_tiles32 : ctx->bufs[0].d;
     for (int t = t0; t < t1; t += ctx->max_batch) {
         const int nb = std::min(ctx->max_batch, t1 - t);
         {
             ProfScope ps(ctx, ctx->site_gather, 0.0, (double)nb * g.P * g.P * (8.0 + 4.0 * ctx->hp.nChannels));
             HIP_TRY(ctx, launch_gather_normalise(image_dev, C_img, band_row0, band_rows, g, ctx->hp.nChannels, mean, stdv, t,
-                                                 nb, ctx->bufs[0].d, ctx->stream));
+                                                 nb, tiles32, ctx->stream));
         }
-        int rc = run_unet(ctx, ctx->bufs[0].d, nb, probs_dev + (size_t)(t - t0) * prob_f);
+        int rc = run_unet(ctx, tiles32, nb, probs_dev + (size_t)(t - t0) * prob_f);
         if (rc) return rc;
     }
     return UMX_OK;
@@ -862,7 +1179,7 @@ int umx_infer_image(umx_ctx* ctx, const double* image_host, int C_img, int H, in
     if ((rc = umx_infer_image_dev(ctx, ctx->d_image, C_img, H, W, mean, stdv, mode, stitch, ctx->d_out))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(out_host, ctx->d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return UMX_OK;
+    return check_range_flag(ctx);
 }
 
 int umx_profile_enable(umx_ctx* ctx, int on) {
@@ -870,7 +1187,7 @@ int umx_profile_enable(umx_ctx* ctx, int on) {
     int rc = prof_fold(ctx);
     if (rc) return rc;
     ctx->prof = on != 0;
-    for (auto& s : ctx->sites) { s.launches = 0; s.total_ms = 0; s.flops = 0; s.bytes = 0; }
+    for (auto& s : ctx->sites) { s.launches = 0; s.total_ms = 0; s.flops = 0; s.bytes = 0; s.exec = 0; }
     return UMX_OK;
 }
 
@@ -890,6 +1207,7 @@ int umx_profile_read(umx_ctx* ctx, umx_prof_entry* entries, int max_entries, int
             e.total_ms = s.total_ms;
             e.flops_per_launch_sum = s.flops;
             e.bytes_per_launch_sum = s.bytes;
+            e.exec_flops_sum = s.exec;
         }
         ++n;
     }

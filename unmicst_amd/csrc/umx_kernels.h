@@ -51,6 +51,60 @@ constexpr int kModeReplace = 1;   // == UMX_MODE_REPLACE
 size_t conv_lds_bytes(int nt, int plane);
 hipError_t launch_conv(const ConvParams& p, int nt, int hpix, hipStream_t stream);
 
+// ---- split-precision (3 x fp16 MFMA) convolution, umx_conv_f16.hip --------------------------------------------
+constexpr int kHaloChunks = 16;  // 64-slot pieces of the LDS halo per plane (halo <= 1024 pixels, the fp32 kernel's limit too)
+constexpr int kStageK = 4;       // max k-steps (of 32 K-slots = 4 (tap, octet) pairs) per weight stage
+constexpr int kMaxLdsPerWG = 80 * 1024;   // two workgroups per CU share the 160 KiB
+
+struct HStage {      // one pipeline stage: optional halo (re)load + nk k-steps of weights
+    int woff;        // offset (uint4 units) of this stage's weight images inside one (phase, N-block) slab
+    short group;     // operand group whose halo is loaded at this stage, or -1 (halo already resident)
+    short oct0;      // first octet (8 channels) of that group to load ...
+    short noct;      // ... and how many: LDS planes 0..noct-1
+    short nk;        // k-steps in this stage (<= kStageK)
+    int k0;          // first k-step in HConvParams::kmap
+};
+
+struct HPhase {
+    const uint4* w;     // packed weights of this phase: [N-block][stage][k-step][N-tile][hi|lo][64 lanes] x 16 B
+    int wblk_stride;    // uint4 per N-block
+    int stage0, nstages;
+    int oy_off, ox_off;
+};
+
+struct HConvParams {
+    const _Float16* src_hi[2];   // NHWC binary16 [B,H,W,Cs], hi and lo planes
+    const _Float16* src_lo[2];
+    int Cs[2];                   // stored channels (multiple of 8)
+    int B, H, W;
+    int Cout, Cds, NT, nblocks;  // real / stored output channels; N-tiles per workgroup; N blocks
+    int twm_log2, th_log2, nimg_m, imgs;
+    int hh, hw, imgplane, nhalo; // halo geometry in pixels; nhalo = imgs * imgplane
+    int plane_slots;             // 16-byte slots per LDS plane (nhalo rounded up to a multiple of 16)
+    int lo_off, b_off, lds_bytes;  // LDS byte offsets: lo planes, weight images; total dynamic LDS
+    int ymin, xmin, tiles_y, tiles_x;
+    int nphase, o_mul;
+    HPhase ph[4];
+    const HStage* stages;
+    const unsigned short* kmap;  // [k-step][4]: LDS slot (plane * plane_slots + tap offset) feeding lanes 16q..16q+15
+    const uint4* zeros;          // >= 16 bytes of zeros in global memory (source for out-of-image halo slots)
+    _Float16* dst_hi;
+    _Float16* dst_lo;
+    float* dst_f32;              // non-NULL: write fp32 NHWC [..,Cout] instead of the (hi, lo) pair
+    int outH, outW, pool;
+    const float* pre_s;          // [Cout], never NULL here: BN scale (or 1) times 2^-(weight shift + activation shift)
+    const float* pre_b;
+    const float* post_s;
+    const float* post_b;
+    int act;
+    float out_scale;             // 2^(activation shift) applied before the split
+    int* overflow_flag;
+};
+
+hipError_t launch_conv_f16(const HConvParams& p, hipStream_t stream);
+hipError_t launch_split_f32(const float* x, size_t npix, int C, int Cs, float scale, _Float16* hi, _Float16* lo,
+                            hipStream_t stream);
+
 struct TileGeom {
     int H, W;            // full image size
     int P, margin, sub;  // patch size, margin, sub-patch

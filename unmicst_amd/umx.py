@@ -15,12 +15,14 @@ from . import build as _build
 from .model import HParams
 
 UMX_OK = 0
+PREC_DEFAULT, PREC_F32, PREC_F16X3 = 0, 1, 2      # enum umx_precision
+PRECISIONS = {"default": PREC_DEFAULT, "f32": PREC_F32, "f16x3": PREC_F16X3}
 MODE_ACCUMULATE, MODE_REPLACE = 0, 1
 STITCH_FP16_COMPAT, STITCH_FP32 = 0, 1
 
 # every symbol include/umx.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "umx_device_count", "umx_device_mem_info", "umx_create", "umx_destroy", "umx_last_error", "umx_set_stream", "umx_synchronize",
+    "umx_device_count", "umx_device_mem_info", "umx_create", "umx_create_opts", "umx_precision_of", "umx_destroy", "umx_last_error", "umx_set_stream", "umx_synchronize",
     "umx_forward_tiles", "umx_forward_tiles_dev", "umx_tile_grid", "umx_infer_image", "umx_infer_image_dev",
     "umx_band_tiles_dev", "umx_stitch_dev", "umx_profile_enable", "umx_profile_read", "umx_test_double_to_half",
     "umx_describe", "umx_version",
@@ -38,9 +40,15 @@ class _HP(ctypes.Structure):
                 ("graph", "imSize", "nChannels", "nClasses", "nOut0", "nLayers", "ks", "nExtraConvs", "featMapsFact")]
 
 
+class _Options(ctypes.Structure):
+    _fields_ = [("device_ordinal", ctypes.c_int32), ("max_batch", ctypes.c_int32), ("precision", ctypes.c_int32),
+                ("act_shift", ctypes.c_int32), ("reserved", ctypes.c_int32 * 12)]
+
+
 class ProfEntry(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 48), ("kernel", ctypes.c_char * 48), ("launches", ctypes.c_int64),
-                ("total_ms", ctypes.c_double), ("flops", ctypes.c_double), ("bytes", ctypes.c_double)]
+                ("total_ms", ctypes.c_double), ("flops", ctypes.c_double), ("bytes", ctypes.c_double),
+                ("exec_flops", ctypes.c_double)]
 
 
 _lib = None
@@ -94,6 +102,11 @@ def load(path: Optional[str] = None):
     L.umx_device_mem_info.argtypes = [c_int, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
     L.umx_create.restype = c_int
     L.umx_create.argtypes = [ctypes.POINTER(_HP), c_void_p, ctypes.c_size_t, c_int, c_int, ctypes.POINTER(c_void_p)]
+    L.umx_create_opts.restype = c_int
+    L.umx_create_opts.argtypes = [ctypes.POINTER(_HP), c_void_p, ctypes.c_size_t, ctypes.POINTER(_Options),
+                                  ctypes.POINTER(c_void_p)]
+    L.umx_precision_of.restype = c_int
+    L.umx_precision_of.argtypes = [c_void_p]
     L.umx_destroy.restype = None
     L.umx_destroy.argtypes = [c_void_p]
     L.umx_last_error.restype = ctypes.c_char_p
@@ -167,18 +180,23 @@ def double_to_half(x: np.ndarray) -> np.ndarray:
 class Engine:
     """One umx_ctx: a model resident on one MI355X."""
 
-    def __init__(self, hp: HParams, blob: np.ndarray, device: int = 0, max_batch: int = 32):
+    def __init__(self, hp: HParams, blob: np.ndarray, device: int = 0, max_batch: int = 32,
+                 precision="default", act_shift: int = -1):
+        """precision: "default" (f16x3 unless UMX_PRECISION=f32), "f32" (exact fp32 MFMA) or "f16x3" (three binary16
+        MFMA products per fp32 product, fp32 accumulation) -- both hold the 1e-4 tolerance."""
         self._L = load()
         self.hp = hp
         self._ctx = ctypes.c_void_p()
         blob = np.ascontiguousarray(blob, dtype="<f4")
         h = _hp_struct(hp)
-        rc = self._L.umx_create(ctypes.byref(h), blob.ctypes.data, blob.size, int(device), int(max_batch),
-                                ctypes.byref(self._ctx))
+        o = _Options(int(device), int(max_batch), PRECISIONS.get(precision, precision), int(act_shift))
+        rc = self._L.umx_create_opts(ctypes.byref(h), blob.ctypes.data, blob.size, ctypes.byref(o),
+                                     ctypes.byref(self._ctx))
         if rc:
             raise UmxError(rc, self._L.umx_last_error(None).decode())
         self.device = device
         self.max_batch = max_batch
+        self.precision = {PREC_F32: "f32", PREC_F16X3: "f16x3"}[self._L.umx_precision_of(self._ctx)]
 
     # -- lifetime
     def close(self) -> None:
@@ -271,5 +289,6 @@ class Engine:
         for i in range(min(n.value, 256)):
             e = arr[i]
             out.append({"name": e.name.decode(), "kernel": e.kernel.decode(), "launches": int(e.launches),
-                        "total_ms": float(e.total_ms), "flops": float(e.flops), "bytes": float(e.bytes)})
+                        "total_ms": float(e.total_ms), "flops": float(e.flops), "bytes": float(e.bytes),
+                        "exec_flops": float(e.exec_flops)})
         return out
