@@ -11,7 +11,11 @@ passes (FETCH_SIZE, WRITE_SIZE: KiB per dispatch) are averaged per (kernel, grid
 gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE reports half the bytes of wide coalesced
 reads) is applied in the ``hbm_read_MB_corrected`` column.
 
-usage: summarize_rocprof.py <kernel_trace.csv | results.db> [--pmc results.db ...] [-o out.csv]
+With ``--cycle SUBSTR`` dispatches are additionally keyed by their position since the last kernel whose name
+contains SUBSTR (e.g. ``gather_normalise``: one UNet pass = gather, split, conv x16, head), which separates layers that
+share a (kernel, grid) pair; ``--names a,b,c`` labels the positions.
+
+usage: summarize_rocprof.py <kernel_trace.csv | results.db> [--pmc results.db ...] [--cycle SUBSTR] [-o out.csv]
 """
 import argparse
 import csv
@@ -36,19 +40,42 @@ def rows_from_csv(path):
 def rows_from_db(path):
     c = sqlite3.connect(path)
     q = ("select name, grid_x / workgroup_x, grid_y, grid_z, lds_size, vgpr_count + accum_vgpr_count, duration "
-         "from kernels")
+         "from kernels order by start")
     for r in c.execute(q):
         yield r
 
 
-def pmc_from_db(path):
-    """-> {counter: {(kernel, wg_x, grid_y, grid_z): [sum, n]}}"""
+class Cycle:
+    """position of a dispatch since the last kernel whose name contains `marker` (-1 before the first one)"""
+
+    def __init__(self, marker):
+        self.marker, self.pos = marker, -1
+
+    def step(self, name):
+        if not self.marker:
+            return 0
+        if self.marker in name:
+            self.pos = 0
+        elif self.pos >= 0:
+            self.pos += 1
+        return self.pos
+
+
+def pmc_from_db(path, marker):
+    """-> {counter: {(pos, kernel, wg_x, grid_y, grid_z): [sum, n]}}"""
     c = sqlite3.connect(path)
     out = {}
-    q = ("select counter_name, kernel_name, grid_size_x / workgroup_size_x, grid_size_y, grid_size_z, value "
-         "from counters_collection")
-    for cn, kn, gx, gy, gz, v in c.execute(q):
-        e = out.setdefault(cn, {}).setdefault((short(kn), gx, gy, gz), [0.0, 0])
+    q = ("select counter_name, kernel_name, grid_size_x / workgroup_size_x, grid_size_y, grid_size_z, value, dispatch_id "
+         "from counters_collection order by dispatch_id, counter_name")
+    cyc, last = Cycle(marker), None
+    pos = 0
+    for cn, kn, gx, gy, gz, v, did in c.execute(q):
+        if did != last:
+            pos = cyc.step(kn)
+            last = did
+        if "umx::" not in kn:
+            continue
+        e = out.setdefault(cn, {}).setdefault((pos, short(kn), gx, gy, gz), [0.0, 0])
         e[0] += v
         e[1] += 1
     return out
@@ -60,36 +87,41 @@ def main():
     ap.add_argument("--pmc", nargs="*", default=[])
     ap.add_argument("-o", "--out")
     ap.add_argument("--all", action="store_true", help="keep kernels outside the umx:: namespace")
+    ap.add_argument("--cycle", default="", help="kernel-name substring that starts a cycle of dispatches")
+    ap.add_argument("--names", default="", help="comma-separated labels of the cycle positions")
     a = ap.parse_args()
     src = rows_from_db(a.trace) if a.trace.endswith(".db") else rows_from_csv(a.trace)
     rows = OrderedDict()
+    cyc = Cycle(a.cycle)
     for name, gx, gy, gz, lds, vg, d in src:
+        pos = cyc.step(name)
         if "umx::" not in name and not a.all:
             continue
-        e = rows.setdefault((short(name), gx, gy, gz, lds, vg), [0, 0, 1 << 62, 0])
+        e = rows.setdefault((pos, short(name), gx, gy, gz, lds, vg), [0, 0, 1 << 62, 0])
         e[0] += 1
         e[1] += d
         e[2] = min(e[2], d)
         e[3] = max(e[3], d)
     pmc = {}
     for p in a.pmc:
-        pmc.update(pmc_from_db(p))
+        pmc.update(pmc_from_db(p, a.cycle))
+    names = a.names.split(",") if a.names else []
     counters = sorted(pmc)
     out = open(a.out, "w", newline="") if a.out else sys.stdout
     w = csv.writer(out)
-    head = ["kernel", "workgroups_x", "grid_y", "grid_z", "lds_bytes", "vgprs", "calls", "avg_us", "min_us", "max_us",
-            "total_ms"] + ["%s_avg_KiB" % c for c in counters]
+    head = ["pos", "kernel", "workgroups_x", "grid_y", "grid_z", "lds_bytes", "vgprs", "calls", "avg_us", "min_us", "max_us",
+            "total_ms"] + ["%s_avg%s" % (c, "_KiB" if c.endswith("_SIZE") else "") for c in counters]
     if "FETCH_SIZE" in pmc:
         head.append("hbm_read_MB_corrected")
     if "WRITE_SIZE" in pmc:
         head.append("hbm_write_MB")
     w.writerow(head)
     for k, e in sorted(rows.items(), key=lambda kv: -kv[1][1]):
-        line = list(k) + [e[0], round(e[1] / e[0] / 1e3, 2), round(e[2] / 1e3, 2), round(e[3] / 1e3, 2),
+        line = [names[k[0]] if 0 <= k[0] < len(names) else k[0]] + list(k[1:]) + [e[0], round(e[1] / e[0] / 1e3, 2), round(e[2] / 1e3, 2), round(e[3] / 1e3, 2),
                           round(e[1] / 1e6, 3)]
         vals = {}
         for c in counters:
-            s = pmc[c].get(k[:4])
+            s = pmc[c].get(k[:5])
             vals[c] = s[0] / s[1] if s else None
             line.append(round(vals[c], 1) if s else "")
         if "FETCH_SIZE" in pmc:

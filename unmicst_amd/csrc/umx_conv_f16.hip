@@ -125,25 +125,23 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
             if (j < st.nk) {
                 const unsigned char* const ap = smem + kb[j];
                 const unsigned char* const bp = Bl + j * (NT * 2048) + lane * 16;
-                h8 ah[kMT], al[kMT], bh[NT], bl[NT];
+                h8 ah[kMT], al[kMT];
 #pragma unroll
                 for (int m = 0; m < kMT; ++m) {
                     ah[m] = *reinterpret_cast<const h8*>(ap + abase[m]);
                     al[m] = *reinterpret_cast<const h8*>(ap + abase[m] + lo_off);
                 }
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    bh[n] = *reinterpret_cast<const h8*>(bp + n * 2048);
-                    bl[n] = *reinterpret_cast<const h8*>(bp + n * 2048 + 1024);
-                }
+                for (int n = 0; n < NT; ++n) {   // B fragments are streamed: two live at a time
+                    const h8 bh = *reinterpret_cast<const h8*>(bp + n * 2048);
+                    const h8 bl = *reinterpret_cast<const h8*>(bp + n * 2048 + 1024);
 #pragma unroll
-                for (int m = 0; m < kMT; ++m)
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+                    for (int m = 0; m < kMT; ++m) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh, acc[m][n], 0, 0, 0);
                     }
+                }
             }
         }
     }
@@ -178,37 +176,12 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
             }
     if (big && p.dst_f32 == nullptr) atomicOr(p.overflow_flag, 1);   // binary16 range exceeded: the host reports it
 
-    auto store = [&](int img, int oy, int ox, int n, float v) {
-        const int co = ncol0 + n * 16;
-        const size_t pix = (size_t)(img * p.outH + oy) * p.outW + ox;
-        if (p.dst_f32) {
-            if (co < p.Cout) p.dst_f32[pix * p.Cout + co] = v;
-        } else if (co < p.Cds) {
-            const _Float16 h = (_Float16)v;
-            p.dst_hi[pix * p.Cds + co] = h;
-            p.dst_lo[pix * p.Cds + co] = (_Float16)(v - (float)h);
-        }
-    };
-
-    if (p.pool) {
-#pragma unroll
-        for (int m = 0; m < kMT; m += 2) {
-            const int t = wave * kMT + m;
-            const int ig = t >> p.th_log2, ty = t & (TH - 1);
-#pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-                const int i = 4 * q + r;
-                const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
-                const int oy = (y0 + ty) >> 1, ox = (x0 + (i & (TWm - 1))) >> 1;
-                if (img < p.B) {
-#pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        store(img, oy, ox, n, fmaxf(fmaxf(acc[m][n][r], acc[m][n][r + 1]),
-                                                    fmaxf(acc[m + 1][n][r], acc[m + 1][n][r + 1])));
-                }
-            }
-        }
-    } else {
+    if (p.dst_f32) {
+        // fp32 NHWC output (the tensor the softmax head reads): direct stores, 64 B per 16-lane group
+        auto store = [&](int img, int oy, int ox, int n, float v) {
+            const int co = ncol0 + n * 16;
+            if (co < p.Cout) p.dst_f32[((size_t)(img * p.outH + oy) * p.outW + ox) * p.Cout + co] = v;
+        };
 #pragma unroll
         for (int m = 0; m < kMT; ++m) {
             const int t = wave * kMT + m;
@@ -223,6 +196,93 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
                     for (int n = 0; n < NT; ++n) store(img, oy, ox, n, acc[m][n][r]);
                 }
             }
+        }
+        return;
+    }
+
+    // (hi, lo) binary16 output through a per-wave LDS transpose: the C/D layout has one channel per lane (2-byte
+    // stores, 32 B per 16-lane group); staged as [pixel][channel] rows, every lane stores 16 contiguous bytes and a
+    // wave-instruction covers whole pixels' channel vectors (consecutive pixels are contiguous in NHWC).
+    __syncthreads();   // every wave is done with the halo / weight images: LDS is free
+    constexpr int PITCH = NT * 32 + 16;   // bytes per staged pixel row of one plane (16-byte aligned)
+    constexpr int PLANE = 16 * PITCH;
+    constexpr int UR = NT * 2;            // 16-byte units per staged row
+    unsigned char* const stg = smem + wave * (2 * PLANE);
+    const bool odd = li & 1;
+
+    // two values of this lane (rows ra and ra+1, same channel) -> packed channel pairs: even lanes write row ra, odd
+    // lanes row ra+1, after swapping one (hi, lo) pair with the neighbouring lane (one DPP move per two values)
+    auto put2 = [&](int ra, int n, float va, float vb) {
+        const _Float16 ha = (_Float16)va, hb = (_Float16)vb;
+        const _Float16 la = (_Float16)(va - (float)ha), lb = (_Float16)(vb - (float)hb);
+        union { _Float16 h[2]; int i; } pa, pb, rc, wh, wl;
+        pa.h[0] = ha; pa.h[1] = la;
+        pb.h[0] = hb; pb.h[1] = lb;
+        const int give = odd ? pa.i : pb.i;
+        rc.i = __builtin_amdgcn_update_dpp(0, give, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
+        if (odd) { wh.h[0] = rc.h[0]; wh.h[1] = hb; wl.h[0] = rc.h[1]; wl.h[1] = lb; }
+        else { wh.h[0] = ha; wh.h[1] = rc.h[0]; wl.h[0] = la; wl.h[1] = rc.h[1]; }
+        unsigned char* const d = stg + (ra + (odd ? 1 : 0)) * PITCH + (n * 16 + (li & ~1)) * 2;
+        *reinterpret_cast<int*>(d) = wh.i;
+        *reinterpret_cast<int*>(d + PLANE) = wl.i;
+    };
+
+    // staged rows [0, R) -> global; pixel_of(row) gives the NHWC pixel index or -1
+    auto flush = [&](int R, auto pixel_of) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < (16 * UR + 63) / 64; ++k) {
+            const int u = lane + 64 * k;
+            const int row = u / UR, cu = u - row * UR;
+            const int c0 = nblk * (NT * 16) + cu * 8;
+            if (row < R && c0 < p.Cds) {
+                const long pix = pixel_of(row);
+                if (pix >= 0) {
+                    const uint4 vh = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16);
+                    const uint4 vl = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16 + PLANE);
+                    *reinterpret_cast<uint4*>(p.dst_hi + pix * p.Cds + c0) = vh;
+                    *reinterpret_cast<uint4*>(p.dst_lo + pix * p.Cds + c0) = vl;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staged rows are in registers before the next tile overwrites
+    };
+
+    if (p.pool) {
+#pragma unroll
+        for (int m = 0; m < kMT; m += 2) {
+            const int t = wave * kMT + m;
+            const int ig = t >> p.th_log2, ty = t & (TH - 1);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                // pooled pixel j = 2q + r/2 of the 8 this M-tile pair produces
+                const float v0 = fmaxf(fmaxf(acc[m][n][0], acc[m][n][1]), fmaxf(acc[m + 1][n][0], acc[m + 1][n][1]));
+                const float v1 = fmaxf(fmaxf(acc[m][n][2], acc[m][n][3]), fmaxf(acc[m + 1][n][2], acc[m + 1][n][3]));
+                put2(2 * q, n, v0, v1);
+            }
+            flush(8, [&](int j) -> long {
+                const int i = 2 * j;
+                const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
+                if (img >= p.B) return -1;
+                return (long)(img * p.outH + ((y0 + ty) >> 1)) * p.outW + ((x0 + (i & (TWm - 1))) >> 1);
+            });
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) {
+            const int t = wave * kMT + m;
+            const int ig = t >> p.th_log2, ty = t & (TH - 1);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                put2(4 * q, n, acc[m][n][0], acc[m][n][1]);
+                put2(4 * q + 2, n, acc[m][n][2], acc[m][n][3]);
+            }
+            flush(16, [&](int i) -> long {
+                const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
+                if (img >= p.B) return -1;
+                return (long)(img * p.outH + (y0 + ty) * p.o_mul + ph.oy_off) * p.outW +
+                       (x0 + (i & (TWm - 1))) * p.o_mul + ph.ox_off;
+            });
         }
     }
 }
@@ -249,6 +309,9 @@ hipError_t launch_conv_f16(const HConvParams& p, hipStream_t stream) {
         case 4: return launch_h_nt<4>(p, stream);
         case 5: return launch_h_nt<5>(p, stream);
         case 6: return launch_h_nt<6>(p, stream);
+        case 7: return launch_h_nt<7>(p, stream);
+        case 8: return launch_h_nt<8>(p, stream);
+        case 9: return launch_h_nt<9>(p, stream);
         default: return hipErrorInvalidValue;
     }
 }

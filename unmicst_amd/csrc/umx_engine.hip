@@ -60,6 +60,7 @@ struct Launch {
     ConvParams cp;
     // split-precision plan (UMX_PREC_F16X3)
     HConvParams hcp;
+    int nt16 = 1;             // N-tiles per workgroup of the split-precision kernel
     int wshift = 0;           // weights are stored times 2^wshift
     int n_ksteps = 0;         // K-slots of 32 executed per output tile, all phases (for the executed-FLOP figure)
     float* d_pre_s16 = nullptr;
@@ -115,6 +116,9 @@ struct umx_ctx {
     float* d_tiles32 = nullptr; // fp32 staging of gathered tiles before the split (f16 path)
     int* d_flag = nullptr;      // binary16 range overflow flag
     uint4* d_zeros = nullptr;
+    struct Step16 { int launch; int sub; };   // launch index (-1: input split) and sub-batch size (0: whole batch)
+    std::vector<Step16> plan16;
+    Launch split_launch;
 };
 
 namespace {
@@ -536,7 +540,18 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, std::string* 
     h.ymin = g.ymin; h.xmin = g.xmin; h.tiles_y = g.tiles_y; h.tiles_x = g.tiles_x;
     h.nphase = L.nphase; h.o_mul = L.o_mul;
     h.H = L.H; h.W = L.W; h.Cout = L.Cout; h.Cds = round_up(L.Cout, 8);
-    h.NT = L.nt; h.nblocks = L.Np / (16 * L.nt);
+    int nt16 = 1, Np16 = 16;
+    {   // N-tiles per workgroup: minimise padded N, prefer wide workgroups (fewer re-reads of the input halo)
+        const int t16 = (L.Cout + 15) / 16;
+        int best_pad = 1 << 30;
+        for (int c = 1; c <= kMaxNT16; ++c) {
+            const int padded = round_up(t16, c);
+            if (padded < best_pad || (padded == best_pad && c > nt16)) { nt16 = c; best_pad = padded; }
+        }
+        Np16 = best_pad * 16;
+    }
+    L.nt16 = nt16;
+    h.NT = nt16; h.nblocks = Np16 / (16 * nt16);
     h.outH = L.outH; h.outW = L.outW; h.pool = L.pool; h.act = L.act;
     if (h.nhalo > kHaloChunks * 64) { *why = "halo too large for the split-precision kernel"; return UMX_ERR_INVALID; }
     h.plane_slots = round_up(h.nhalo, 16);
@@ -572,11 +587,19 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, std::string* 
             }
         return total;
     };
+    // LDS budget per workgroup: 80 KiB = 2 workgroups per CU; narrow layers (few accumulators -> few VGPRs) are
+    // latency-bound, so they get a smaller budget and 3 workgroups per CU cover each other's load phases
+    int lds_cap = kMaxLdsPerWG;
+    {
+        const char* e = getenv("UMX_LDS_CAP_NARROW");
+        const int narrow = e ? atoi(e) : 53 * 1024;
+        if (nt16 <= 3 && narrow >= 16 * 1024) lds_cap = std::min(lds_cap, narrow);
+    }
     int bestOC = 0, bestS = 0, bestK = 1 << 30;
     for (int OC = 1; OC <= 8; ++OC) {
-        const int room = kMaxLdsPerWG - OC * plane_pair;
-        if (room < L.nt * 2048) continue;
-        const int S = std::min(kStageK, room / (L.nt * 2048));
+        const int room = lds_cap - OC * plane_pair;
+        if (room < nt16 * 2048) continue;
+        const int S = std::min(kStageK, room / (nt16 * 2048));
         const int k = ksteps_for(OC);
         // prefer fewer k-steps; among near-equal (within 2%) prefer the conflict-free OC = 4 and larger stages
         const bool better = k * 100 < bestK * 98 || (k * 100 <= bestK * 102 && (S > bestS || (S == bestS && OC == 4)));
@@ -586,7 +609,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, std::string* 
     const int OC = bestOC, S = bestS;
     h.lo_off = OC * h.plane_slots * 16;
     h.b_off = 2 * h.lo_off;
-    h.lds_bytes = h.b_off + S * L.nt * 2048;
+    h.lds_bytes = std::max(h.b_off + S * nt16 * 2048, kWaves * 2 * 16 * (nt16 * 32 + 16));   // stages | epilogue transpose
 
     std::vector<HStage> stages;
     std::vector<unsigned short> kmap;
@@ -633,12 +656,12 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, std::string* 
         h.ph[ph].nstages = (int)stages.size() - h.ph[ph].stage0;
         L.n_ksteps += (int)steps.size();
         // weight images: [nblk][k-step][n][hi|lo][lane][8]; stage woff = running k-step offset
-        const size_t per_blk = steps.size() * (size_t)L.nt * 2 * 64 * 8;
+        const size_t per_blk = steps.size() * (size_t)nt16 * 2 * 64 * 8;
         h.ph[ph].wblk_stride = (int)(per_blk / 8);
         {
             int kofs = 0;
             for (int si = h.ph[ph].stage0; si < (int)stages.size(); ++si) {
-                stages[si].woff = kofs * L.nt * 2 * 64;
+                stages[si].woff = kofs * nt16 * 2 * 64;
                 kofs += stages[si].nk;
             }
         }
@@ -646,14 +669,14 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, std::string* 
         W.assign(per_blk * h.nblocks, (_Float16)0.f);
         for (int nb = 0; nb < h.nblocks; ++nb)
             for (size_t ks = 0; ks < steps.size(); ++ks)
-                for (int n = 0; n < L.nt; ++n)
+                for (int n = 0; n < nt16; ++n)
                     for (int lane = 0; lane < 64; ++lane) {
                         const Pair& pr = steps[ks][lane >> 4];
                         if (pr.tap < 0) continue;
                         const Group& G = L.g[pr.gi];
                         const int Cp = round_up(G.C, 4);
-                        const int co = nb * L.nt * 16 + n * 16 + (lane & 15);
-                        const size_t base = nb * per_blk + ((ks * L.nt + n) * 2) * 512 + (size_t)lane * 8;
+                        const int co = nb * nt16 * 16 + n * 16 + (lane & 15);
+                        const size_t base = nb * per_blk + ((ks * nt16 + n) * 2) * 512 + (size_t)lane * 8;
                         for (int j = 0; j < 8; ++j) {
                             const int c = pr.oct * 8 + j;
                             if (c >= G.C || co >= L.Cout) continue;
@@ -686,7 +709,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, std::string* 
         if ((rc = upload_raw(ctx, wimg[ph], &d))) return rc;
         h.ph[ph].w = reinterpret_cast<const uint4*>(d);
     }
-    L.exec_flops = 2.0 * 3.0 * (double)L.n_ksteps * 32.0 * (L.Np) * L.H * L.W;   // MFMA work incl. split and padding
+    L.exec_flops = 2.0 * 3.0 * (double)L.n_ksteps * 32.0 * Np16 * L.H * L.W;   // MFMA work incl. split and padding
     return UMX_OK;
 }
 
@@ -759,37 +782,66 @@ struct ProfScope {
 inline _Float16* hi_of(const Buffer& b) { return reinterpret_cast<_Float16*>(b.d); }
 inline _Float16* lo_of(const Buffer& b, int n) { return reinterpret_cast<_Float16*>(b.d) + (size_t)n * b.S * b.S * b.Cs; }
 
-int run_unet_f16(umx_ctx* ctx, const float* tiles, int n, float* probs) {
-    {   // fp32 tiles -> (hi, lo) input planes (2 -> 8 channels, scaled by 2^act_shift)
+// One launch of the split-precision plan on tiles [k0, k0+ns) of a batch of n: every tensor lives in its full-batch
+// buffer (hi plane of n tiles, then lo plane of n tiles), a sub-batch is a slice of both planes.
+int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, int ns, float* probs) {
+    auto hi_at = [&](const Buffer& b) { return hi_of(b) + (size_t)k0 * b.S * b.S * b.Cs; };
+    auto lo_at = [&](const Buffer& b) { return lo_of(b, n) + (size_t)k0 * b.S * b.S * b.Cs; };
+    if (L.name == "input.split") {   // fp32 tiles -> (hi, lo) input planes (2 -> 8 channels, scaled by 2^act_shift)
         const Buffer& b0 = ctx->bufs[0];
         if (ctx->site_split < 0) ctx->site_split = site_of(ctx, "input.split", "split_f32");
-        ProfScope ps(ctx, ctx->site_split, 0.0, (double)n * b0.S * b0.S * (4.0 * b0.C + 4.0 * b0.Cs));
-        HIP_TRY(ctx, launch_split_f32(tiles, (size_t)n * b0.S * b0.S, b0.C, b0.Cs, std::ldexp(1.f, ctx->act_shift), hi_of(b0),
-                                      lo_of(b0, n), ctx->stream));
+        ProfScope ps(ctx, ctx->site_split, 0.0, (double)ns * b0.S * b0.S * (4.0 * b0.C + 4.0 * b0.Cs));
+        HIP_TRY(ctx, launch_split_f32(tiles + (size_t)k0 * b0.floats_per_tile, (size_t)ns * b0.S * b0.S, b0.C, b0.Cs,
+                                      std::ldexp(1.f, ctx->act_shift), hi_at(b0), lo_at(b0), ctx->stream));
+        return UMX_OK;
     }
-    for (auto& L : ctx->plan) {
-        if (L.head) {
-            const size_t npix = (size_t)n * L.H * L.W;
-            ProfScope ps(ctx, site_of(ctx, L.name, "head_softmax"), L.flops * n, L.bytes * n);
-            HIP_TRY(ctx, launch_head_softmax(ctx->bufs[L.g[0].src].d, npix, L.head_C, L.head_K, L.d_head_w, L.d_pre_s,
-                                             L.d_pre_b, probs, ctx->stream));
-            continue;
+    if (L.head) {
+        const Buffer& sb = ctx->bufs[L.g[0].src];
+        const size_t npix = (size_t)ns * L.H * L.W;
+        ProfScope ps(ctx, site_of(ctx, L.name, "head_softmax"), L.flops * ns, L.bytes * ns);
+        HIP_TRY(ctx, launch_head_softmax(sb.d + (size_t)k0 * sb.floats_per_tile, npix, L.head_C, L.head_K, L.d_head_w,
+                                         L.d_pre_s, L.d_pre_b, probs + (size_t)k0 * L.H * L.W * L.head_K, ctx->stream));
+        return UMX_OK;
+    }
+    HConvParams p = L.hcp;
+    p.B = ns;
+    for (int gi = 0; gi < L.ngroups; ++gi) {
+        const Buffer& sb = ctx->bufs[L.g[gi].src];
+        p.src_hi[gi] = hi_at(sb);
+        p.src_lo[gi] = lo_at(sb);
+        p.Cs[gi] = sb.Cs;
+    }
+    const Buffer& db = ctx->bufs[L.dst];
+    if (db.as_f32) p.dst_f32 = db.d + (size_t)k0 * db.floats_per_tile;
+    else { p.dst_hi = hi_at(db); p.dst_lo = lo_at(db); }
+    char kn[48];
+    snprintf(kn, sizeof kn, "conv_f16x3<NT=%d>", L.nt16);
+    ProfScope ps(ctx, site_of(ctx, L.name, kn), L.flops * ns, L.bytes * ns, L.exec_flops * ns);
+    HIP_TRY(ctx, launch_conv_f16(p, ctx->stream));
+    return UMX_OK;
+}
+
+// Launch order of the split-precision plan.  Layers whose tensors are large per tile (the full-resolution ends of the
+// UNet) run as chains over sub-batches, so that a producer's output is still in the 256 MiB Infinity Cache when the next
+// layer reads it; the channel-heavy middle runs once over the whole batch (it needs the M extent to fill 256 CUs).
+int run_unet_f16(umx_ctx* ctx, const float* tiles, int n, float* probs) {
+    const int nl = (int)ctx->plan16.size();
+    int i = 0;
+    while (i < nl) {
+        int j = i;
+        const int sub = ctx->plan16[i].sub;
+        while (j < nl && ctx->plan16[j].sub == sub) ++j;
+        const int step = sub > 0 ? sub : n;
+        for (int k0 = 0; k0 < n; k0 += step) {
+            const int ns = std::min(step, n - k0);
+            for (int l = i; l < j; ++l) {
+                const int li = ctx->plan16[l].launch;
+                Launch& L = li < 0 ? ctx->split_launch : ctx->plan[li];
+                int rc = run_launch_f16(ctx, L, tiles, n, k0, ns, probs);
+                if (rc) return rc;
+            }
         }
-        HConvParams p = L.hcp;
-        p.B = n;
-        for (int gi = 0; gi < L.ngroups; ++gi) {
-            const Buffer& sb = ctx->bufs[L.g[gi].src];
-            p.src_hi[gi] = hi_of(sb);
-            p.src_lo[gi] = lo_of(sb, n);
-            p.Cs[gi] = sb.Cs;
-        }
-        const Buffer& db = ctx->bufs[L.dst];
-        if (db.as_f32) p.dst_f32 = db.d;
-        else { p.dst_hi = hi_of(db); p.dst_lo = lo_of(db, n); }
-        char kn[48];
-        snprintf(kn, sizeof kn, "conv_f16x3<NT=%d>", L.nt);
-        ProfScope ps(ctx, site_of(ctx, L.name, kn), L.flops * n, L.bytes * n, L.exec_flops * n);
-        HIP_TRY(ctx, launch_conv_f16(p, ctx->stream));
+        i = j;
     }
     if (ctx->prof && ctx->pending.size() > 4096) return prof_fold(ctx);
     return UMX_OK;
@@ -1016,6 +1068,30 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
                 std::vector<float>().swap(L.g[gi].packed[ph]);
             }
         L.cp.pre_s = L.d_pre_s; L.cp.pre_b = L.d_pre_b; L.cp.post_s = L.d_post_s; L.cp.post_b = L.d_post_b;
+    }
+    if (f16) {
+        // chains over sub-batches for the launches with large per-tile tensors (see run_unet_f16)
+        const char* e = getenv("UMX_CHAIN_MB");
+        const double budget = (e ? atof(e) : 0.0) * 1e6;         // bytes of one chained layer's tensors kept cache-resident
+        const double big = 2.0e6;                                 // per-tile bytes that make a layer "full-resolution"
+        c->split_launch.name = "input.split";
+        const Buffer& b0 = c->bufs[0];
+        c->split_launch.bytes = (double)b0.S * b0.S * (4.0 * b0.C + 4.0 * b0.Cs);
+        std::vector<double> bytes = {c->split_launch.bytes};
+        for (auto& L : c->plan) bytes.push_back(L.head ? L.bytes : 4.0 * L.outH * L.outW * round_up(L.Cout, 8) +
+                                                [&] { double t = 0; for (int gi = 0; gi < L.ngroups; ++gi)
+                                                          t += 4.0 * L.H * L.W * round_up(L.g[gi].C, 8); return t; }());
+        const int nl = (int)bytes.size();
+        for (int i = 0; i < nl;) {
+            int j = i;
+            const bool hr = budget > 0 && bytes[i] >= big;
+            double mx = 0;
+            while (j < nl && (budget > 0 && bytes[j] >= big) == hr) { mx = std::max(mx, bytes[j]); ++j; }
+            int sub = 0;
+            if (hr && j - i >= 2) sub = std::max(1, (int)(budget / mx));
+            for (int l = i; l < j; ++l) c->plan16.push_back({l - 1, sub});
+            i = j;
+        }
     }
     *out = ctx.release();
     return UMX_OK;

@@ -53,6 +53,7 @@ hipError_t launch_conv(const ConvParams& p, int nt, int hpix, hipStream_t stream
 
 // ---- split-precision (3 x fp16 MFMA) convolution, umx_conv_f16.hip --------------------------------------------
 constexpr int kHaloChunks = 16;  // 64-slot pieces of the LDS halo per plane (halo <= 1024 pixels, the fp32 kernel's limit too)
+constexpr int kMaxNT16 = 9;      // N-tiles per workgroup of the split-precision kernel (144 output channels)
 constexpr int kStageK = 4;       // max k-steps (of 32 K-slots = 4 (tap, octet) pairs) per weight stage
 constexpr int kMaxLdsPerWG = 80 * 1024;   // two workgroups per CU share the 160 KiB
 
