@@ -14,8 +14,8 @@
 //   LDS          input halo, octet-planar: plane[octet][halo pixel] of 16-byte slots, hi planes then lo planes (an
 //                A-fragment read = 16 consecutive pixels of one plane per 16-lane group: conflict-free when the four
 //                groups read four planes at the same tap); then the stage's weight images.
-// Staging is LDS-DMA (global_load_lds_dwordx4: no staging VGPRs), single-buffered; two 256-thread workgroups per CU
-// cover each other's load phases.  A k-step is any 4 (tap, octet) pairs (table built on the host), so channel counts
+// Staging is LDS-DMA (global_load_lds_dwordx4: no staging VGPRs) in a two-deep pipeline: two weight buffers and two halo
+// slots, the loads of stage s+1 in flight under the MFMAs of stage s, one barrier per stage; 2-3 workgroups per CU.  A k-step is any 4 (tap, octet) pairs (table built on the host), so channel counts
 // only need to be multiples of 8, not 32.
 #include "umx_kernels.h"
 
@@ -47,20 +47,27 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     const int y0 = ty_i * TH, x0 = tx_i * TWm;
     const int nblk = blockIdx.y;
     const HPhase& ph = p.ph[blockIdx.z];
-
+    // diagnostic stamps (shader-clock cycles), wave 0 only: [0] prologue, [1] waiting for loads + barriers, [2] MFMA
+    // blocks, [3] epilogue, [4] whole kernel
+    long long t_in = 0, t_wait = 0, t_comp = 0, t_a = 0, t_b = 0;
+    if (p.dbg) t_in = __builtin_amdgcn_s_memtime();
     // ---- halo slot -> source pixel, fixed for the whole kernel: slot e = c*64 + lane
+    const int nch = (p.nhalo + 63) >> 6;
     int hsrc[kHaloChunks];   // >= 0: pixel index (img*H + y)*W + x;  -1: outside the image (zeros);  -2: no such slot
 #pragma unroll
     for (int c = 0; c < kHaloChunks; ++c) {
-        const int e = c * 64 + lane;
         int v = -2;
-        if (e < p.nhalo) {
-            const int il = e / p.imgplane;
-            const int r = e - il * p.imgplane;
-            const int hy = r / p.hw;
-            const int hx = r - hy * p.hw;
-            const int gy = y0 + p.ymin + hy, gx = x0 + p.xmin + hx, img = img0 + il;
-            v = (img < p.B && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? (img * p.H + gy) * p.W + gx : -1;
+        if (c < nch) {   // wave-uniform: unused chunks cost nothing
+            const int e = c * 64 + lane;
+            if (e < p.nhalo) {
+                // e < 1024: the float quotients are exact after truncation (error ~1e-4 << 0.5 / divisor)
+                const int il = (int)(((float)e + 0.5f) * p.inv_imgplane);
+                const int r = e - il * p.imgplane;
+                const int hy = (int)(((float)r + 0.5f) * p.inv_hw);
+                const int hx = r - hy * p.hw;
+                const int gy = y0 + p.ymin + hy, gx = x0 + p.xmin + hx, img = img0 + il;
+                v = (img < p.B && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? (img * p.H + gy) * p.W + gx : -1;
+            }
         }
         hsrc[c] = v;
     }
@@ -84,17 +91,13 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     const int lo_off = p.lo_off;   // byte offset of the lo planes
     unsigned char* const Bl = smem + p.b_off;
     const uint4* const wbase = ph.w + (size_t)nblk * ph.wblk_stride;
-    const int nch = (p.nhalo + 63) >> 6;
 
-    for (int s = 0; s < ph.nstages; ++s) {
-        const HStage st = p.stages[ph.stage0 + s];
-        __syncthreads();   // every wave is done reading the previous stage's LDS images
-
-        unsigned kb[kStageK];
-#pragma unroll
-        for (int j = 0; j < kStageK; ++j) kb[j] = j < st.nk ? (unsigned)p.kmap[(st.k0 + j) * 4 + q] << 4 : 0u;
-
-        if (st.group >= 0) {   // (re)load the halo: octets [oct0, oct0+noct) of operand group `group`
+    // Two-deep software pipeline: the LDS-DMA loads of stage s+1 (next weight block into the other weight buffer, and,
+    // at a chunk boundary, the next halo chunk into the other halo slot) are in flight while stage s runs its MFMAs.
+    // One barrier per stage: it orders "everyone's loads of stage s have landed" (each wave waits for its own first)
+    // and "everyone is done computing stage s-1" (so the buffers stage s+1 loads into are free).
+    auto issue = [&](const HStage& st, int buf) {
+        if (st.group >= 0) {   // halo chunk: octets [oct0, oct0+noct) of operand group `group` -> planes plane0..
             const int g = st.group;
             const _Float16* const shi = p.src_hi[g];
             const _Float16* const slo = p.src_lo[g];
@@ -102,7 +105,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
             for (int t = wave; t < st.noct * 2; t += kWaves) {   // one (plane, hi|lo) per iteration, wave-uniform
                 const int pl = t >> 1;
                 const _Float16* const sb = ((t & 1) ? slo : shi) + (st.oct0 + pl) * 8;
-                unsigned char* const dst = smem + ((t & 1) ? lo_off : 0) + pl * plane_bytes;
+                unsigned char* const dst = smem + ((t & 1) ? lo_off : 0) + (st.plane0 + pl) * plane_bytes;
 #pragma unroll
                 for (int c = 0; c < kHaloChunks; ++c) {
                     if (c < nch && hsrc[c] != -2) {
@@ -112,19 +115,46 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
                 }
             }
         }
-        {   // weight images of this stage: a linear copy, 1 KiB per wave-instruction
-            const uint4* const wsrc = wbase + st.woff + lane;
-            const int npieces = st.nk * NT * 2;
-            for (int pc = wave; pc < npieces; pc += kWaves) UMX_GLDS16(wsrc + pc * 64, Bl + pc * 1024);
+        // weight block: [64 B header: k-map of its k-steps][nk x NT x (hi, lo) images], a linear copy
+        unsigned char* const wl = Bl + buf * p.wbuf_bytes;
+        const uint4* const wsrc = wbase + st.woff;
+        if (wave == 0 && lane < 4) UMX_GLDS16(wsrc + lane, wl);
+        const int npieces = st.nk * NT * 2;
+        for (int pc = wave; pc < npieces; pc += kWaves) UMX_GLDS16(wsrc + 4 + pc * 64 + lane, wl + 64 + pc * 1024);
+    };
+
+    // epilogue constants of this N-block ([pre_s | pre_b | post_s | post_b] x NT*16 floats, defaults and 2^shift factors
+    // folded on the host): loaded by LDS-DMA under the MFMAs of the last stage, into the weight buffer that stage frees
+    auto issue_econst = [&](int buf) {
+        if (wave == kWaves - 1) {
+            float* const dst = reinterpret_cast<float*>(Bl + buf * p.wbuf_bytes);
+#pragma unroll
+            for (int i = 0; i < (NT * 16 + 63) / 64; ++i)
+                if (i * 64 + lane < NT * 16)
+                    UMX_GLDS16(p.econst + (size_t)nblk * (NT * 16) + i * 64 + lane, dst + i * 256);
         }
+    };
+    const float* const ec = reinterpret_cast<const float*>(Bl + (ph.nstages & 1) * p.wbuf_bytes);
+    if (ph.nstages == 0) issue_econst(0);
+    HStage cur = p.stages[ph.stage0];
+    if (ph.nstages > 0) issue(cur, 0);
+    long long t_pro = 0;
+    if (p.dbg) { t_pro = __builtin_amdgcn_s_memtime(); t_a = t_pro; }
+    for (int s = 0; s < ph.nstages; ++s) {
+        const HStage nxt = p.stages[ph.stage0 + (s + 1 < ph.nstages ? s + 1 : s)];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (p.dbg) { t_b = __builtin_amdgcn_s_memtime(); t_wait += t_b - t_a; }
+        if (s + 1 < ph.nstages) issue(nxt, (s + 1) & 1);
+        else issue_econst((s + 1) & 1);
 
+        const unsigned char* const wl = Bl + (s & 1) * p.wbuf_bytes;
 #pragma unroll
         for (int j = 0; j < kStageK; ++j) {
-            if (j < st.nk) {
-                const unsigned char* const ap = smem + kb[j];
-                const unsigned char* const bp = Bl + j * (NT * 2048) + lane * 16;
+            if (j < cur.nk) {
+                const unsigned kb = (unsigned)*reinterpret_cast<const unsigned short*>(wl + (j * 4 + q) * 2) << 4;
+                const unsigned char* const ap = smem + kb;
+                const unsigned char* const bp = wl + 64 + j * (NT * 2048) + lane * 16;
                 h8 ah[kMT], al[kMT];
 #pragma unroll
                 for (int m = 0; m < kMT; ++m) {
@@ -137,95 +167,110 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
                     const h8 bl = *reinterpret_cast<const h8*>(bp + n * 2048 + 1024);
 #pragma unroll
                     for (int m = 0; m < kMT; ++m) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl, acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh, acc[m][n], 0, 0, 0);
+                        // weights are the A operand (rows = output channels), activations the B operand (columns =
+                        // pixels): D[channel][pixel], so a lane ends up with 4 consecutive channels of one pixel
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[m], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[m], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[m], acc[m][n], 0, 0, 0);
                     }
                 }
             }
         }
+        cur = nxt;
+        if (p.dbg) { t_a = __builtin_amdgcn_s_memtime(); t_comp += t_a - t_b; }
     }
+    struct DbgOut {   // written when the kernel returns (both epilogue paths)
+        const HConvParams& p; long long t_in, t_pro, t_wait, t_comp, t_epi; int tid;
+        __device__ ~DbgOut() {
+            if (p.dbg && tid == 0) {
+                const long long t_end = __builtin_amdgcn_s_memtime();
+                const size_t w = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+                long long* d = p.dbg + w * 5;
+                d[0] = t_pro - t_in; d[1] = t_wait; d[2] = t_comp; d[3] = t_end - t_epi; d[4] = t_end - t_in;
+            }
+        }
+    } dbg_out{p, t_in, t_pro, t_wait, t_comp, p.dbg ? (long long)__builtin_amdgcn_s_memtime() : 0, tid};
 
-    // ---- epilogue: (acc * pre_s + pre_b) -> activation -> (* post_s + post_b) -> [2x2 max-pool] -> * out_scale
-    //      -> split to (hi, lo) binary16 NHWC, or fp32 NHWC for the layer feeding the softmax head.
-    // C/D layout of the 16x16 tile: column (output channel) = lane & 15, row (pixel) = 4*(lane>>4) + reg.
-    const int ncol0 = nblk * (NT * 16) + li;
-    float ps[NT], pb[NT], qs[NT], qb[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int co = ncol0 + n * 16;
-        const bool ok = co < p.Cout;
-        ps[n] = ok ? p.pre_s[co] : 0.f;
-        pb[n] = (p.pre_b && ok) ? p.pre_b[co] : 0.f;
-        qs[n] = ((p.post_s && ok) ? p.post_s[co] : 1.f) * p.out_scale;
-        qb[n] = ((p.post_b && ok) ? p.post_b[co] : 0.f) * p.out_scale;
-    }
+    // ---- epilogue: (acc * pre_s + pre_b) -> activation -> (* post_s + post_b, output shift folded in) -> [2x2 max-pool]
+    //      -> (hi, lo) binary16 NHWC, or fp32 NHWC for the tensor the softmax head reads.
+    // C/D layout (weights as the A operand): row = output channel 4*(lane>>4) + reg of the N-tile, column = pixel
+    // lane & 15 of the M-tile.  A lane therefore stores 4 consecutive channels of its pixel in one 8-byte (binary16)
+    // or 16-byte (fp32) store; the 4 lane groups complete the 16 channels (32 / 64 contiguous bytes per pixel).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the constants have landed ...
+    __syncthreads();                                    // ... for every wave
+    const float4* const ec4 = reinterpret_cast<const float4*>(ec);
+
+    // fp32 output: direct 16-byte stores (64 contiguous bytes per pixel and N-tile).
+    // (hi, lo) output: through a per-wave LDS transpose -- each lane drops its 4 channels (8 bytes) into a [pixel][channel]
+    // row image, then the wave stores whole rows, 16 bytes per lane, consecutive lanes consecutive addresses (pixels
+    // that are neighbours in x are contiguous in NHWC): full-line writes instead of 8-byte fragments.
+    constexpr int PITCH = NT * 32 + 16;   // bytes per staged pixel row of one plane
+    constexpr int PLANE = 16 * PITCH;
+    constexpr int UR = NT * 2;            // 16-byte units per staged row
+    unsigned char* const stg = smem + wave * (2 * PLANE);
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+    // epilogue arithmetic in place; the constants come from LDS (4 consecutive channels = one float4 per array)
     bool big = false;
 #pragma unroll
-    for (int m = 0; m < kMT; ++m)
+    for (int n = 0; n < NT; ++n) {
+        const float4 ps = ec4[0 * NT * 4 + n * 4 + q], pb = ec4[1 * NT * 4 + n * 4 + q];
+        const float4 qs = ec4[2 * NT * 4 + n * 4 + q], qb = ec4[3 * NT * 4 + n * 4 + q];
+        const float psa[4] = {ps.x, ps.y, ps.z, ps.w}, pba[4] = {pb.x, pb.y, pb.z, pb.w};
+        const float qsa[4] = {qs.x, qs.y, qs.z, qs.w}, qba[4] = {qb.x, qb.y, qb.z, qb.w};
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+        for (int m = 0; m < kMT; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = acc[m][n][r] * ps[n] + pb[n];
+                float v = acc[m][n][r] * psa[r] + pba[r];
                 if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
                 else if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.2f * v;
-                v = v * qs[n] + qb[n];
+                v = v * qsa[r] + qba[r];
                 big |= !(fabsf(v) < 60000.f);
                 acc[m][n][r] = v;
             }
+        if (p.pool) {   // rows m, m+1 are vertical neighbours; pixels li, li^1 horizontal neighbours
+#pragma unroll
+            for (int m = 0; m < kMT; m += 2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = fmaxf(acc[m][n][r], acc[m + 1][n][r]);
+                    const float b = __builtin_bit_cast(
+                        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1 /* quad_perm [1,0,3,2] */,
+                                                           0xF, 0xF, false));
+                    acc[m][n][r] = fmaxf(a, b);   // both lanes of the pair hold the pooled value; the even one stores
+                }
+        }
+    }
     if (big && p.dst_f32 == nullptr) atomicOr(p.overflow_flag, 1);   // binary16 range exceeded: the host reports it
 
     if (p.dst_f32) {
-        // fp32 NHWC output (the tensor the softmax head reads): direct stores, 64 B per 16-lane group
-        auto store = [&](int img, int oy, int ox, int n, float v) {
-            const int co = ncol0 + n * 16;
-            if (co < p.Cout) p.dst_f32[((size_t)(img * p.outH + oy) * p.outW + ox) * p.Cout + co] = v;
-        };
 #pragma unroll
         for (int m = 0; m < kMT; ++m) {
             const int t = wave * kMT + m;
             const int ig = t >> p.th_log2, ty = t & (TH - 1);
+            const int img = img0 + ig * p.nimg_m + (li >> p.twm_log2);
+            if (img >= p.B) continue;
+            const long pix = (long)(img * p.outH + (y0 + ty) * p.o_mul + ph.oy_off) * p.outW +
+                             (x0 + (li & (TWm - 1))) * p.o_mul + ph.ox_off;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 4 * q + r;
-                const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
-                const int oy = (y0 + ty) * p.o_mul + ph.oy_off, ox = (x0 + (i & (TWm - 1))) * p.o_mul + ph.ox_off;
-                if (img < p.B) {
+            for (int n = 0; n < NT; ++n) {
+                const int c0 = nblk * (NT * 16) + n * 16 + 4 * q;
+                const f32x4 v = acc[m][n];
+                float* const d = p.dst_f32 + pix * p.Cout + c0;
+                if ((p.Cout & 3) == 0) {
+                    if (c0 < p.Cout) *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) store(img, oy, ox, n, acc[m][n][r]);
+                    for (int r = 0; r < 4; ++r)
+                        if (c0 + r < p.Cout) d[r] = v[r];
                 }
             }
         }
         return;
     }
 
-    // (hi, lo) binary16 output through a per-wave LDS transpose: the C/D layout has one channel per lane (2-byte
-    // stores, 32 B per 16-lane group); staged as [pixel][channel] rows, every lane stores 16 contiguous bytes and a
-    // wave-instruction covers whole pixels' channel vectors (consecutive pixels are contiguous in NHWC).
-    __syncthreads();   // every wave is done with the halo / weight images: LDS is free
-    constexpr int PITCH = NT * 32 + 16;   // bytes per staged pixel row of one plane (16-byte aligned)
-    constexpr int PLANE = 16 * PITCH;
-    constexpr int UR = NT * 2;            // 16-byte units per staged row
-    unsigned char* const stg = smem + wave * (2 * PLANE);
-    const bool odd = li & 1;
-
-    // two values of this lane (rows ra and ra+1, same channel) -> packed channel pairs: even lanes write row ra, odd
-    // lanes row ra+1, after swapping one (hi, lo) pair with the neighbouring lane (one DPP move per two values)
-    auto put2 = [&](int ra, int n, float va, float vb) {
-        const _Float16 ha = (_Float16)va, hb = (_Float16)vb;
-        const _Float16 la = (_Float16)(va - (float)ha), lb = (_Float16)(vb - (float)hb);
-        union { _Float16 h[2]; int i; } pa, pb, rc, wh, wl;
-        pa.h[0] = ha; pa.h[1] = la;
-        pb.h[0] = hb; pb.h[1] = lb;
-        const int give = odd ? pa.i : pb.i;
-        rc.i = __builtin_amdgcn_update_dpp(0, give, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
-        if (odd) { wh.h[0] = rc.h[0]; wh.h[1] = hb; wl.h[0] = rc.h[1]; wl.h[1] = lb; }
-        else { wh.h[0] = ha; wh.h[1] = rc.h[0]; wl.h[0] = la; wl.h[1] = rc.h[1]; }
-        unsigned char* const d = stg + (ra + (odd ? 1 : 0)) * PITCH + (n * 16 + (li & ~1)) * 2;
-        *reinterpret_cast<int*>(d) = wh.i;
-        *reinterpret_cast<int*>(d + PLANE) = wl.i;
-    };
+    __syncthreads();   // every wave has read its constants: the LDS is free for the transpose
 
     // staged rows [0, R) -> global; pixel_of(row) gives the NHWC pixel index or -1
     auto flush = [&](int R, auto pixel_of) {
@@ -247,19 +292,27 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staged rows are in registers before the next tile overwrites
     };
+    auto put = [&](int row, int m) {   // this lane's 4 channels of every N-tile -> staged row
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            h4 hi, lo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                hi[r] = (_Float16)acc[m][n][r];
+                lo[r] = (_Float16)(acc[m][n][r] - (float)hi[r]);
+            }
+            unsigned char* const d = stg + row * PITCH + (n * 16 + 4 * q) * 2;
+            *reinterpret_cast<h4*>(d) = hi;
+            *reinterpret_cast<h4*>(d + PLANE) = lo;
+        }
+    };
 
     if (p.pool) {
 #pragma unroll
         for (int m = 0; m < kMT; m += 2) {
             const int t = wave * kMT + m;
             const int ig = t >> p.th_log2, ty = t & (TH - 1);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                // pooled pixel j = 2q + r/2 of the 8 this M-tile pair produces
-                const float v0 = fmaxf(fmaxf(acc[m][n][0], acc[m][n][1]), fmaxf(acc[m + 1][n][0], acc[m + 1][n][1]));
-                const float v1 = fmaxf(fmaxf(acc[m][n][2], acc[m][n][3]), fmaxf(acc[m + 1][n][2], acc[m + 1][n][3]));
-                put2(2 * q, n, v0, v1);
-            }
+            if ((li & 1) == 0) put(li >> 1, m);   // pooled pixel j = li/2 of the 8 this M-tile pair produces
             flush(8, [&](int j) -> long {
                 const int i = 2 * j;
                 const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
@@ -272,11 +325,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
         for (int m = 0; m < kMT; ++m) {
             const int t = wave * kMT + m;
             const int ig = t >> p.th_log2, ty = t & (TH - 1);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                put2(4 * q, n, acc[m][n][0], acc[m][n][1]);
-                put2(4 * q + 2, n, acc[m][n][2], acc[m][n][3]);
-            }
+            put(li, m);
             flush(16, [&](int i) -> long {
                 const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
                 if (img >= p.B) return -1;

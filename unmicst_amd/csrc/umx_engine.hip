@@ -63,7 +63,6 @@ struct Launch {
     int nt16 = 1;             // N-tiles per workgroup of the split-precision kernel
     int wshift = 0;           // weights are stored times 2^wshift
     int n_ksteps = 0;         // K-slots of 32 executed per output tile, all phases (for the executed-FLOP figure)
-    float* d_pre_s16 = nullptr;
     float* d_head_w = nullptr;
     float *d_pre_s = nullptr, *d_pre_b = nullptr, *d_post_s = nullptr, *d_post_b = nullptr;
 };
@@ -570,50 +569,61 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, std::string* 
     }
     const float wscale = std::ldexp(1.f, L.wshift);
 
-    // choose octets per chunk (OC) and k-steps per stage (S): minimise executed k-steps, then maximise S
+    // ---- chunking.  A chunk = up to OC octets of one operand group, resident in LDS while its (tap, octet) pairs are
+    // consumed 4 per k-step; a stage = up to S k-steps = one weight block.  Consecutive chunks alternate between two
+    // halo slots (even chunks at plane 0, odd chunks behind them) so that chunk c+1 loads while chunk c computes.
     int noct[2] = {0, 0};
     for (int gi = 0; gi < L.ngroups; ++gi) noct[gi] = round_up(L.g[gi].C, 8) / 8;
-    auto ksteps_for = [&](int OC) {
-        int total = 0;
-        for (int ph = 0; ph < L.nphase; ++ph)
-            for (int gi = 0; gi < L.ngroups; ++gi) {
-                const int nt = (int)L.g[gi].taps[ph].size();
-                if (!nt) continue;
-                const int nchunk = (noct[gi] + OC - 1) / OC;
-                for (int c = 0; c < nchunk; ++c) {
-                    const int o0 = c * noct[gi] / nchunk, o1 = (c + 1) * noct[gi] / nchunk;
-                    total += (nt * (o1 - o0) + 3) / 4;
-                }
+    struct Chunk { int gi, o0, o1, npairs; };
+    auto chunks_for = [&](int OC, int ph) {
+        std::vector<Chunk> out;
+        for (int gi = 0; gi < L.ngroups; ++gi) {
+            const int nt = (int)L.g[gi].taps[ph].size();
+            if (!nt) continue;
+            const int nchunk = (noct[gi] + OC - 1) / OC;
+            for (int c = 0; c < nchunk; ++c) {
+                const int o0 = c * noct[gi] / nchunk, o1 = (c + 1) * noct[gi] / nchunk;
+                out.push_back({gi, o0, o1, nt * (o1 - o0)});
             }
-        return total;
+        }
+        return out;
     };
-    // LDS budget per workgroup: 80 KiB = 2 workgroups per CU; narrow layers (few accumulators -> few VGPRs) are
-    // latency-bound, so they get a smaller budget and 3 workgroups per CU cover each other's load phases
+    // LDS budget per workgroup: 80 KiB = 2 workgroups per CU; narrow layers (few accumulators -> few VGPRs) get a smaller
+    // budget so that 3 workgroups per CU cover each other
     int lds_cap = kMaxLdsPerWG;
     {
         const char* e = getenv("UMX_LDS_CAP_NARROW");
         const int narrow = e ? atoi(e) : 53 * 1024;
         if (nt16 <= 3 && narrow >= 16 * 1024) lds_cap = std::min(lds_cap, narrow);
     }
-    int bestOC = 0, bestS = 0, bestK = 1 << 30;
+    int bestOC = 0, bestS = 0, bestE = 0, bestO = 0;
+    double bestCost = 1e30;
     for (int OC = 1; OC <= 8; ++OC) {
-        const int room = lds_cap - OC * plane_pair;
-        if (room < nt16 * 2048) continue;
-        const int S = std::min(kStageK, room / (nt16 * 2048));
-        const int k = ksteps_for(OC);
-        // prefer fewer k-steps; among near-equal (within 2%) prefer the conflict-free OC = 4 and larger stages
-        const bool better = k * 100 < bestK * 98 || (k * 100 <= bestK * 102 && (S > bestS || (S == bestS && OC == 4)));
-        if (bestOC == 0 || better) { bestOC = OC; bestS = S; bestK = k; }
+        int E = 0, O = 0, ksteps = 0;
+        for (int ph = 0; ph < L.nphase; ++ph) {
+            const auto ch = chunks_for(OC, ph);
+            for (size_t c = 0; c < ch.size(); ++c) {
+                ((c & 1) ? O : E) = std::max((c & 1) ? O : E, ch[c].o1 - ch[c].o0);
+                ksteps += (ch[c].npairs + 3) / 4;
+            }
+        }
+        for (int S = 1; S <= kStageK; ++S) {
+            const int lds = (E + O) * plane_pair + 2 * (64 + S * nt16 * 2048);
+            if (lds > lds_cap) continue;
+            // executed k-steps, plus a barrier/latency charge per stage, slight preference for the conflict-free OC = 4
+            const double cost = ksteps * (1.0 + 0.30 / S) * (OC == 4 ? 0.98 : 1.0);
+            if (cost < bestCost) { bestCost = cost; bestOC = OC; bestS = S; bestE = E; bestO = O; }
+        }
     }
     if (!bestOC) { *why = "LDS footprint too large for the split-precision kernel"; return UMX_ERR_INVALID; }
     const int OC = bestOC, S = bestS;
-    h.lo_off = OC * h.plane_slots * 16;
+    h.lo_off = (bestE + bestO) * h.plane_slots * 16;
     h.b_off = 2 * h.lo_off;
-    h.lds_bytes = std::max(h.b_off + S * nt16 * 2048, kWaves * 2 * 16 * (nt16 * 32 + 16));   // stages | epilogue transpose
+    h.wbuf_bytes = 64 + S * nt16 * 2048;
+    h.lds_bytes = std::max(h.b_off + 2 * h.wbuf_bytes, kWaves * 2 * 16 * (nt16 * 32 + 16));   // pipeline | epilogue transpose
 
     std::vector<HStage> stages;
-    std::vector<unsigned short> kmap;
-    std::vector<std::vector<_Float16>> wimg(L.nphase);   // per phase: [nblk][...] halves
+    std::vector<std::vector<_Float16>> wimg(L.nphase);   // per phase: [nblk][stage blocks] halves
     L.n_ksteps = 0;
     for (int ph = 0; ph < L.nphase; ++ph) {
         h.ph[ph].oy_off = L.oy_off[ph];
@@ -621,89 +631,115 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, std::string* 
         h.ph[ph].stage0 = (int)stages.size();
         struct Pair { int gi, tap, oct, plane; };
         std::vector<std::vector<Pair>> steps;   // k-steps of this phase, each 4 pairs (padded ones have tap = -1)
-        for (int gi = 0; gi < L.ngroups; ++gi) {
+        const auto ch = chunks_for(OC, ph);
+        for (size_t c = 0; c < ch.size(); ++c) {
+            const int gi = ch[c].gi, o0 = ch[c].o0, o1 = ch[c].o1;
+            const int plane0 = (c & 1) ? bestE : 0;
             const int nt = (int)L.g[gi].taps[ph].size();
-            if (!nt) continue;
-            const int nchunk = (noct[gi] + OC - 1) / OC;
-            for (int c = 0; c < nchunk; ++c) {
-                const int o0 = c * noct[gi] / nchunk, o1 = (c + 1) * noct[gi] / nchunk;
-                std::vector<Pair> pairs;
-                for (int t = 0; t < nt; ++t)
-                    for (int o = o0; o < o1; ++o) pairs.push_back({gi, t, o, o - o0});
-                while (pairs.size() % 4) pairs.push_back({gi, -1, o0, 0});   // zero-weight filler, reads a loaded slot
-                const int nk_chunk = (int)pairs.size() / 4;
-                for (int k = 0; k < nk_chunk; k += S) {
-                    HStage st;
-                    st.woff = 0;  // filled below
-                    st.group = k == 0 ? (short)gi : (short)-1;
-                    st.oct0 = (short)o0;
-                    st.noct = (short)(o1 - o0);
-                    st.nk = (short)std::min(S, nk_chunk - k);
-                    st.k0 = (int)kmap.size() / 4;
-                    for (int j = 0; j < st.nk; ++j) {
-                        std::vector<Pair> four(pairs.begin() + (k + j) * 4, pairs.begin() + (k + j) * 4 + 4);
-                        for (auto& pr : four) {
-                            const auto& tp = L.g[gi].taps[ph][pr.tap < 0 ? 0 : pr.tap];
-                            const int tapoff = (tp.first - g.ymin) * g.hw + (tp.second - g.xmin);
-                            kmap.push_back((unsigned short)(pr.plane * h.plane_slots + tapoff));
-                        }
-                        steps.push_back(four);
-                    }
-                    stages.push_back(st);
-                }
+            std::vector<Pair> pairs;
+            for (int t = 0; t < nt; ++t)
+                for (int o = o0; o < o1; ++o) pairs.push_back({gi, t, o, plane0 + o - o0});
+            while (pairs.size() % 4) pairs.push_back({gi, -1, o0, plane0});   // zero-weight filler, reads a loaded slot
+            const int nk_chunk = (int)pairs.size() / 4;
+            for (int k = 0; k < nk_chunk; k += S) {
+                HStage st;
+                memset(&st, 0, sizeof st);
+                st.group = k == 0 ? (short)gi : (short)-1;
+                st.oct0 = (short)o0;
+                st.noct = (short)(o1 - o0);
+                st.plane0 = (short)plane0;
+                st.nk = (short)std::min(S, nk_chunk - k);
+                for (int j = 0; j < st.nk; ++j)
+                    steps.push_back(std::vector<Pair>(pairs.begin() + (k + j) * 4, pairs.begin() + (k + j) * 4 + 4));
+                stages.push_back(st);
             }
         }
         h.ph[ph].nstages = (int)stages.size() - h.ph[ph].stage0;
         L.n_ksteps += (int)steps.size();
-        // weight images: [nblk][k-step][n][hi|lo][lane][8]; stage woff = running k-step offset
-        const size_t per_blk = steps.size() * (size_t)nt16 * 2 * 64 * 8;
-        h.ph[ph].wblk_stride = (int)(per_blk / 8);
-        {
-            int kofs = 0;
-            for (int si = h.ph[ph].stage0; si < (int)stages.size(); ++si) {
-                stages[si].woff = kofs * nt16 * 2 * 64;
-                kofs += stages[si].nk;
-            }
+        // weight slab of one N-block: per stage a block = 64-byte header (k-map) + nk * NT * (hi, lo) images
+        size_t per_blk = 0;   // halves
+        for (int si = h.ph[ph].stage0; si < (int)stages.size(); ++si) {
+            stages[si].woff = (int)(per_blk / 8);
+            per_blk += 32 + (size_t)stages[si].nk * nt16 * 2 * 512;
         }
+        h.ph[ph].wblk_stride = (int)(per_blk / 8);
         std::vector<_Float16>& W = wimg[ph];
         W.assign(per_blk * h.nblocks, (_Float16)0.f);
-        for (int nb = 0; nb < h.nblocks; ++nb)
-            for (size_t ks = 0; ks < steps.size(); ++ks)
-                for (int n = 0; n < nt16; ++n)
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const Pair& pr = steps[ks][lane >> 4];
-                        if (pr.tap < 0) continue;
-                        const Group& G = L.g[pr.gi];
-                        const int Cp = round_up(G.C, 4);
-                        const int co = nb * nt16 * 16 + n * 16 + (lane & 15);
-                        const size_t base = nb * per_blk + ((ks * nt16 + n) * 2) * 512 + (size_t)lane * 8;
-                        for (int j = 0; j < 8; ++j) {
-                            const int c = pr.oct * 8 + j;
-                            if (c >= G.C || co >= L.Cout) continue;
-                            const float v = G.packed[ph][((size_t)pr.tap * Cp + c) * L.Np + co] * wscale;
-                            const _Float16 hi = (_Float16)v;
-                            W[base + j] = hi;
-                            W[base + 512 + j] = (_Float16)(v - (float)hi);
+        for (int nb = 0; nb < h.nblocks; ++nb) {
+            size_t ks = 0;
+            for (int si = h.ph[ph].stage0; si < (int)stages.size(); ++si) {
+                const size_t blk = nb * per_blk + (size_t)stages[si].woff * 8;
+                unsigned short* const hdr = reinterpret_cast<unsigned short*>(&W[blk]);
+                for (int j = 0; j < stages[si].nk; ++j, ++ks) {
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const Pair& pr = steps[ks][qq];
+                        const auto& tp = L.g[pr.gi].taps[ph][pr.tap < 0 ? 0 : pr.tap];
+                        const int slot = pr.plane * h.plane_slots + (tp.first - g.ymin) * g.hw + (tp.second - g.xmin);
+                        if (slot < 0 || slot >= (bestE + bestO) * h.plane_slots || slot > 65535) {
+                            *why = "internal: k-map slot out of range";
+                            return UMX_ERR_INVALID;
                         }
+                        hdr[j * 4 + qq] = (unsigned short)slot;
                     }
+                    for (int n = 0; n < nt16; ++n)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const Pair& pr = steps[ks][lane >> 4];
+                            if (pr.tap < 0) continue;
+                            const Group& G = L.g[pr.gi];
+                            const int Cp = round_up(G.C, 4);
+                            const int co = nb * nt16 * 16 + n * 16 + (lane & 15);
+                            const size_t base = blk + 32 + (((size_t)j * nt16 + n) * 2) * 512 + (size_t)lane * 8;
+                            for (int e = 0; e < 8; ++e) {
+                                const int c = pr.oct * 8 + e;
+                                if (c >= G.C || co >= L.Cout) continue;
+                                const float v = G.packed[ph][((size_t)pr.tap * Cp + c) * L.Np + co] * wscale;
+                                const _Float16 hi = (_Float16)v;
+                                W[base + e] = hi;
+                                W[base + 512 + e] = (_Float16)(v - (float)hi);
+                            }
+                        }
+                }
+            }
+        }
     }
-    if (kmap.size() / 4 > 60000) { *why = "too many k-steps"; return UMX_ERR_INVALID; }
-    for (unsigned short v : kmap)
-        if ((int)v >= OC * h.plane_slots) { *why = "internal: k-map slot out of range"; return UMX_ERR_INVALID; }
 
-    // epilogue constants: pre_s absorbs 2^-(weight shift + input activation shift)
-    std::vector<float> ps(L.Cout);
-    const float unshift = std::ldexp(1.f, -(L.wshift + act_shift));
-    for (int c = 0; c < L.Cout; ++c) ps[c] = (L.pre_s.empty() ? 1.f : L.pre_s[c]) * unshift;
+    // epilogue constants per N-block: pre_s absorbs 2^-(weight shift + input activation shift), post_* the output's
+    // 2^(activation shift); padded channels get pre_s = post_s = 0 so that they store exact zeros
+    {
+        const float unshift = std::ldexp(1.f, -(L.wshift + act_shift));
+        const float oscale = out_f32 ? 1.f : std::ldexp(1.f, act_shift);
+        const int nb16 = nt16 * 16;
+        std::vector<float> ec((size_t)h.nblocks * 4 * nb16, 0.f);
+        for (int nb = 0; nb < h.nblocks; ++nb)
+            for (int i = 0; i < nb16; ++i) {
+                const int c = nb * nb16 + i;
+                if (c >= L.Cout) continue;
+                float* e = &ec[(size_t)nb * 4 * nb16];
+                e[0 * nb16 + i] = (L.pre_s.empty() ? 1.f : L.pre_s[c]) * unshift;
+                e[1 * nb16 + i] = L.pre_b.empty() ? 0.f : L.pre_b[c];
+                e[2 * nb16 + i] = (L.post_s.empty() ? 1.f : L.post_s[c]) * oscale;
+                e[3 * nb16 + i] = (L.post_b.empty() ? 0.f : L.post_b[c]) * oscale;
+            }
+        float* d = nullptr;
+        int rc2 = upload(ctx, ec, &d);
+        if (rc2) return rc2;
+        h.econst = reinterpret_cast<const uint4*>(d);
+    }
+    if (getenv("UMX_DEBUG_PLAN"))
+        fprintf(stderr, "[umx plan] %-12s NT %d x %d blocks, OC %d (slots %d+%d planes), S %d, LDS %d B, k-steps %d, wshift %d\n",
+                L.name.c_str(), nt16, h.nblocks, OC, bestE, bestO, S, h.lds_bytes, L.n_ksteps, L.wshift);
+    h.inv_imgplane = 1.f / (float)h.imgplane;
+    h.inv_hw = 1.f / (float)h.hw;
     int rc;
-    if ((rc = upload(ctx, ps, &L.d_pre_s16))) return rc;
-    h.pre_s = L.d_pre_s16; h.pre_b = L.d_pre_b; h.post_s = L.d_post_s; h.post_b = L.d_post_b;
-    h.out_scale = out_f32 ? 1.f : std::ldexp(1.f, act_shift);
     HStage* d_st = nullptr;
-    unsigned short* d_km = nullptr;
-    if ((rc = upload_raw(ctx, stages, &d_st)) || (rc = upload_raw(ctx, kmap, &d_km))) return rc;
+    {
+        HStage dummy;   // the kernel reads stages[stage0] before looking at nstages
+        memset(&dummy, 0, sizeof dummy);
+        dummy.group = -1;
+        stages.push_back(dummy);
+    }
+    if ((rc = upload_raw(ctx, stages, &d_st))) return rc;
     h.stages = d_st;
-    h.kmap = d_km;
     for (int ph = 0; ph < L.nphase; ++ph) {
         _Float16* d = nullptr;
         if ((rc = upload_raw(ctx, wimg[ph], &d))) return rc;
@@ -816,6 +852,28 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
     else { p.dst_hi = hi_at(db); p.dst_lo = lo_at(db); }
     char kn[48];
     snprintf(kn, sizeof kn, "conv_f16x3<NT=%d>", L.nt16);
+    {
+        // diagnostic: UMX_DEBUG_STAMPS=<layer name> prints the mean s_memtime segments of that layer's workgroups
+        static const char* dbg_layer = getenv("UMX_DEBUG_STAMPS");
+        if (dbg_layer && L.name == dbg_layer) {
+            const size_t nwg = (size_t)((ns + p.imgs - 1) / p.imgs) * p.tiles_y * p.tiles_x * p.nblocks * p.nphase;
+            long long* d = nullptr;
+            HIP_TRY(ctx, hipMalloc((void**)&d, nwg * 5 * sizeof(long long)));
+            p.dbg = d;
+            HIP_TRY(ctx, launch_conv_f16(p, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            std::vector<long long> hst(nwg * 5);
+            HIP_TRY(ctx, hipMemcpy(hst.data(), d, hst.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            hipFree(d);
+            double m[5] = {0, 0, 0, 0, 0};
+            for (size_t w = 0; w < nwg; ++w)
+                for (int k = 0; k < 5; ++k) m[k] += (double)hst[w * 5 + k] / nwg;
+            fprintf(stderr, "[umx stamps] %s: %zu workgroups, LDS %d B, OC-planes %d, wbuf %d B | cycles(100MHz ticks?) prologue %.0f "
+                            "wait %.0f mfma %.0f epilogue %.0f total %.0f\n", L.name.c_str(), nwg, p.lds_bytes,
+                    p.lo_off / (p.plane_slots * 16), p.wbuf_bytes, m[0], m[1], m[2], m[3], m[4]);
+            return UMX_OK;
+        }
+    }
     ProfScope ps(ctx, site_of(ctx, L.name, kn), L.flops * ns, L.bytes * ns, L.exec_flops * ns);
     HIP_TRY(ctx, launch_conv_f16(p, ctx->stream));
     return UMX_OK;

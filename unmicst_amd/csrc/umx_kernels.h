@@ -57,13 +57,15 @@ constexpr int kMaxNT16 = 9;      // N-tiles per workgroup of the split-precision
 constexpr int kStageK = 4;       // max k-steps (of 32 K-slots = 4 (tap, octet) pairs) per weight stage
 constexpr int kMaxLdsPerWG = 80 * 1024;   // two workgroups per CU share the 160 KiB
 
-struct HStage {      // one pipeline stage: optional halo (re)load + nk k-steps of weights
-    int woff;        // offset (uint4 units) of this stage's weight images inside one (phase, N-block) slab
-    short group;     // operand group whose halo is loaded at this stage, or -1 (halo already resident)
+struct HStage {      // one pipeline stage: optional halo chunk load + one weight block of nk k-steps
+    int woff;        // offset (uint4 units) of this stage's weight block inside one (phase, N-block) slab; a block is
+                     // a 64-byte header (k-map [nk][4] of LDS slots, unsigned short) + nk * NT * (hi, lo) images
+    short group;     // operand group whose halo chunk is loaded with this stage, or -1 (chunk already resident)
     short oct0;      // first octet (8 channels) of that group to load ...
-    short noct;      // ... and how many: LDS planes 0..noct-1
+    short noct;      // ... and how many ...
     short nk;        // k-steps in this stage (<= kStageK)
-    int k0;          // first k-step in HConvParams::kmap
+    short plane0;    // ... into LDS planes plane0 .. plane0+noct-1 (consecutive chunks alternate between two slots)
+    short pad;
 };
 
 struct HPhase {
@@ -82,24 +84,24 @@ struct HConvParams {
     int twm_log2, th_log2, nimg_m, imgs;
     int hh, hw, imgplane, nhalo; // halo geometry in pixels; nhalo = imgs * imgplane
     int plane_slots;             // 16-byte slots per LDS plane (nhalo rounded up to a multiple of 16)
-    int lo_off, b_off, lds_bytes;  // LDS byte offsets: lo planes, weight images; total dynamic LDS
+    int lo_off, b_off, lds_bytes;  // LDS byte offsets: lo planes, weight buffers; total dynamic LDS
+    int wbuf_bytes;                // one weight buffer (there are two): 64 + S * NT * 2048
     int ymin, xmin, tiles_y, tiles_x;
     int nphase, o_mul;
     HPhase ph[4];
     const HStage* stages;
-    const unsigned short* kmap;  // [k-step][4]: LDS slot (plane * plane_slots + tap offset) feeding lanes 16q..16q+15
     const uint4* zeros;          // >= 16 bytes of zeros in global memory (source for out-of-image halo slots)
     _Float16* dst_hi;
     _Float16* dst_lo;
     float* dst_f32;              // non-NULL: write fp32 NHWC [..,Cout] instead of the (hi, lo) pair
     int outH, outW, pool;
-    const float* pre_s;          // [Cout], never NULL here: BN scale (or 1) times 2^-(weight shift + activation shift)
-    const float* pre_b;
-    const float* post_s;
-    const float* post_b;
+    const uint4* econst;         // epilogue constants per N-block: [pre_s | pre_b | post_s | post_b] x NT*16 floats;
+                                 // pre_s = BN scale (or 1) * 2^-(weight shift + activation shift), post_* carry the
+                                 // 2^(activation shift) of the output; everything 0 for padded channels
+    float inv_imgplane, inv_hw;  // 1 / imgplane, 1 / hw
     int act;
-    float out_scale;             // 2^(activation shift) applied before the split
     int* overflow_flag;
+    long long* dbg;              // diagnostic builds only (UMX_DEBUG_STAMPS): per-workgroup s_memtime segments, or NULL
 };
 
 hipError_t launch_conv_f16(const HConvParams& p, hipStream_t stream);
