@@ -28,7 +28,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),           \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-template <int NT>
+// NPH = 1: one output phase per workgroup (plain convolutions; transposed convolutions one sub-pixel phase at a time,
+//          phase = blockIdx.z), KMT = 4 M-tiles per wave (256 pixels per workgroup).
+// NPH = 4: stride-2 transposed convolution with all four sub-pixel phases in one workgroup: the input halo is loaded
+//          once instead of four times, every stage carries the phase whose accumulators it feeds, KMT = 2 (128 input
+//          pixels -> 512 output pixels per workgroup), and the epilogue interleaves the phases so that whole output
+//          rows (32 consecutive pixels) are stored contiguously.
+template <int NT, int KMT, int NPH>
 __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -46,7 +52,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     const int img0 = bid * p.imgs;
     const int y0 = ty_i * TH, x0 = tx_i * TWm;
     const int nblk = blockIdx.y;
-    const HPhase& ph = p.ph[blockIdx.z];
+    const HPhase& ph = p.ph[NPH == 1 ? blockIdx.z : 0];
     // diagnostic stamps (shader-clock cycles), wave 0 only: [0] prologue, [1] waiting for loads + barriers, [2] MFMA
     // blocks, [3] epilogue, [4] whole kernel
     long long t_in = 0, t_wait = 0, t_comp = 0, t_a = 0, t_b = 0;
@@ -73,19 +79,21 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     }
 
     // ---- per-lane A-fragment pixel offsets (bytes) of this wave's M-tiles
-    int abase[kMT];
+    int abase[KMT];
 #pragma unroll
-    for (int m = 0; m < kMT; ++m) {
-        const int t = wave * kMT + m;
+    for (int m = 0; m < KMT; ++m) {
+        const int t = wave * KMT + m;
         const int ig = t >> p.th_log2, ty = t & (TH - 1);
         abase[m] = ((ig * p.nimg_m + (li >> p.twm_log2)) * p.imgplane + ty * p.hw + (li & (TWm - 1))) << 4;
     }
 
-    f32x4 acc[kMT][NT];
+    f32x4 accs[NPH][KMT][NT];
 #pragma unroll
-    for (int m = 0; m < kMT; ++m)
+    for (int h = 0; h < NPH; ++h)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < KMT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) accs[h][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int plane_bytes = p.plane_slots << 4;
     const int lo_off = p.lo_off;   // byte offset of the lo planes
@@ -149,29 +157,35 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
         else issue_econst((s + 1) & 1);
 
         const unsigned char* const wl = Bl + (s & 1) * p.wbuf_bytes;
+        // the k-steps of this stage on one accumulator set (the phase loop is unrolled: static register indexing)
 #pragma unroll
-        for (int j = 0; j < kStageK; ++j) {
-            if (j < cur.nk) {
-                const unsigned kb = (unsigned)*reinterpret_cast<const unsigned short*>(wl + (j * 4 + q) * 2) << 4;
-                const unsigned char* const ap = smem + kb;
-                const unsigned char* const bp = wl + 64 + j * (NT * 2048) + lane * 16;
-                h8 ah[kMT], al[kMT];
+        for (int h = 0; h < NPH; ++h) {
+            if (NPH > 1 && cur.phase != h) continue;   // wave-uniform
 #pragma unroll
-                for (int m = 0; m < kMT; ++m) {
-                    ah[m] = *reinterpret_cast<const h8*>(ap + abase[m]);
-                    al[m] = *reinterpret_cast<const h8*>(ap + abase[m] + lo_off);
-                }
+            for (int j = 0; j < kStageK; ++j) {
+                if (j < cur.nk) {
+                    const unsigned kb = (unsigned)*reinterpret_cast<const unsigned short*>(wl + (j * 4 + q) * 2) << 4;
+                    const unsigned char* const ap = smem + kb;
+                    const unsigned char* const bp = wl + 64 + j * (NT * 2048) + lane * 16;
+                    h8 ah[KMT], al[KMT];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {   // B fragments are streamed: two live at a time
-                    const h8 bh = *reinterpret_cast<const h8*>(bp + n * 2048);
-                    const h8 bl = *reinterpret_cast<const h8*>(bp + n * 2048 + 1024);
+                    for (int m = 0; m < KMT; ++m) {
+                        ah[m] = *reinterpret_cast<const h8*>(ap + abase[m]);
+                        al[m] = *reinterpret_cast<const h8*>(ap + abase[m] + lo_off);
+                    }
 #pragma unroll
-                    for (int m = 0; m < kMT; ++m) {
-                        // weights are the A operand (rows = output channels), activations the B operand (columns =
-                        // pixels): D[channel][pixel], so a lane ends up with 4 consecutive channels of one pixel
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[m], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[m], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[m], acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < NT; ++n) {   // B fragments are streamed: two live at a time
+                        const h8 bh = *reinterpret_cast<const h8*>(bp + n * 2048);
+                        const h8 bl = *reinterpret_cast<const h8*>(bp + n * 2048 + 1024);
+#pragma unroll
+                        for (int m = 0; m < KMT; ++m) {
+                            // weights are the A operand (rows = output channels), activations the B operand (columns =
+                            // pixels): D[channel][pixel], so a lane ends up with 4 consecutive channels of one pixel
+                            f32x4 c = accs[h][m][n];
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[m], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[m], c, 0, 0, 0);
+                            accs[h][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[m], c, 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -204,8 +218,9 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     // (hi, lo) output: through a per-wave LDS transpose -- each lane drops its 4 channels (8 bytes) into a [pixel][channel]
     // row image, then the wave stores whole rows, 16 bytes per lane, consecutive lanes consecutive addresses (pixels
     // that are neighbours in x are contiguous in NHWC): full-line writes instead of 8-byte fragments.
+    constexpr int ROWS = NPH == 4 ? 32 : 16;   // staged pixel rows per flush
     constexpr int PITCH = NT * 32 + 16;   // bytes per staged pixel row of one plane
-    constexpr int PLANE = 16 * PITCH;
+    constexpr int PLANE = ROWS * PITCH;
     constexpr int UR = NT * 2;            // 16-byte units per staged row
     unsigned char* const stg = smem + wave * (2 * PLANE);
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -219,55 +234,61 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
         const float psa[4] = {ps.x, ps.y, ps.z, ps.w}, pba[4] = {pb.x, pb.y, pb.z, pb.w};
         const float qsa[4] = {qs.x, qs.y, qs.z, qs.w}, qba[4] = {qb.x, qb.y, qb.z, qb.w};
 #pragma unroll
-        for (int m = 0; m < kMT; ++m)
+        for (int h = 0; h < NPH; ++h)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = acc[m][n][r] * psa[r] + pba[r];
-                if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-                else if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.2f * v;
-                v = v * qsa[r] + qba[r];
-                big |= !(fabsf(v) < 60000.f);
-                acc[m][n][r] = v;
-            }
-        if (p.pool) {   // rows m, m+1 are vertical neighbours; pixels li, li^1 horizontal neighbours
-#pragma unroll
-            for (int m = 0; m < kMT; m += 2)
+            for (int m = 0; m < KMT; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float a = fmaxf(acc[m][n][r], acc[m + 1][n][r]);
-                    const float b = __builtin_bit_cast(
-                        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1 /* quad_perm [1,0,3,2] */,
-                                                           0xF, 0xF, false));
-                    acc[m][n][r] = fmaxf(a, b);   // both lanes of the pair hold the pooled value; the even one stores
+                    float v = accs[h][m][n][r] * psa[r] + pba[r];
+                    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.2f * v;
+                    v = v * qsa[r] + qba[r];
+                    big |= !(fabsf(v) < 60000.f);
+                    accs[h][m][n][r] = v;
                 }
+        if constexpr (NPH == 1) {
+            if (p.pool) {   // rows m, m+1 are vertical neighbours; pixels li, li^1 horizontal neighbours
+#pragma unroll
+                for (int m = 0; m < KMT; m += 2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a = fmaxf(accs[0][m][n][r], accs[0][m + 1][n][r]);
+                        const float b = __builtin_bit_cast(
+                            float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1 /* quad_perm [1,0,3,2] */,
+                                                               0xF, 0xF, false));
+                        accs[0][m][n][r] = fmaxf(a, b);   // both lanes of the pair hold the pooled value; the even one stores
+                    }
+            }
         }
     }
     if (big && p.dst_f32 == nullptr) atomicOr(p.overflow_flag, 1);   // binary16 range exceeded: the host reports it
 
     if (p.dst_f32) {
+        if constexpr (NPH == 1) {
 #pragma unroll
-        for (int m = 0; m < kMT; ++m) {
-            const int t = wave * kMT + m;
-            const int ig = t >> p.th_log2, ty = t & (TH - 1);
-            const int img = img0 + ig * p.nimg_m + (li >> p.twm_log2);
-            if (img >= p.B) continue;
-            const long pix = (long)(img * p.outH + (y0 + ty) * p.o_mul + ph.oy_off) * p.outW +
-                             (x0 + (li & (TWm - 1))) * p.o_mul + ph.ox_off;
+            for (int m = 0; m < KMT; ++m) {
+                const int t = wave * KMT + m;
+                const int ig = t >> p.th_log2, ty = t & (TH - 1);
+                const int img = img0 + ig * p.nimg_m + (li >> p.twm_log2);
+                if (img >= p.B) continue;
+                const long pix = (long)(img * p.outH + (y0 + ty) * p.o_mul + ph.oy_off) * p.outW +
+                                 (x0 + (li & (TWm - 1))) * p.o_mul + ph.ox_off;
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const int c0 = nblk * (NT * 16) + n * 16 + 4 * q;
-                const f32x4 v = acc[m][n];
-                float* const d = p.dst_f32 + pix * p.Cout + c0;
-                if ((p.Cout & 3) == 0) {
-                    if (c0 < p.Cout) *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
+                for (int n = 0; n < NT; ++n) {
+                    const int c0 = nblk * (NT * 16) + n * 16 + 4 * q;
+                    const f32x4 v = accs[0][m][n];
+                    float* const d = p.dst_f32 + pix * p.Cout + c0;
+                    if ((p.Cout & 3) == 0) {
+                        if (c0 < p.Cout) *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (c0 + r < p.Cout) d[r] = v[r];
+                        for (int r = 0; r < 4; ++r)
+                            if (c0 + r < p.Cout) d[r] = v[r];
+                    }
                 }
             }
         }
-        return;
+        return;   // (the planner never pairs fp32 output with the fused transposed convolution)
     }
 
     __syncthreads();   // every wave has read its constants: the LDS is free for the transpose
@@ -276,7 +297,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     auto flush = [&](int R, auto pixel_of) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int k = 0; k < (16 * UR + 63) / 64; ++k) {
+        for (int k = 0; k < (ROWS * UR + 63) / 64; ++k) {
             const int u = lane + 64 * k;
             const int row = u / UR, cu = u - row * UR;
             const int c0 = nblk * (NT * 16) + cu * 8;
@@ -292,27 +313,41 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staged rows are in registers before the next tile overwrites
     };
-    auto put = [&](int row, int m) {   // this lane's 4 channels of every N-tile -> staged row
+#define UMX_PUT(row, A) /* this lane's 4 channels of every N-tile of accumulator row A -> staged row */ \
+    _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                        \
+        h4 hi, lo;                                                                                           \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                      \
+            hi[r] = (_Float16)(A)[n][r];                                                                     \
+            lo[r] = (_Float16)((A)[n][r] - (float)hi[r]);                                                    \
+        }                                                                                                    \
+        unsigned char* const d = stg + (row) * PITCH + (n * 16 + 4 * q) * 2;                                 \
+        *reinterpret_cast<h4*>(d) = hi;                                                                      \
+        *reinterpret_cast<h4*>(d + PLANE) = lo;                                                              \
+    }
+    if constexpr (NPH == 4) {
+        // output row 2y+pu of M-tile row y: its 32 pixels 2x+pv come from phases (pu,0) and (pu,1), interleaved here
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            h4 hi, lo;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                hi[r] = (_Float16)acc[m][n][r];
-                lo[r] = (_Float16)(acc[m][n][r] - (float)hi[r]);
-            }
-            unsigned char* const d = stg + row * PITCH + (n * 16 + 4 * q) * 2;
-            *reinterpret_cast<h4*>(d) = hi;
-            *reinterpret_cast<h4*>(d + PLANE) = lo;
-        }
-    };
-
-    if (p.pool) {
-#pragma unroll
-        for (int m = 0; m < kMT; m += 2) {
-            const int t = wave * kMT + m;
+        for (int m = 0; m < KMT; ++m) {
+            const int t = wave * KMT + m;
             const int ig = t >> p.th_log2, ty = t & (TH - 1);
-            if ((li & 1) == 0) put(li >> 1, m);   // pooled pixel j = li/2 of the 8 this M-tile pair produces
+#pragma unroll
+            for (int pu = 0; pu < 2; ++pu) {
+                UMX_PUT(2 * li, accs[pu * 2 + 0][m])
+                UMX_PUT(2 * li + 1, accs[pu * 2 + 1][m])
+                flush(32, [&](int row) -> long {
+                    const int i = row >> 1;
+                    const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
+                    if (img >= p.B) return -1;
+                    return (long)(img * p.outH + (y0 + ty) * 2 + pu) * p.outW + (x0 + (i & (TWm - 1))) * 2 + (row & 1);
+                });
+            }
+        }
+    } else if (p.pool) {
+#pragma unroll
+        for (int m = 0; m < KMT; m += 2) {
+            const int t = wave * KMT + m;
+            const int ig = t >> p.th_log2, ty = t & (TH - 1);
+            if ((li & 1) == 0) { UMX_PUT(li >> 1, accs[0][m]) }   // pooled pixel j = li/2 of the 8 this M-tile pair produces
             flush(8, [&](int j) -> long {
                 const int i = 2 * j;
                 const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
@@ -322,10 +357,10 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
         }
     } else {
 #pragma unroll
-        for (int m = 0; m < kMT; ++m) {
-            const int t = wave * kMT + m;
+        for (int m = 0; m < KMT; ++m) {
+            const int t = wave * KMT + m;
             const int ig = t >> p.th_log2, ty = t & (TH - 1);
-            put(li, m);
+            UMX_PUT(li, accs[0][m])
             flush(16, [&](int i) -> long {
                 const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
                 if (img >= p.B) return -1;
@@ -336,31 +371,41 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     }
 }
 
-template <int NT>
+template <int NT, int KMT, int NPH>
 static hipError_t launch_h_nt(const HConvParams& p, hipStream_t stream) {
     const int img_groups = (p.B + p.imgs - 1) / p.imgs;
-    dim3 grid((unsigned)(img_groups * p.tiles_y * p.tiles_x), (unsigned)p.nblocks, (unsigned)p.nphase);
+    dim3 grid((unsigned)(img_groups * p.tiles_y * p.tiles_x), (unsigned)p.nblocks, (unsigned)(NPH == 1 ? p.nphase : 1));
     const size_t lds = (size_t)p.lds_bytes;
-    const void* kern = reinterpret_cast<const void*>(conv_f16x3<NT>);
+    const void* kern = reinterpret_cast<const void*>(conv_f16x3<NT, KMT, NPH>);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(conv_f16x3<NT>, grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_f16x3<NT, KMT, NPH>), grid, dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
 hipError_t launch_conv_f16(const HConvParams& p, hipStream_t stream) {
+    if (p.fused_phases) {
+        switch (p.NT) {
+            case 1: return launch_h_nt<1, 2, 4>(p, stream);
+            case 2: return launch_h_nt<2, 2, 4>(p, stream);
+            case 3: return launch_h_nt<3, 2, 4>(p, stream);
+            case 4: return launch_h_nt<4, 2, 4>(p, stream);
+            case 5: return launch_h_nt<5, 2, 4>(p, stream);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (p.NT) {
-        case 1: return launch_h_nt<1>(p, stream);
-        case 2: return launch_h_nt<2>(p, stream);
-        case 3: return launch_h_nt<3>(p, stream);
-        case 4: return launch_h_nt<4>(p, stream);
-        case 5: return launch_h_nt<5>(p, stream);
-        case 6: return launch_h_nt<6>(p, stream);
-        case 7: return launch_h_nt<7>(p, stream);
-        case 8: return launch_h_nt<8>(p, stream);
-        case 9: return launch_h_nt<9>(p, stream);
+        case 1: return launch_h_nt<1, kMT, 1>(p, stream);
+        case 2: return launch_h_nt<2, kMT, 1>(p, stream);
+        case 3: return launch_h_nt<3, kMT, 1>(p, stream);
+        case 4: return launch_h_nt<4, kMT, 1>(p, stream);
+        case 5: return launch_h_nt<5, kMT, 1>(p, stream);
+        case 6: return launch_h_nt<6, kMT, 1>(p, stream);
+        case 7: return launch_h_nt<7, kMT, 1>(p, stream);
+        case 8: return launch_h_nt<8, kMT, 1>(p, stream);
+        case 9: return launch_h_nt<9, kMT, 1>(p, stream);
         default: return hipErrorInvalidValue;
     }
 }

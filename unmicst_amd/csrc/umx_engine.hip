@@ -534,16 +534,29 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, std::string* 
     const ConvParams& g = L.cp;   // tile geometry shared with the fp32 kernel
     HConvParams& h = L.hcp;
     memset(&h, 0, sizeof h);
-    h.twm_log2 = g.twm_log2; h.th_log2 = g.th_log2; h.nimg_m = g.nimg_m; h.imgs = g.imgs;
-    h.hh = g.hh; h.hw = g.hw; h.imgplane = g.imgplane; h.nhalo = g.imgs * g.imgplane;
-    h.ymin = g.ymin; h.xmin = g.xmin; h.tiles_y = g.tiles_y; h.tiles_x = g.tiles_x;
+    const int t16 = (L.Cout + 15) / 16;
+    // stride-2 transposed convolution with few output channels: all four sub-pixel phases in one workgroup (the input
+    // halo is read once instead of four times; 4 accumulator sets limit it to 5 N-tiles and 128 input pixels)
+    const bool fused = L.nphase == 4 && L.o_mul == 2 && L.ngroups == 1 && !out_f32 && t16 <= 5 && L.H >= 8 && L.W >= 16 &&
+                       !getenv("UMX_NO_FUSED_CONVT");
+    h.fused_phases = fused ? 1 : 0;
+    if (fused) {
+        const int THg = 1 << g.th_log2, TWg = 1 << g.twm_log2;   // >= 8 and == 16 under the conditions above
+        h.twm_log2 = 4; h.th_log2 = 3; h.nimg_m = 1; h.imgs = 1;
+        h.hh = 8 + (g.hh - THg); h.hw = 16 + (g.hw - TWg);
+        h.tiles_y = L.H / 8; h.tiles_x = L.W / 16;
+    } else {
+        h.twm_log2 = g.twm_log2; h.th_log2 = g.th_log2; h.nimg_m = g.nimg_m; h.imgs = g.imgs;
+        h.hh = g.hh; h.hw = g.hw; h.tiles_y = g.tiles_y; h.tiles_x = g.tiles_x;
+    }
+    h.imgplane = h.hh * h.hw; h.nhalo = h.imgs * h.imgplane;
+    h.ymin = g.ymin; h.xmin = g.xmin;
     h.nphase = L.nphase; h.o_mul = L.o_mul;
     h.H = L.H; h.W = L.W; h.Cout = L.Cout; h.Cds = round_up(L.Cout, 8);
     int nt16 = 1, Np16 = 16;
     {   // N-tiles per workgroup: minimise padded N, prefer wide workgroups (fewer re-reads of the input halo)
-        const int t16 = (L.Cout + 15) / 16;
         int best_pad = 1 << 30;
-        for (int c = 1; c <= kMaxNT16; ++c) {
+        for (int c = 1; c <= (fused ? 5 : kMaxNT16); ++c) {
             const int padded = round_up(t16, c);
             if (padded < best_pad || (padded == best_pad && c > nt16)) { nt16 = c; best_pad = padded; }
         }
@@ -572,39 +585,43 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, std::string* 
     // ---- chunking.  A chunk = up to OC octets of one operand group, resident in LDS while its (tap, octet) pairs are
     // consumed 4 per k-step; a stage = up to S k-steps = one weight block.  Consecutive chunks alternate between two
     // halo slots (even chunks at plane 0, odd chunks behind them) so that chunk c+1 loads while chunk c computes.
+    // Per-phase kernels walk their own chunk list (groups with taps in that phase); the fused kernel walks one list
+    // and, inside each chunk, the phases one after the other.
     int noct[2] = {0, 0};
     for (int gi = 0; gi < L.ngroups; ++gi) noct[gi] = round_up(L.g[gi].C, 8) / 8;
-    struct Chunk { int gi, o0, o1, npairs; };
-    auto chunks_for = [&](int OC, int ph) {
+    struct Chunk { int gi, o0, o1; };
+    auto chunks_for = [&](int OC, int ph /* -1: every group */) {
         std::vector<Chunk> out;
         for (int gi = 0; gi < L.ngroups; ++gi) {
-            const int nt = (int)L.g[gi].taps[ph].size();
-            if (!nt) continue;
+            if (ph >= 0 && L.g[gi].taps[ph].empty()) continue;
             const int nchunk = (noct[gi] + OC - 1) / OC;
-            for (int c = 0; c < nchunk; ++c) {
-                const int o0 = c * noct[gi] / nchunk, o1 = (c + 1) * noct[gi] / nchunk;
-                out.push_back({gi, o0, o1, nt * (o1 - o0)});
-            }
+            for (int c = 0; c < nchunk; ++c) out.push_back({gi, c * noct[gi] / nchunk, (c + 1) * noct[gi] / nchunk});
         }
         return out;
     };
+    const int nlists = fused ? 1 : L.nphase;   // independent stage lists (= kernel phases)
+    auto phases_of = [&](int list) { return fused ? std::make_pair(0, L.nphase) : std::make_pair(list, list + 1); };
     // LDS budget per workgroup: 80 KiB = 2 workgroups per CU; narrow layers (few accumulators -> few VGPRs) get a smaller
     // budget so that 3 workgroups per CU cover each other
     int lds_cap = kMaxLdsPerWG;
     {
         const char* e = getenv("UMX_LDS_CAP_NARROW");
         const int narrow = e ? atoi(e) : 53 * 1024;
-        if (nt16 <= 3 && narrow >= 16 * 1024) lds_cap = std::min(lds_cap, narrow);
+        if (!fused && nt16 <= 3 && narrow >= 16 * 1024) lds_cap = std::min(lds_cap, narrow);
     }
+    const int stage_rows = fused ? 32 : 16;
+    const int epi_bytes = kWaves * 2 * stage_rows * (nt16 * 32 + 16);   // epilogue transpose staging
     int bestOC = 0, bestS = 0, bestE = 0, bestO = 0;
     double bestCost = 1e30;
-    for (int OC = 1; OC <= 8; ++OC) {
+    for (int OC = 1; OC <= 9; ++OC) {
         int E = 0, O = 0, ksteps = 0;
-        for (int ph = 0; ph < L.nphase; ++ph) {
-            const auto ch = chunks_for(OC, ph);
+        for (int list = 0; list < nlists; ++list) {
+            const auto ch = chunks_for(OC, fused ? -1 : list);
+            const auto pr = phases_of(list);
             for (size_t c = 0; c < ch.size(); ++c) {
                 ((c & 1) ? O : E) = std::max((c & 1) ? O : E, ch[c].o1 - ch[c].o0);
-                ksteps += (ch[c].npairs + 3) / 4;
+                for (int ph = pr.first; ph < pr.second; ++ph)
+                    ksteps += ((int)L.g[ch[c].gi].taps[ph].size() * (ch[c].o1 - ch[c].o0) + 3) / 4;
             }
         }
         for (int S = 1; S <= kStageK; ++S) {
@@ -620,61 +637,69 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, std::string* 
     h.lo_off = (bestE + bestO) * h.plane_slots * 16;
     h.b_off = 2 * h.lo_off;
     h.wbuf_bytes = 64 + S * nt16 * 2048;
-    h.lds_bytes = std::max(h.b_off + 2 * h.wbuf_bytes, kWaves * 2 * 16 * (nt16 * 32 + 16));   // pipeline | epilogue transpose
+    h.lds_bytes = std::max(h.b_off + 2 * h.wbuf_bytes, epi_bytes);
+    if (h.lds_bytes > kMaxLdsPerWG) { *why = "epilogue staging exceeds the LDS budget"; return UMX_ERR_INVALID; }
 
     std::vector<HStage> stages;
-    std::vector<std::vector<_Float16>> wimg(L.nphase);   // per phase: [nblk][stage blocks] halves
+    std::vector<std::vector<_Float16>> wimg(nlists);   // per stage list: [nblk][stage blocks] halves
     L.n_ksteps = 0;
-    for (int ph = 0; ph < L.nphase; ++ph) {
-        h.ph[ph].oy_off = L.oy_off[ph];
-        h.ph[ph].ox_off = L.ox_off[ph];
-        h.ph[ph].stage0 = (int)stages.size();
-        struct Pair { int gi, tap, oct, plane; };
-        std::vector<std::vector<Pair>> steps;   // k-steps of this phase, each 4 pairs (padded ones have tap = -1)
-        const auto ch = chunks_for(OC, ph);
+    for (int list = 0; list < nlists; ++list) {
+        const auto pr = phases_of(list);
+        h.ph[list].oy_off = L.oy_off[list];
+        h.ph[list].ox_off = L.ox_off[list];
+        h.ph[list].stage0 = (int)stages.size();
+        struct Pair { int gi, ph, tap, oct, plane; };
+        std::vector<std::vector<Pair>> steps;   // k-steps of this list, each 4 pairs (padded ones have tap = -1)
+        const auto ch = chunks_for(OC, fused ? -1 : list);
         for (size_t c = 0; c < ch.size(); ++c) {
             const int gi = ch[c].gi, o0 = ch[c].o0, o1 = ch[c].o1;
             const int plane0 = (c & 1) ? bestE : 0;
-            const int nt = (int)L.g[gi].taps[ph].size();
-            std::vector<Pair> pairs;
-            for (int t = 0; t < nt; ++t)
-                for (int o = o0; o < o1; ++o) pairs.push_back({gi, t, o, plane0 + o - o0});
-            while (pairs.size() % 4) pairs.push_back({gi, -1, o0, plane0});   // zero-weight filler, reads a loaded slot
-            const int nk_chunk = (int)pairs.size() / 4;
-            for (int k = 0; k < nk_chunk; k += S) {
-                HStage st;
-                memset(&st, 0, sizeof st);
-                st.group = k == 0 ? (short)gi : (short)-1;
-                st.oct0 = (short)o0;
-                st.noct = (short)(o1 - o0);
-                st.plane0 = (short)plane0;
-                st.nk = (short)std::min(S, nk_chunk - k);
-                for (int j = 0; j < st.nk; ++j)
-                    steps.push_back(std::vector<Pair>(pairs.begin() + (k + j) * 4, pairs.begin() + (k + j) * 4 + 4));
-                stages.push_back(st);
+            bool first = true;   // the chunk's first stage carries its halo load
+            for (int ph = pr.first; ph < pr.second; ++ph) {
+                const int nt = (int)L.g[gi].taps[ph].size();
+                if (!nt) continue;
+                std::vector<Pair> pairs;
+                for (int t = 0; t < nt; ++t)
+                    for (int o = o0; o < o1; ++o) pairs.push_back({gi, ph, t, o, plane0 + o - o0});
+                while (pairs.size() % 4) pairs.push_back({gi, ph, -1, o0, plane0});   // zero-weight filler on a loaded slot
+                const int nk_chunk = (int)pairs.size() / 4;
+                for (int k = 0; k < nk_chunk; k += S) {
+                    HStage st;
+                    memset(&st, 0, sizeof st);
+                    st.group = first ? (short)gi : (short)-1;
+                    first = false;
+                    st.oct0 = (short)o0;
+                    st.noct = (short)(o1 - o0);
+                    st.plane0 = (short)plane0;
+                    st.phase = (short)ph;
+                    st.nk = (short)std::min(S, nk_chunk - k);
+                    for (int j = 0; j < st.nk; ++j)
+                        steps.push_back(std::vector<Pair>(pairs.begin() + (k + j) * 4, pairs.begin() + (k + j) * 4 + 4));
+                    stages.push_back(st);
+                }
             }
         }
-        h.ph[ph].nstages = (int)stages.size() - h.ph[ph].stage0;
+        h.ph[list].nstages = (int)stages.size() - h.ph[list].stage0;
         L.n_ksteps += (int)steps.size();
         // weight slab of one N-block: per stage a block = 64-byte header (k-map) + nk * NT * (hi, lo) images
         size_t per_blk = 0;   // halves
-        for (int si = h.ph[ph].stage0; si < (int)stages.size(); ++si) {
+        for (int si = h.ph[list].stage0; si < (int)stages.size(); ++si) {
             stages[si].woff = (int)(per_blk / 8);
             per_blk += 32 + (size_t)stages[si].nk * nt16 * 2 * 512;
         }
-        h.ph[ph].wblk_stride = (int)(per_blk / 8);
-        std::vector<_Float16>& W = wimg[ph];
+        h.ph[list].wblk_stride = (int)(per_blk / 8);
+        std::vector<_Float16>& W = wimg[list];
         W.assign(per_blk * h.nblocks, (_Float16)0.f);
         for (int nb = 0; nb < h.nblocks; ++nb) {
             size_t ks = 0;
-            for (int si = h.ph[ph].stage0; si < (int)stages.size(); ++si) {
+            for (int si = h.ph[list].stage0; si < (int)stages.size(); ++si) {
                 const size_t blk = nb * per_blk + (size_t)stages[si].woff * 8;
                 unsigned short* const hdr = reinterpret_cast<unsigned short*>(&W[blk]);
                 for (int j = 0; j < stages[si].nk; ++j, ++ks) {
                     for (int qq = 0; qq < 4; ++qq) {
-                        const Pair& pr = steps[ks][qq];
-                        const auto& tp = L.g[pr.gi].taps[ph][pr.tap < 0 ? 0 : pr.tap];
-                        const int slot = pr.plane * h.plane_slots + (tp.first - g.ymin) * g.hw + (tp.second - g.xmin);
+                        const Pair& pr2 = steps[ks][qq];
+                        const auto& tp = L.g[pr2.gi].taps[pr2.ph][pr2.tap < 0 ? 0 : pr2.tap];
+                        const int slot = pr2.plane * h.plane_slots + (tp.first - g.ymin) * h.hw + (tp.second - g.xmin);
                         if (slot < 0 || slot >= (bestE + bestO) * h.plane_slots || slot > 65535) {
                             *why = "internal: k-map slot out of range";
                             return UMX_ERR_INVALID;
@@ -683,16 +708,16 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, std::string* 
                     }
                     for (int n = 0; n < nt16; ++n)
                         for (int lane = 0; lane < 64; ++lane) {
-                            const Pair& pr = steps[ks][lane >> 4];
-                            if (pr.tap < 0) continue;
-                            const Group& G = L.g[pr.gi];
+                            const Pair& pr2 = steps[ks][lane >> 4];
+                            if (pr2.tap < 0) continue;
+                            const Group& G = L.g[pr2.gi];
                             const int Cp = round_up(G.C, 4);
                             const int co = nb * nt16 * 16 + n * 16 + (lane & 15);
                             const size_t base = blk + 32 + (((size_t)j * nt16 + n) * 2) * 512 + (size_t)lane * 8;
                             for (int e = 0; e < 8; ++e) {
-                                const int c = pr.oct * 8 + e;
+                                const int c = pr2.oct * 8 + e;
                                 if (c >= G.C || co >= L.Cout) continue;
-                                const float v = G.packed[ph][((size_t)pr.tap * Cp + c) * L.Np + co] * wscale;
+                                const float v = G.packed[pr2.ph][((size_t)pr2.tap * Cp + c) * L.Np + co] * wscale;
                                 const _Float16 hi = (_Float16)v;
                                 W[base + e] = hi;
                                 W[base + 512 + e] = (_Float16)(v - (float)hi);
@@ -726,8 +751,9 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, std::string* 
         h.econst = reinterpret_cast<const uint4*>(d);
     }
     if (getenv("UMX_DEBUG_PLAN"))
-        fprintf(stderr, "[umx plan] %-12s NT %d x %d blocks, OC %d (slots %d+%d planes), S %d, LDS %d B, k-steps %d, wshift %d\n",
-                L.name.c_str(), nt16, h.nblocks, OC, bestE, bestO, S, h.lds_bytes, L.n_ksteps, L.wshift);
+        fprintf(stderr, "[umx plan] %-12s %sNT %d x %d blocks, OC %d (slots %d+%d planes), S %d, LDS %d B, k-steps %d, wshift %d\n",
+                L.name.c_str(), fused ? "fused-phase " : "", nt16, h.nblocks, OC, bestE, bestO, S, h.lds_bytes, L.n_ksteps,
+                L.wshift);
     h.inv_imgplane = 1.f / (float)h.imgplane;
     h.inv_hw = 1.f / (float)h.hw;
     int rc;
@@ -740,10 +766,10 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, std::string* 
     }
     if ((rc = upload_raw(ctx, stages, &d_st))) return rc;
     h.stages = d_st;
-    for (int ph = 0; ph < L.nphase; ++ph) {
+    for (int list = 0; list < nlists; ++list) {
         _Float16* d = nullptr;
-        if ((rc = upload_raw(ctx, wimg[ph], &d))) return rc;
-        h.ph[ph].w = reinterpret_cast<const uint4*>(d);
+        if ((rc = upload_raw(ctx, wimg[list], &d))) return rc;
+        h.ph[list].w = reinterpret_cast<const uint4*>(d);
     }
     L.exec_flops = 2.0 * 3.0 * (double)L.n_ksteps * 32.0 * Np16 * L.H * L.W;   // MFMA work incl. split and padding
     return UMX_OK;

@@ -65,7 +65,7 @@ struct HStage {      // one pipeline stage: optional halo chunk load + one weigh
     short noct;      // ... and how many ...
     short nk;        // k-steps in this stage (<= kStageK)
     short plane0;    // ... into LDS planes plane0 .. plane0+noct-1 (consecutive chunks alternate between two slots)
-    short pad;
+    short phase;     // fused transposed convolution: the sub-pixel phase (accumulator set) this stage feeds
 };
 
 struct HPhase {
@@ -88,6 +88,7 @@ struct HConvParams {
     int wbuf_bytes;                // one weight buffer (there are two): 64 + S * NT * 2048
     int ymin, xmin, tiles_y, tiles_x;
     int nphase, o_mul;
+    int fused_phases;            // 1: stride-2 transposed convolution, all 4 phases per workgroup (KMT = 2, ph[0] only)
     HPhase ph[4];
     const HStage* stages;
     const uint4* zeros;          // >= 16 bytes of zeros in global memory (source for out-of-image halo slots)
