@@ -133,13 +133,14 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
 
     // epilogue constants of this N-block ([pre_s | pre_b | post_s | post_b] x NT*16 floats, defaults and 2^shift factors
     // folded on the host): loaded by LDS-DMA under the MFMAs of the last stage, into the weight buffer that stage frees
+    const int ec_units = p.head_K > 0 ? (4 + p.head_K) * (NT * 4) + 4 : NT * 16;   // uint4 per N-block
     auto issue_econst = [&](int buf) {
         if (wave == kWaves - 1) {
             float* const dst = reinterpret_cast<float*>(Bl + buf * p.wbuf_bytes);
 #pragma unroll
-            for (int i = 0; i < (NT * 16 + 63) / 64; ++i)
-                if (i * 64 + lane < NT * 16)
-                    UMX_GLDS16(p.econst + (size_t)nblk * (NT * 16) + i * 64 + lane, dst + i * 256);
+            for (int i = 0; i < (8 * NT * 4 + 4 + 63) / 64; ++i)
+                if (i * 64 + lane < ec_units)
+                    UMX_GLDS16(p.econst + (size_t)nblk * ec_units + i * 64 + lane, dst + i * 256);
         }
     };
     const float* const ec = reinterpret_cast<const float*>(Bl + (ph.nstages & 1) * p.wbuf_bytes);
@@ -261,7 +262,60 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
             }
         }
     }
-    if (big && p.dst_f32 == nullptr) atomicOr(p.overflow_flag, 1);   // binary16 range exceeded: the host reports it
+    if (big && p.dst_f32 == nullptr && p.head_K == 0) atomicOr(p.overflow_flag, 1);   // binary16 range exceeded: the host reports it
+
+    if constexpr (NPH == 1) {
+        if (p.head_K > 0) {
+            // fused top layer (reference UnMicst1-5.py:212-222,236-237 / UnMicst.py:167-171,186): 1x1 conv over this pixel's
+            // channels -- 4*NT of them in this lane, the rest in the lanes li+16, li+32, li+48 -- BN affine, softmax
+            const int K = p.head_K;
+            const float* const hsb = ec + (4 + K) * (NT * 16);   // [scale x 8 | bias x 8]
+#pragma unroll
+            for (int m = 0; m < KMT; ++m) {
+                float lg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < K) {
+                            const float4 w = ec4[(4 + k) * (NT * 4) + n * 4 + q];
+                            lg[k] += accs[0][m][n][0] * w.x + accs[0][m][n][1] * w.y + accs[0][m][n][2] * w.z +
+                                     accs[0][m][n][3] * w.w;
+                        }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < K) {
+                        lg[k] += __shfl_xor(lg[k], 16);
+                        lg[k] += __shfl_xor(lg[k], 32);
+                    }
+                const int t = wave * KMT + m;
+                const int ig = t >> p.th_log2, ty = t & (TH - 1);
+                const int img = img0 + ig * p.nimg_m + (li >> p.twm_log2);
+                if (q == 0 && img < p.B) {
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < K) {
+                            lg[k] = lg[k] * hsb[k] + hsb[8 + k];
+                            mx = fmaxf(mx, lg[k]);
+                        }
+                    float sum = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < K) {
+                            lg[k] = expf(lg[k] - mx);
+                            sum += lg[k];
+                        }
+                    const float inv = 1.f / sum;
+                    float* const d = p.probs + ((long)(img * p.outH + y0 + ty) * p.outW + x0 + (li & (TWm - 1))) * K;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < K) d[k] = lg[k] * inv;
+                }
+            }
+            return;
+        }
+    }
 
     if (p.dst_f32) {
         if constexpr (NPH == 1) {
@@ -433,6 +487,53 @@ hipError_t launch_split_f32(const float* x, size_t npix, int C, int Cs, float sc
     const size_t total = npix * (size_t)Cs;
     const unsigned blocks = (unsigned)((total + 255) / 256 < 256 * 16 ? (total + 255) / 256 : 256 * 16);
     hipLaunchKernelGGL(split_f32_kernel, dim3(blocks), dim3(256), 0, stream, x, npix, C, Cs, scale, hi, lo);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// PI2D.getPatch + per-tile normalisation + batch fill (reference PartitionOfImage.py:58-63,77-82, UnMicst1-5.py:700-702)
+// written straight into the (hi, lo) binary16 input planes of the first convolution (channels padded to Cs = 8):
+// one thread per tile pixel, two 16-byte stores.  Same float64 arithmetic as gather_normalise_kernel.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gather_split_kernel(const double* __restrict__ image, int C_img, int band_row0,
+                                                          int band_rows, TileGeom g, int Cn, double mean, double stdv,
+                                                          int tile0, int ntiles, float scale, uint4* __restrict__ hi,
+                                                          uint4* __restrict__ lo) {
+    const size_t total = (size_t)ntiles * g.P * g.P;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(e % g.P);
+        const size_t r1 = e / g.P;
+        const int y = (int)(r1 % g.P);
+        const int t = tile0 + (int)(r1 / g.P);
+        const int pr = t / g.npc, pc = t - pr * g.npc;
+        const int iy = pr * g.sub + y - g.margin, ix = pc * g.sub + x - g.margin;
+        const bool inside = iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+        union { _Float16 h[8]; uint4 u; } vh, vl;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float f = 0.f;
+            if (c < Cn) {
+                double v = 0.0;
+                if (inside) v = image[((size_t)(C_img == 1 ? 0 : c) * band_rows + (iy - band_row0)) * g.W + ix];
+                f = (float)((v - mean) / stdv) * scale;
+            }
+            vh.h[c] = (_Float16)f;
+            vl.h[c] = (_Float16)(f - (float)vh.h[c]);
+        }
+        hi[e] = vh.u;
+        lo[e] = vl.u;
+    }
+}
+
+hipError_t launch_gather_split(const double* image, int C_img, int band_row0, int band_rows, const TileGeom& g, int Cn,
+                               double mean, double stdv, int tile0, int ntiles, float scale, _Float16* hi, _Float16* lo,
+                               hipStream_t stream) {
+    if (ntiles <= 0) return hipSuccess;
+    if (Cn > 8) return hipErrorInvalidValue;
+    const size_t total = (size_t)ntiles * g.P * g.P;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 256 * 16 ? (total + 255) / 256 : 256 * 16);
+    hipLaunchKernelGGL(gather_split_kernel, dim3(blocks), dim3(256), 0, stream, image, C_img, band_row0, band_rows, g, Cn,
+                       mean, stdv, tile0, ntiles, scale, reinterpret_cast<uint4*>(hi), reinterpret_cast<uint4*>(lo));
     return hipGetLastError();
 }
 

@@ -115,6 +115,7 @@ struct umx_ctx {
     float* d_tiles32 = nullptr; // fp32 staging of gathered tiles before the split (f16 path)
     int* d_flag = nullptr;      // binary16 range overflow flag
     uint4* d_zeros = nullptr;
+    bool head_fused = false;
     struct Step16 { int launch; int sub; };   // launch index (-1: input split) and sub-batch size (0: whole batch)
     std::vector<Step16> plan16;
     Launch split_launch;
@@ -530,7 +531,7 @@ int upload_raw(umx_ctx* ctx, const std::vector<T>& h, T** out) {
 
 // ---- split-precision plan of one conv launch: chunking of the input octets, k-step table, stage table, weight images
 // (layout documented in umx_conv_f16.hip).  Reads the fp32 packing [tap][Cp][Np] produced by the Builder.
-int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, std::string* why) {
+int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch* head, std::string* why) {
     const ConvParams& g = L.cp;   // tile geometry shared with the fp32 kernel
     HConvParams& h = L.hcp;
     memset(&h, 0, sizeof h);
@@ -734,17 +735,29 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, std::string* 
         const float unshift = std::ldexp(1.f, -(L.wshift + act_shift));
         const float oscale = out_f32 ? 1.f : std::ldexp(1.f, act_shift);
         const int nb16 = nt16 * 16;
-        std::vector<float> ec((size_t)h.nblocks * 4 * nb16, 0.f);
+        // a fused softmax head needs every channel of a pixel in one workgroup; it replaces the fp32 store of this layer
+        const bool fuse_head = head && out_f32 && h.nblocks == 1 && head->head_K <= 4 && !fused && !getenv("UMX_NO_FUSED_HEAD");
+        h.head_K = fuse_head ? head->head_K : 0;
+        const size_t per_blk = fuse_head ? (size_t)(4 + h.head_K) * nb16 + 16 : (size_t)4 * nb16;
+        std::vector<float> ec((size_t)h.nblocks * per_blk, 0.f);
         for (int nb = 0; nb < h.nblocks; ++nb)
             for (int i = 0; i < nb16; ++i) {
                 const int c = nb * nb16 + i;
                 if (c >= L.Cout) continue;
-                float* e = &ec[(size_t)nb * 4 * nb16];
+                float* e = &ec[(size_t)nb * per_blk];
                 e[0 * nb16 + i] = (L.pre_s.empty() ? 1.f : L.pre_s[c]) * unshift;
                 e[1 * nb16 + i] = L.pre_b.empty() ? 0.f : L.pre_b[c];
                 e[2 * nb16 + i] = (L.post_s.empty() ? 1.f : L.post_s[c]) * oscale;
                 e[3 * nb16 + i] = (L.post_b.empty() ? 0.f : L.post_b[c]) * oscale;
+                for (int k = 0; k < h.head_K; ++k) e[(4 + k) * nb16 + i] = head->head_w[(size_t)c * head->head_K + k];
             }
+        if (fuse_head) {
+            float* e = &ec[(size_t)(4 + h.head_K) * nb16];
+            for (int k = 0; k < h.head_K; ++k) {
+                e[k] = head->pre_s.empty() ? 1.f : head->pre_s[k];
+                e[8 + k] = head->pre_b.empty() ? 0.f : head->pre_b[k];
+            }
+        }
         float* d = nullptr;
         int rc2 = upload(ctx, ec, &d);
         if (rc2) return rc2;
@@ -850,6 +863,7 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
     auto hi_at = [&](const Buffer& b) { return hi_of(b) + (size_t)k0 * b.S * b.S * b.Cs; };
     auto lo_at = [&](const Buffer& b) { return lo_of(b, n) + (size_t)k0 * b.S * b.S * b.Cs; };
     if (L.name == "input.split") {   // fp32 tiles -> (hi, lo) input planes (2 -> 8 channels, scaled by 2^act_shift)
+        if (!tiles) return UMX_OK;   // the gather kernel already wrote the (hi, lo) planes
         const Buffer& b0 = ctx->bufs[0];
         if (ctx->site_split < 0) ctx->site_split = site_of(ctx, "input.split", "split_f32");
         ProfScope ps(ctx, ctx->site_split, 0.0, (double)ns * b0.S * b0.S * (4.0 * b0.C + 4.0 * b0.Cs));
@@ -858,6 +872,7 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
         return UMX_OK;
     }
     if (L.head) {
+        if (ctx->head_fused) return UMX_OK;   // computed in the epilogue of the last convolution
         const Buffer& sb = ctx->bufs[L.g[0].src];
         const size_t npix = (size_t)ns * L.H * L.W;
         ProfScope ps(ctx, site_of(ctx, L.name, "head_softmax"), L.flops * ns, L.bytes * ns);
@@ -874,7 +889,8 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
         p.Cs[gi] = sb.Cs;
     }
     const Buffer& db = ctx->bufs[L.dst];
-    if (db.as_f32) p.dst_f32 = db.d + (size_t)k0 * db.floats_per_tile;
+    if (p.head_K > 0) p.probs = probs + (size_t)k0 * L.H * L.W * p.head_K;   // fused softmax head
+    else if (db.as_f32) p.dst_f32 = db.d + (size_t)k0 * db.floats_per_tile;
     else { p.dst_hi = hi_at(db); p.dst_lo = lo_at(db); }
     char kn[48];
     snprintf(kn, sizeof kn, "conv_f16x3<NT=%d>", L.nt16);
@@ -1134,12 +1150,18 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
         }
         if (!conv_geometry(L, &why)) { c->err = L.name + ": " + why; return bail(UMX_ERR_INVALID); }
         if (f16) {
-            if ((rc = plan_f16(c, L, act_shift, L.dst == head_src, &why))) {
+            if ((rc = plan_f16(c, L, act_shift, L.dst == head_src, &c->plan.back(), &why))) {
                 if (c->err.empty() || !why.empty()) c->err = L.name + ": " + why;
                 return bail(rc);
             }
             L.hcp.zeros = c->d_zeros;
             L.hcp.overflow_flag = c->d_flag;
+            if (L.hcp.head_K > 0) {
+                c->head_fused = true;
+                const Launch& Hd = c->plan.back();
+                L.flops += Hd.flops;
+                L.bytes += 4.0 * Hd.H * Hd.W * Hd.head_K - 4.0 * L.outH * L.outW * L.Cout;   // probabilities out, no fp32 tensor
+            }
             for (int ph = 0; ph < L.nphase; ++ph)
                 for (int gi = 0; gi < L.ngroups; ++gi) std::vector<float>().swap(L.g[gi].packed[ph]);
             continue;
@@ -1274,14 +1296,22 @@ int umx_band_tiles_dev(umx_ctx* ctx, const double* image_dev, int C_img, int H, 
     const size_t prob_f = (size_t)g.P * g.P * ctx->hp.nClasses;
     if (ctx->site_gather < 0) ctx->site_gather = site_of(ctx, "pi2d.gather_normalise", "gather_normalise");
     float* const tiles32 = ctx->precision == UMX_PREC_F16X3 ? ctx->d_tiles32 : ctx->bufs[0].d;
+    const bool direct16 = ctx->precision == UMX_PREC_F16X3 && ctx->hp.nChannels <= 8 && ctx->bufs[0].Cs == 8;
     for (int t = t0; t < t1; t += ctx->max_batch) {
         const int nb = std::min(ctx->max_batch, t1 - t);
         {
-            ProfScope ps(ctx, ctx->site_gather, 0.0, (double)nb * g.P * g.P * (8.0 + 4.0 * ctx->hp.nChannels));
-            HIP_TRY(ctx, launch_gather_normalise(image_dev, C_img, band_row0, band_rows, g, ctx->hp.nChannels, mean, stdv, t,
-                                                 nb, tiles32, ctx->stream));
+            ProfScope ps(ctx, ctx->site_gather, 0.0,
+                         (double)nb * g.P * g.P * (8.0 + (direct16 ? 32.0 : 4.0 * ctx->hp.nChannels)));
+            if (direct16) {   // gather + normalise + (hi, lo) split in one pass
+                const Buffer& b0 = ctx->bufs[0];
+                HIP_TRY(ctx, launch_gather_split(image_dev, C_img, band_row0, band_rows, g, ctx->hp.nChannels, mean, stdv, t, nb,
+                                                 std::ldexp(1.f, ctx->act_shift), hi_of(b0), lo_of(b0, nb), ctx->stream));
+            } else {
+                HIP_TRY(ctx, launch_gather_normalise(image_dev, C_img, band_row0, band_rows, g, ctx->hp.nChannels, mean, stdv, t,
+                                                     nb, tiles32, ctx->stream));
+            }
         }
-        int rc = run_unet(ctx, tiles32, nb, probs_dev + (size_t)(t - t0) * prob_f);
+        int rc = run_unet(ctx, direct16 ? nullptr : tiles32, nb, probs_dev + (size_t)(t - t0) * prob_f);
         if (rc) return rc;
     }
     return UMX_OK;

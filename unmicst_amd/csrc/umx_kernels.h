@@ -95,8 +95,11 @@ struct HConvParams {
     _Float16* dst_hi;
     _Float16* dst_lo;
     float* dst_f32;              // non-NULL: write fp32 NHWC [..,Cout] instead of the (hi, lo) pair
+    float* probs;                // head_K > 0: fused 1x1 conv + BN affine + softmax head, probabilities NHWC [..,head_K]
+    int head_K;                  // (needs nblocks == 1: every channel of a pixel in one workgroup)
     int outH, outW, pool;
-    const uint4* econst;         // epilogue constants per N-block: [pre_s | pre_b | post_s | post_b] x NT*16 floats;
+    const uint4* econst;         // epilogue constants per N-block: [pre_s | pre_b | post_s | post_b] x NT*16 floats
+                                 // (+ with a fused head: head_K rows of NT*16 head weights, then [scale | bias] x 8);
                                  // pre_s = BN scale (or 1) * 2^-(weight shift + activation shift), post_* carry the
                                  // 2^(activation shift) of the output; everything 0 for padded channels
     float inv_imgplane, inv_hw;  // 1 / imgplane, 1 / hw
@@ -114,6 +117,10 @@ struct TileGeom {
     int P, margin, sub;  // patch size, margin, sub-patch
     int npr, npc;        // patch rows / cols
 };
+
+hipError_t launch_gather_split(const double* image, int C_img, int band_row0, int band_rows, const TileGeom& g, int Cn,
+                               double mean, double stdv, int tile0, int ntiles, float scale, _Float16* hi, _Float16* lo,
+                               hipStream_t stream);
 
 hipError_t launch_gather_normalise(const double* image, int C_img, int band_row0, int band_rows, const TileGeom& g,
                                    int Cn, double mean, double stdv, int tile0, int ntiles, float* tiles,
