@@ -46,6 +46,28 @@ def synth_rows(torch, C, row0, rows, W, device):
     return torch.clamp(base + 0.12 * h, 0.0, 0.983).contiguous()
 
 
+def pmc_traffic(layer, precision, batch):
+    """HBM bytes per launch of `layer` from the committed rocprofv3 counter passes of this same command
+    (profiles/r01/final_<precision>_by_layer_pmc.csv, written by tools/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE collected in
+    separate --pmc passes, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  None when no profile of
+    this configuration is committed."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01", "final_%s_b%d_by_layer_pmc.csv" % (precision, batch))
+    if not os.path.exists(path):
+        return None
+    best = None
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            if r["pos"] == layer and r.get("hbm_read_MB_corrected") and r.get("hbm_write_MB"):
+                if best is None or int(r["calls"]) > int(best["calls"]):   # full batches, not the tail batch
+                    best = r
+    if best is None:
+        return None
+    rd, wr = float(best["hbm_read_MB_corrected"]) * 1e6, float(best["hbm_write_MB"]) * 1e6
+    return {"bytes_per_launch": rd + wr, "read": rd, "write": wr, "avg_launch_us_profiled": float(best["avg_us"]),
+            "source": os.path.relpath(path, ROOT)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,12 +170,14 @@ def main():
             # achieved = ALGORITHMIC fp32 FLOPs of the layer / HIP-event time of its launches; peak = dense MFMA peak of
             # the dtype the matrix cores run (f16x3 issues 3 binary16 MFMA FLOPs per algorithmic FLOP: "mfma_issued")
             "bound": "mfma", "achieved": round(dom_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(dom_tflops / peak, 4), "traffic": None,
+            "frac": round(dom_tflops / peak, 4), "traffic": pmc_traffic(dom["name"], eng.precision, args.batch),
             "kernel": dom["kernel"], "layer": dom["name"],
             "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
             "flop_per_launch": dom["flops"] / dom["launches"],
             "mfma_issued": {"tflops": round(dom["exec_flops"] / (dom["total_ms"] * 1e-3) / 1e12, 2),
                             "frac": round(dom["exec_flops"] / (dom["total_ms"] * 1e-3) / 1e12 / peak, 4)},
+            "compulsory_hbm": {"GBps": round(dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9, 1),
+                               "frac_of_8TBps": round(dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
             "all_conv_launches": {"achieved": round(all_flops / (all_ms * 1e-3) / 1e12, 2),
                                   "frac": round(all_flops / (all_ms * 1e-3) / 1e12 / peak, 4),
                                   "mfma_issued_frac": round(all_exec / (all_ms * 1e-3) / 1e12 / peak, 4),

@@ -85,3 +85,23 @@ def test_no_silent_cpu_fallback(lib):
     with pytest.raises(umx.UmxError) as e:
         umx.Engine(hp, model.random_blob(hp))
     assert e.value.code == 3
+
+
+def test_precision_options_are_validated_before_any_device_work(lib):
+    """umx_create_opts: unknown precision / out-of-range act_shift are UMX_ERR_INVALID even without a GPU; both real
+    precisions reach the device check (and fail with UMX_ERR_NO_DEVICE here -- there is no CPU fallback for either)."""
+    hp = helpers.small_hps()["v2_solo_like"]
+    blob = model.random_blob(hp)
+    with pytest.raises(umx.UmxError) as e:
+        umx.Engine(hp, blob, precision=7)
+    assert e.value.code == 1
+    with pytest.raises(umx.UmxError) as e:
+        umx.Engine(hp, blob, precision="f16x3", act_shift=9)
+    assert e.value.code == 1
+    if umx.device_count() == 0:
+        for prec in ("f32", "f16x3", "default"):
+            with pytest.raises(umx.UmxError) as e:
+                umx.Engine(hp, blob, precision=prec)
+            assert e.value.code == 3
+    assert ctypes.sizeof(umx._Options) == 64      # umx_options: 4 + 12 reserved int32
+    assert ctypes.sizeof(umx.ProfEntry) == 48 + 48 + 8 + 4 * 8

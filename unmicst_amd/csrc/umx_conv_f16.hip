@@ -158,6 +158,11 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
         else issue_econst((s + 1) & 1);
 
         const unsigned char* const wl = Bl + (s & 1) * p.wbuf_bytes;
+        // k-map of the stage up front: one LDS round trip per stage instead of one on every k-step's critical path
+        unsigned kbs[kStageK];
+#pragma unroll
+        for (int j = 0; j < kStageK; ++j)
+            kbs[j] = (unsigned)*reinterpret_cast<const unsigned short*>(wl + (j * 4 + q) * 2) << 4;
         // the k-steps of this stage on one accumulator set (the phase loop is unrolled: static register indexing)
 #pragma unroll
         for (int h = 0; h < NPH; ++h) {
@@ -165,8 +170,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
 #pragma unroll
             for (int j = 0; j < kStageK; ++j) {
                 if (j < cur.nk) {
-                    const unsigned kb = (unsigned)*reinterpret_cast<const unsigned short*>(wl + (j * 4 + q) * 2) << 4;
-                    const unsigned char* const ap = smem + kb;
+                    const unsigned char* const ap = smem + kbs[j];
                     const unsigned char* const bp = wl + 64 + j * (NT * 2048) + lane * 16;
                     h8 ah[KMT], al[KMT];
 #pragma unroll
