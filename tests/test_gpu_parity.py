@@ -162,3 +162,34 @@ def test_errors_are_reported_not_raised_in_c():
             eng.infer_image(np.zeros((3, 20, 20)), 0.1, 0.1)  # 3 channels into a 1-channel model
         with pytest.raises(umx.UmxError):
             eng.infer_image(np.zeros((20, 20)), 0.1, 0.0)     # std == 0
+
+
+def test_sharded_entry_point_with_rccl_world_of_one(tmp_path):
+    """bench.py's N>1 code path (sharding.infer_image_sharded: band tiles, halo exchange, RCCL all-gather) driven with the
+    real engine and the nccl backend in a world of one rank; the result must equal umx_infer_image bit for bit.  (Worlds of
+    2 and 3 ranks run on CPU over gloo in tests/test_sharding_cpu.py; 8 GPUs are the driver's to launch.)"""
+    import subprocess
+    import sys
+    script = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import helpers
+from unmicst_amd import model, sharding, umx
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29581")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+hp = helpers.small_hps()["v2_duo_like"]
+blob = model.random_blob(hp, seed=4)
+img = np.random.default_rng(2).random((2, 150, 61)) * 0.5
+with umx.Engine(hp, blob, max_batch=8) as eng:
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    want = eng.infer_image(img, 0.2, 0.2)
+    band = torch.from_numpy(img).cuda()
+    got = sharding.infer_image_sharded(eng, band, 0, 150, 61, 0.2, 0.2, umx.MODE_ACCUMULATE, umx.STITCH_FP16_COMPAT)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy().view(np.uint16), want.view(np.uint16))
+dist.destroy_process_group()
+print("sharded ok")
+''' % (helpers.ROOT, helpers.ROOT)
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "sharded ok" in r.stdout, r.stderr[-3000:]

@@ -1184,9 +1184,12 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
         const Buffer& b0 = c->bufs[0];
         c->split_launch.bytes = (double)b0.S * b0.S * (4.0 * b0.C + 4.0 * b0.Cs);
         std::vector<double> bytes = {c->split_launch.bytes};
-        for (auto& L : c->plan) bytes.push_back(L.head ? L.bytes : 4.0 * L.outH * L.outW * round_up(L.Cout, 8) +
-                                                [&] { double t = 0; for (int gi = 0; gi < L.ngroups; ++gi)
-                                                          t += 4.0 * L.H * L.W * round_up(L.g[gi].C, 8); return t; }());
+        for (auto& L : c->plan) {
+            double t = L.head ? L.bytes : 4.0 * L.outH * L.outW * round_up(L.Cout, 8);
+            if (!L.head)
+                for (int gi = 0; gi < L.ngroups; ++gi) t += 4.0 * L.H * L.W * round_up(L.g[gi].C, 8);
+            bytes.push_back(t);
+        }
         const int nl = (int)bytes.size();
         for (int i = 0; i < nl;) {
             int j = i;
