@@ -612,24 +612,85 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     }
     const int stage_rows = fused ? 32 : 16;
     const int epi_bytes = kWaves * 2 * stage_rows * (nt16 * 32 + 16);   // epilogue transpose staging
+
+    // One stage list (= one kernel phase, or the whole fused transposed convolution) for a given (OC, S, slot base E):
+    // (tap, octet) pairs of every chunk -> k-steps of 4 -> stages of <= S k-steps.  Pairs left over when a chunk's
+    // pair count is not a multiple of 4 are carried into the first k-step of the next chunk instead of being padded:
+    // the previous chunk's halo slot is still resident then (its reload is issued at the start of the next chunk's LAST
+    // stage, so the next chunk must have >= 2 stages).  Not across the phases of the fused kernel (other accumulators).
+    struct Pair { int gi, ph, tap, oct, plane; };
+    const bool carry_ok = !fused && !getenv("UMX_NO_KSTEP_CARRY");
+    auto npairs_of = [&](const Chunk& k, int ph) { return (int)L.g[k.gi].taps[ph].size() * (k.o1 - k.o0); };
+    auto plan_list = [&](int OC, int S, int E, int list, std::vector<HStage>* stages_out,
+                         std::vector<std::vector<Pair>>* steps_out, int* nchunks) {
+        const auto pr = phases_of(list);
+        const auto ch = chunks_for(OC, fused ? -1 : list);
+        if (nchunks) *nchunks = (int)ch.size();
+        int nsteps = 0;
+        std::vector<Pair> carry;
+        for (size_t c = 0; c < ch.size(); ++c) {
+            const int gi = ch[c].gi, o0 = ch[c].o0, o1 = ch[c].o1;
+            const int plane0 = (c & 1) ? E : 0;
+            bool first = true;   // the chunk's first stage carries its halo load
+            for (int ph = pr.first; ph < pr.second; ++ph) {
+                const int nt = (int)L.g[gi].taps[ph].size();
+                if (!nt) continue;
+                std::vector<Pair> pairs = carry;
+                carry.clear();
+                for (int t = 0; t < nt; ++t)
+                    for (int o = o0; o < o1; ++o) pairs.push_back({gi, ph, t, o, plane0 + o - o0});
+                const int rem = (int)pairs.size() % 4;
+                if (rem && carry_ok && c + 1 < ch.size() && (int)pairs.size() >= 4) {
+                    // stages the next chunk will have if it takes the remainder (it pads or carries on in turn)
+                    const int next_k = (rem + npairs_of(ch[c + 1], ph) + (c + 2 < ch.size() ? 0 : 3)) / 4;
+                    if ((next_k + S - 1) / S >= 2) {
+                        carry.assign(pairs.end() - rem, pairs.end());
+                        pairs.resize(pairs.size() - rem);
+                    }
+                }
+                while (pairs.size() % 4) pairs.push_back({gi, ph, -1, o0, plane0});   // zero-weight filler on a loaded slot
+                const int nk_chunk = (int)pairs.size() / 4;
+                nsteps += nk_chunk;
+                for (int k = 0; k < nk_chunk; k += S) {
+                    HStage st;
+                    memset(&st, 0, sizeof st);
+                    st.group = first ? (short)gi : (short)-1;
+                    first = false;
+                    st.oct0 = (short)o0;
+                    st.noct = (short)(o1 - o0);
+                    st.plane0 = (short)plane0;
+                    st.phase = (short)ph;
+                    st.nk = (short)std::min(S, nk_chunk - k);
+                    if (steps_out)
+                        for (int j = 0; j < st.nk; ++j)
+                            steps_out->push_back(std::vector<Pair>(pairs.begin() + (k + j) * 4, pairs.begin() + (k + j) * 4 + 4));
+                    if (stages_out) stages_out->push_back(st);
+                }
+            }
+        }
+        return nsteps;
+    };
+
     int bestOC = 0, bestS = 0, bestE = 0, bestO = 0;
     double bestCost = 1e30;
     for (int OC = 1; OC <= 9; ++OC) {
-        int E = 0, O = 0, ksteps = 0;
+        int E = 0, O = 0;
         for (int list = 0; list < nlists; ++list) {
             const auto ch = chunks_for(OC, fused ? -1 : list);
-            const auto pr = phases_of(list);
-            for (size_t c = 0; c < ch.size(); ++c) {
-                ((c & 1) ? O : E) = std::max((c & 1) ? O : E, ch[c].o1 - ch[c].o0);
-                for (int ph = pr.first; ph < pr.second; ++ph)
-                    ksteps += ((int)L.g[ch[c].gi].taps[ph].size() * (ch[c].o1 - ch[c].o0) + 3) / 4;
-            }
+            for (size_t c = 0; c < ch.size(); ++c) ((c & 1) ? O : E) = std::max((c & 1) ? O : E, ch[c].o1 - ch[c].o0);
         }
         for (int S = 1; S <= kStageK; ++S) {
             const int lds = (E + O) * plane_pair + 2 * (64 + S * nt16 * 2048);
             if (lds > lds_cap) continue;
-            // executed k-steps, plus a barrier/latency charge per stage, slight preference for the conflict-free OC = 4
-            const double cost = ksteps * (1.0 + 0.30 / S) * (OC == 4 ? 0.98 : 1.0);
+            int ksteps = 0, nchunks = 0;
+            for (int list = 0; list < nlists; ++list) {
+                int nc = 0;
+                ksteps += plan_list(OC, S, E, list, nullptr, nullptr, &nc);
+                nchunks += nc;
+            }
+            // executed k-steps (exact), a barrier/latency charge per stage, a charge per halo chunk load (measured
+            // ~0.35 k-steps on the deep layers), slight preference for the conflict-free OC = 4
+            const double cost = (ksteps * (1.0 + 0.30 / S) + 0.35 * nchunks) * (OC == 4 ? 0.98 : 1.0);
             if (cost < bestCost) { bestCost = cost; bestOC = OC; bestS = S; bestE = E; bestO = O; }
         }
     }
@@ -645,41 +706,11 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     std::vector<std::vector<_Float16>> wimg(nlists);   // per stage list: [nblk][stage blocks] halves
     L.n_ksteps = 0;
     for (int list = 0; list < nlists; ++list) {
-        const auto pr = phases_of(list);
         h.ph[list].oy_off = L.oy_off[list];
         h.ph[list].ox_off = L.ox_off[list];
         h.ph[list].stage0 = (int)stages.size();
-        struct Pair { int gi, ph, tap, oct, plane; };
         std::vector<std::vector<Pair>> steps;   // k-steps of this list, each 4 pairs (padded ones have tap = -1)
-        const auto ch = chunks_for(OC, fused ? -1 : list);
-        for (size_t c = 0; c < ch.size(); ++c) {
-            const int gi = ch[c].gi, o0 = ch[c].o0, o1 = ch[c].o1;
-            const int plane0 = (c & 1) ? bestE : 0;
-            bool first = true;   // the chunk's first stage carries its halo load
-            for (int ph = pr.first; ph < pr.second; ++ph) {
-                const int nt = (int)L.g[gi].taps[ph].size();
-                if (!nt) continue;
-                std::vector<Pair> pairs;
-                for (int t = 0; t < nt; ++t)
-                    for (int o = o0; o < o1; ++o) pairs.push_back({gi, ph, t, o, plane0 + o - o0});
-                while (pairs.size() % 4) pairs.push_back({gi, ph, -1, o0, plane0});   // zero-weight filler on a loaded slot
-                const int nk_chunk = (int)pairs.size() / 4;
-                for (int k = 0; k < nk_chunk; k += S) {
-                    HStage st;
-                    memset(&st, 0, sizeof st);
-                    st.group = first ? (short)gi : (short)-1;
-                    first = false;
-                    st.oct0 = (short)o0;
-                    st.noct = (short)(o1 - o0);
-                    st.plane0 = (short)plane0;
-                    st.phase = (short)ph;
-                    st.nk = (short)std::min(S, nk_chunk - k);
-                    for (int j = 0; j < st.nk; ++j)
-                        steps.push_back(std::vector<Pair>(pairs.begin() + (k + j) * 4, pairs.begin() + (k + j) * 4 + 4));
-                    stages.push_back(st);
-                }
-            }
-        }
+        plan_list(OC, S, bestE, list, &stages, &steps, nullptr);
         h.ph[list].nstages = (int)stages.size() - h.ph[list].stage0;
         L.n_ksteps += (int)steps.size();
         // weight slab of one N-block: per stage a block = 64-byte header (k-map) + nk * NT * (hi, lo) images
