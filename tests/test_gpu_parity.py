@@ -193,3 +193,36 @@ print("sharded ok")
 ''' % (helpers.ROOT, helpers.ROOT)
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "sharded ok" in r.stdout, r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("prec", PRECS)
+@pytest.mark.parametrize("key", ["nucleiDAPI1-5", "nucleiDAPILAMIN"])
+def test_forward_tiles_shipped_hyper_parameters(key, prec):
+    """The exact hyper-parameters of the reference's solo / duo models (hp.data of models/nucleiDAPI1-5 and
+    models/nucleiDAPILAMIN: 64x64x1 with widths 80..1280, 128x128x2 with widths 36..1152).  Their weight shards are
+    not shipped (reference Dockerfile:5-6), so seeded weights stand in: this pins shapes / planner / kernels at full width,
+    not the trained numerics."""
+    from oracle import oracle
+    hp = model.KNOWN_HP[key]
+    blob = model.random_blob(hp, seed=7)
+    x = np.random.default_rng(3).normal(size=(3, hp.imSize, hp.imSize, hp.nChannels)).astype(np.float32)
+    ref = oracle.forward(hp, blob, x)
+    with umx.Engine(hp, blob, max_batch=2, precision=prec) as eng:
+        got = eng.forward_tiles(x)
+    assert np.abs(got - ref).max() <= TILE_TOL
+
+
+@pytest.mark.parametrize("shape", [(5, 7), (31, 200), (129, 33)])
+def test_infer_image_edge_sizes(shape):
+    """Images smaller than one tile / one sub-patch and ragged sizes (the reference pads to whole sub-patches,
+    PartitionOfImage.py:46-63): stitched planes vs the reference-equivalent oracle loop."""
+    from oracle import oracle
+    hp = helpers.small_hps()["v2_solo_like"]
+    blob = model.random_blob(hp, seed=5)
+    img = np.random.default_rng(11).random(shape) * 0.7
+    with umx.Engine(hp, blob, max_batch=3) as eng:
+        got = eng.infer_image(img, 0.3, 0.2)
+    assert got.shape == (hp.nClasses,) + shape
+    for k in range(hp.nClasses):
+        ref = oracle.single_image_inference(hp, blob, img, 0.3, 0.2, "accumulate", k, duplicate_plane=False)
+        assert np.abs(got[k].astype(np.float32) - ref.astype(np.float32)).max() <= 1e-3
