@@ -181,3 +181,29 @@ def test_band_partition_and_ownership_cover_the_image_once():
                         lo = max(0, (y0 + m - patch + sub) // sub) if y0 + m - patch + 1 > 0 else 0
                         hi = min(npr - 1, (y1 - 1 + m) // sub)
                         assert lo >= max(0, a - 1) and hi <= b - 1
+
+
+def test_slabs_tile_the_owned_rows_and_only_need_computed_patch_rows():
+    """sharding.slab_rows: the slabs of a band partition its owned rows, and slab i only touches patch rows below cut
+    i+1 (or the band's last patch row, which is computed first) -- the condition for stitching it before later tiles exist."""
+    for npr in (2, 5, 11, 86):
+        for world in (1, 2, 3, 8):
+            for patch in (32, 256):
+                m = patch // 8
+                sub = patch - 2 * m
+                H = npr * sub - 3
+                bands = sharding.band_partition(npr, world)
+                active = [b for b in bands if b[1] > b[0]]
+                n = max(1, min(4, min(b - a for a, b in active)))
+                for a, b in active:
+                    y0, y1 = sharding.owned_rows(a, b, npr, sub, m, H)
+                    cuts = sharding._slab_cuts(a, b, n)
+                    pos = y0
+                    for i in range(n):
+                        s0, s1 = sharding.slab_rows(a, b, npr, sub, m, H, n, i)
+                        assert s0 == pos and s1 >= s0
+                        pos = s1
+                        if s1 > s0 and i < n - 1:
+                            hi = min(npr - 1, (s1 - 1 + m) // sub)     # last patch row touching the slab
+                            assert hi < cuts[i + 1]
+                    assert pos == y1

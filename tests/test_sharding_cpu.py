@@ -22,7 +22,8 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,hp_name,H,W,C", [(2, "v2_duo_like", 100, 61, 2), (3, "legacy_k3_x0", 130, 40, 1),
-                                                  (2, "v2_duo_like", 20, 30, 2)])  # last: fewer patch rows than ranks
+                                                  (2, "v2_duo_like", 20, 30, 2),    # fewer patch rows than ranks
+                                                  (2, "v2_solo_like", 260, 40, 1)])  # 6 + 5 patch rows: 4 slabs per band
 def test_sharded_equals_single_process(tmp_path, world, hp_name, H, W, C):
     from oracle import oracle
     from unmicst_amd import model

@@ -5,11 +5,12 @@ units; the only coupling is the overlap-add stitch (each output pixel is covered
 
 * patch rows are split into contiguous bands, one per rank (``band_partition``);
 * rank r computes the tile probabilities of its patch rows [pa, pb) from the image rows it holds;
-* ONE exchange step: rank r sends the probabilities of its LAST patch row to rank r+1 (the 2*margin image rows
-  below a band boundary are covered by patch rows pb-1 and pb);
+* ONE exchange step: rank r sends the probabilities of its LAST patch row (computed first) to rank r+1 (the 2*margin
+  image rows below a band boundary are covered by patch rows pb-1 and pb);
 * rank r stitches the image rows it owns -- padded rows [pa*sub, pb*sub) -- visiting covering tiles in ascending
   global tile index, exactly like the single-GPU kernel, so the float16 result is bit-identical to a 1-GPU run;
-* the stitched bands are all-gathered (``dist.all_gather_into_tensor`` on equal-size padded bands).
+* the stitched rows are all-gathered slab by slab (``dist.all_gather_into_tensor``, asynchronous, on equal-size padded
+  slabs) while the next slab's tiles are being computed.
 
 The engine object only needs ``hp``, ``tile_grid``, ``band_tiles_dev``, ``stitch_dev`` -- tests drive the same host
 logic on CPU (gloo) with an oracle-backed stand-in.
@@ -80,13 +81,36 @@ def infer_band_local(eng, d_image, mean: float, std: float, rank: int, world: in
     return out
 
 
+def _slab_cuts(pa: int, pb: int, n: int) -> List[int]:
+    return [pa + ((pb - pa) * i) // n for i in range(n + 1)]
+
+
+def slab_rows(pa: int, pb: int, npr: int, sub: int, margin: int, H: int, n: int, i: int) -> Tuple[int, int]:
+    """Image rows of slab i of n of the band holding patch rows [pa, pb): the band's owned rows cut where patch-row
+    cut c stops touching them -- image rows below c*sub - margin are covered by patch rows < c only."""
+    if pa >= pb:
+        return (0, 0)
+    y0, y1 = owned_rows(pa, pb, npr, sub, margin, H)
+    c = _slab_cuts(pa, pb, n)
+    s0 = y0 if i == 0 else min(y1, max(y0, c[i] * sub - margin))
+    s1 = y1 if i == n - 1 else min(y1, max(y0, c[i + 1] * sub - margin))
+    return (s0, max(s0, s1))
+
+
 def infer_image_sharded(eng, d_band, band_row0: int, H: int, W: int, mean: float, std: float, mode: int, stitch: int,
-                        group=None, gather: bool = True):
+                        group=None, gather: bool = True, nslabs: int = 4):
     """Distributed whole-slide inference.  Every rank calls this with the image rows it holds.
 
     d_band: float64 tensor [C, band_rows, W] = image rows [band_row0, band_row0+band_rows) (must cover
     ``needed_image_rows`` of this rank's patch rows).  Returns the full [K, H, W] result on every rank
     (``gather=True``) or this rank's stitched band and its (y0, y1).
+
+    Schedule -- communication rides under tile compute (on a GPU every engine call is stream-ordered on the engine's
+    stream, which the caller sets to torch's current stream; RCCL work runs on the communicator's stream):
+      1. the LAST patch row of the band is computed first and sent to the next rank (the one exchange step of the path);
+      2. the band is then computed in ``nslabs`` slabs of patch rows; as soon as a slab's image rows are final they are
+         stitched and their all-gather starts asynchronously, overlapping the next slab's tiles.
+    The stitch still visits tiles in ascending global index, so the result is bit-identical to a single-GPU run.
     """
     import torch
     import torch.distributed as dist
@@ -102,50 +126,62 @@ def infer_image_sharded(eng, d_band, band_row0: int, H: int, W: int, mean: float
     dev = d_band.device
     out_dtype = torch.float32 if stitch == umx.STITCH_FP32 else torch.float16
     P, K = hp.imSize, hp.nClasses
+    glob = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    # the same slab count on every rank (every rank issues the same sequence of collectives)
+    n = max(1, min(int(nslabs), min(bands[r][1] - bands[r][0] for r in active)))
 
     has_prev = pa < pb and pa > 0
     has_next = pa < pb and pb < npr
     lo = pa - 1 if has_prev else pa
     probs = torch.empty((max(pb - lo, 0) * npc, P, P, K), dtype=torch.float32, device=dev)
-    if pa < pb:
-        own = probs[(pa - lo) * npc:]
-        eng.band_tiles_dev(d_band.data_ptr(), C, H, W, band_row0, band_rows, mean, std, pa, pb, own.data_ptr())
-        eng.synchronize()
-    # the one exchange step of the path: last patch row of rank r -> rank r+1 (point-to-point over xGMI)
+
+    def tiles(r0, r1):   # patch rows [r0, r1) of this band -> probs
+        if r1 > r0:
+            eng.band_tiles_dev(d_band.data_ptr(), C, H, W, band_row0, band_rows, mean, std, r0, r1,
+                               probs[(r0 - lo) * npc:].data_ptr())
+
     reqs = []
-    if has_next:
-        nxt = active[active.index(rank) + 1]
-        reqs.append(dist.isend(probs[-npc:].contiguous(), dst=dist.get_global_rank(group, nxt) if group else nxt,
-                               group=group))
-    if has_prev:
-        prv = active[active.index(rank) - 1]
-        reqs.append(dist.irecv(probs[:npc], src=dist.get_global_rank(group, prv) if group else prv, group=group))
-    for r in reqs:
-        r.wait()
-    if dev.type == "cuda":
-        torch.cuda.current_stream(dev).synchronize()
-
-    band = torch.empty((K, y1 - y0, W), dtype=out_dtype, device=dev)
-    if y1 > y0:
-        eng.stitch_dev(probs.data_ptr(), lo, pb, H, W, mode, stitch, y0, y1, band.data_ptr())
+    if pa < pb:
+        tiles(pb - 1, pb)                       # last patch row first: the next rank is waiting for it
         eng.synchronize()
-    if not gather:
-        return band, (y0, y1)
+    if has_next:
+        reqs.append(dist.isend(probs[-npc:], dst=glob(active[active.index(rank) + 1]), group=group))
+    if has_prev:
+        reqs.append(dist.irecv(probs[:npc], src=glob(active[active.index(rank) - 1]), group=group))
 
-    # all-gather of equal-size (padded) stitched bands, then drop the padding
-    rows = [owned_rows(a, b, npr, sub, margin, H) for a, b in bands]
-    max_rows = max(1, max(b - a for a, b in rows))
-    padded = torch.zeros((K, max_rows, W), dtype=out_dtype, device=dev)
-    padded[:, :y1 - y0] = band
-    gathered = torch.empty((world * K, max_rows, W), dtype=out_dtype, device=dev)   # concatenation along dim 0
-    if dev.type == "cpu":
-        # gloo (CPU tests): move the raw bytes, whatever the element type
-        dist.all_gather_into_tensor(gathered.view(torch.uint8), padded.view(torch.uint8), group=group)
-    else:
-        dist.all_gather_into_tensor(gathered, padded, group=group)
-    gathered = gathered.view(world, K, max_rows, W)
-    full = torch.empty((K, H, W), dtype=out_dtype, device=dev)
-    for r, (a, b) in enumerate(rows):
-        if b > a:
-            full[:, a:b] = gathered[r, :, :b - a]
+    cuts = _slab_cuts(pa, pb, n) if pa < pb else [0] * (n + 1)
+    full = torch.empty((K, H, W), dtype=out_dtype, device=dev) if gather else None
+    slabs, pending = [], []
+    for i in range(n):
+        tiles(cuts[i], min(cuts[i + 1], pb - 1))
+        if i == 0:
+            for r in reqs:                      # the previous rank's last patch row feeds the first rows of this band
+                r.wait()
+        s0, s1 = slab_rows(pa, pb, npr, sub, margin, H, n, i)
+        slab = torch.empty((K, s1 - s0, W), dtype=out_dtype, device=dev)
+        if s1 > s0:
+            eng.stitch_dev(probs.data_ptr(), lo, pb, H, W, mode, stitch, s0, s1, slab.data_ptr())
+        if not gather:
+            slabs.append(slab)
+            continue
+        rows = [slab_rows(a, b, npr, sub, margin, H, n, i) for a, b in bands]
+        mx = max(1, max(b - a for a, b in rows))
+        padded = torch.zeros((K, mx, W), dtype=out_dtype, device=dev)
+        padded[:, :s1 - s0] = slab
+        gathered = torch.empty((world * K, mx, W), dtype=out_dtype, device=dev)   # concatenation along dim 0
+        if dev.type == "cpu":   # gloo (CPU tests): move the raw bytes, whatever the element type
+            work = dist.all_gather_into_tensor(gathered.view(torch.uint8), padded.view(torch.uint8), group=group,
+                                               async_op=True)
+        else:
+            work = dist.all_gather_into_tensor(gathered, padded, group=group, async_op=True)
+        pending.append((work, gathered, rows, mx))
+    if not gather:
+        eng.synchronize()
+        return (torch.cat(slabs, dim=1) if slabs else torch.empty((K, 0, W), dtype=out_dtype, device=dev)), (y0, y1)
+    for work, gathered, rows, mx in pending:
+        work.wait()
+        g4 = gathered.view(world, K, mx, W)
+        for r, (a, b) in enumerate(rows):
+            if b > a:
+                full[:, a:b] = g4[r, :, :b - a]
     return full
