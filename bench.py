@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--cols", type=int, default=0, help="override slide width")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-layer table to stderr")
+    ap.add_argument("--slabs", type=int, default=2, help="N>1 path: row slabs per band (stitch + async all-gather each)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the N>1 code path (band halo exchange + slab all-gathers) even in a world of one rank")
     args = ap.parse_args()
 
     import torch
@@ -101,9 +104,11 @@ def main():
         sys.exit(3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     key, C_img, band_rows, W = WORKLOADS[args.workload]
     band_rows = args.band_rows or band_rows
@@ -123,18 +128,18 @@ def main():
     pa, pb = sharding.band_partition(npr, world)[rank]
     r0, r1 = sharding.needed_image_rows(pa, pb, sub, margin, hp.imSize, H)
     band = synth_rows(torch, C_img, r0, max(r1 - r0, 1), W, dev)   # resident in HBM before the timed region
-    out_full = torch.empty((hp.nClasses, H, W), dtype=torch.float16, device=dev) if world == 1 else None
+    out_full = torch.empty((hp.nClasses, H, W), dtype=torch.float16, device=dev) if not sharded else None
 
     def step():
-        if world == 1:
+        if not sharded:
             eng.infer_image_dev(band.data_ptr(), C_img, H, W, mean, std, umx.MODE_ACCUMULATE, umx.STITCH_FP16_COMPAT,
                                 out_full.data_ptr())
             return out_full
         return sharding.infer_image_sharded(eng, band, r0, H, W, mean, std, umx.MODE_ACCUMULATE,
-                                            umx.STITCH_FP16_COMPAT)
+                                            umx.STITCH_FP16_COMPAT, nslabs=args.slabs)
 
     def fence():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -203,14 +208,14 @@ def main():
             "config": {"workload": "%s: %s hp (%s graph, seeded weights), %d-channel synthetic slide %dx%d, "
                                    "%d tiles/step, batch %d, fp16-compat stitch%s" % (
                                        args.workload, key, "v2" if hp.graph else "legacy", C_img, H, W, tiles_total,
-                                       args.batch, ", band halo exchange + RCCL all-gather" if world > 1 else ""),
+                                       args.batch, ", band halo exchange + slab-wise RCCL all-gather" if sharded else ""),
                        "tiles_per_step": tiles_total, "slide": [H, W], "flop_per_tile_as_written": hp.flops_per_tile(),
                        "flop_per_tile_executed_unpadded": umx.describe(hp)["flops_per_tile"], "checksum": checksum},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     eng.close()
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

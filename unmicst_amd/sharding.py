@@ -98,7 +98,7 @@ def slab_rows(pa: int, pb: int, npr: int, sub: int, margin: int, H: int, n: int,
 
 
 def infer_image_sharded(eng, d_band, band_row0: int, H: int, W: int, mean: float, std: float, mode: int, stitch: int,
-                        group=None, gather: bool = True, nslabs: int = 4):
+                        group=None, gather: bool = True, nslabs: int = 2):
     """Distributed whole-slide inference.  Every rank calls this with the image rows it holds.
 
     d_band: float64 tensor [C, band_rows, W] = image rows [band_row0, band_row0+band_rows) (must cover
