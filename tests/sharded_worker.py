@@ -81,7 +81,7 @@ def main():
     pa, pb = sharding.band_partition(npr, world)[rank]
     r0, r1 = sharding.needed_image_rows(pa, pb, sub, m, hp.imSize, H)
     band = torch.from_numpy(np.ascontiguousarray(img[:, r0:max(r1, r0 + 1)]))   # each rank holds ONLY its rows
-    full = sharding.infer_image_sharded(eng, band, r0, H, W, 0.2, 0.2, 0, 0)
+    full = sharding.infer_image_sharded(eng, band, r0, H, W, 0.2, 0.2, 0, 0, nslabs=4)   # clamped to the smallest band
     np.save("%s.rank%d.npy" % (out_path, rank), full.numpy())
     dist.barrier()
     dist.destroy_process_group()
