@@ -275,6 +275,14 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
             // channels -- 4*NT of them in this lane, the rest in the lanes li+16, li+32, li+48 -- BN affine, softmax
             const int K = p.head_K;
             const float* const hsb = ec + (4 + K) * (NT * 16);   // [scale x 8 | bias x 8]
+            // sum over the 4 lane groups holding one pixel's channels (lanes li, li+16, li+32, li+48).  ds_bpermute based:
+            // v_permlane16/32_swap would avoid the LDS crossbar, but on ROCm 7.2 the builtin's second result came back
+            // equal to the first when both operands are the same value (probed on MI355X), so it is not used.
+            auto sum4 = [](float x) {
+                x += __shfl_xor(x, 16);
+                return x + __shfl_xor(x, 32);
+            };
+            float mine[4] = {0.f, 0.f, 0.f, 0.f};   // logits of the pixel this lane finishes: pixel li of M-tile q
 #pragma unroll
             for (int m = 0; m < KMT; ++m) {
                 float lg[4] = {0.f, 0.f, 0.f, 0.f};
@@ -290,32 +298,35 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (k < K) {
-                        lg[k] += __shfl_xor(lg[k], 16);
-                        lg[k] += __shfl_xor(lg[k], 32);
+                        const float t = sum4(lg[k]);
+                        if ((m & 3) == q) mine[k] = t;
                     }
-                const int t = wave * KMT + m;
-                const int ig = t >> p.th_log2, ty = t & (TH - 1);
-                const int img = img0 + ig * p.nimg_m + (li >> p.twm_log2);
-                if (q == 0 && img < p.B) {
-                    float mx = -INFINITY;
+                if ((m & 3) == 3 || m == KMT - 1) {   // every lane group finishes one of the last (up to) 4 M-tiles
+                    const int mq = (m & ~3) + q;
+                    const int t = wave * KMT + mq;
+                    const int ig = t >> p.th_log2, ty = t & (TH - 1);
+                    const int img = img0 + ig * p.nimg_m + (li >> p.twm_log2);
+                    if (mq < KMT && img < p.B) {
+                        float mx = -INFINITY;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (k < K) {
-                            lg[k] = lg[k] * hsb[k] + hsb[8 + k];
-                            mx = fmaxf(mx, lg[k]);
-                        }
-                    float sum = 0.f;
+                        for (int k = 0; k < 4; ++k)
+                            if (k < K) {
+                                mine[k] = mine[k] * hsb[k] + hsb[8 + k];
+                                mx = fmaxf(mx, mine[k]);
+                            }
+                        float sum = 0.f;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (k < K) {
-                            lg[k] = expf(lg[k] - mx);
-                            sum += lg[k];
-                        }
-                    const float inv = 1.f / sum;
-                    float* const d = p.probs + ((long)(img * p.outH + y0 + ty) * p.outW + x0 + (li & (TWm - 1))) * K;
+                        for (int k = 0; k < 4; ++k)
+                            if (k < K) {
+                                mine[k] = expf(mine[k] - mx);
+                                sum += mine[k];
+                            }
+                        const float inv = 1.f / sum;
+                        float* const d = p.probs + ((long)(img * p.outH + y0 + ty) * p.outW + x0 + (li & (TWm - 1))) * K;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (k < K) d[k] = lg[k] * inv;
+                        for (int k = 0; k < 4; ++k)
+                            if (k < K) d[k] = mine[k] * inv;
+                    }
                 }
             }
             return;
