@@ -116,8 +116,6 @@ struct umx_ctx {
     int* d_flag = nullptr;      // binary16 range overflow flag
     uint4* d_zeros = nullptr;
     bool head_fused = false;
-    struct Step16 { int launch; int sub; };   // launch index (-1: input split) and sub-batch size (0: whole batch)
-    std::vector<Step16> plan16;
     Launch split_launch;
 };
 
@@ -952,28 +950,14 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
     return UMX_OK;
 }
 
-// Launch order of the split-precision plan.  Layers whose tensors are large per tile (the full-resolution ends of the
-// UNet) run as chains over sub-batches, so that a producer's output is still in the 256 MiB Infinity Cache when the next
-// layer reads it; the channel-heavy middle runs once over the whole batch (it needs the M extent to fill 256 CUs).
+// The split-precision plan: input split (unless the gather kernel already wrote the planes), then every launch once
+// over the whole batch.  (Running the full-resolution layers as chains over sub-batches, to keep producer -> consumer
+// tensors in the 256 MiB Infinity Cache, was measured slower at every sub-batch size -- DESIGN.md section 4.)
 int run_unet_f16(umx_ctx* ctx, const float* tiles, int n, float* probs) {
-    const int nl = (int)ctx->plan16.size();
-    int i = 0;
-    while (i < nl) {
-        int j = i;
-        const int sub = ctx->plan16[i].sub;
-        while (j < nl && ctx->plan16[j].sub == sub) ++j;
-        const int step = sub > 0 ? sub : n;
-        for (int k0 = 0; k0 < n; k0 += step) {
-            const int ns = std::min(step, n - k0);
-            for (int l = i; l < j; ++l) {
-                const int li = ctx->plan16[l].launch;
-                Launch& L = li < 0 ? ctx->split_launch : ctx->plan[li];
-                int rc = run_launch_f16(ctx, L, tiles, n, k0, ns, probs);
-                if (rc) return rc;
-            }
-        }
-        i = j;
-    }
+    int rc = run_launch_f16(ctx, ctx->split_launch, tiles, n, 0, n, probs);
+    if (rc) return rc;
+    for (auto& L : ctx->plan)
+        if ((rc = run_launch_f16(ctx, L, tiles, n, 0, n, probs))) return rc;
     if (ctx->prof && ctx->pending.size() > 4096) return prof_fold(ctx);
     return UMX_OK;
 }
@@ -1206,33 +1190,7 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
             }
         L.cp.pre_s = L.d_pre_s; L.cp.pre_b = L.d_pre_b; L.cp.post_s = L.d_post_s; L.cp.post_b = L.d_post_b;
     }
-    if (f16) {
-        // chains over sub-batches for the launches with large per-tile tensors (see run_unet_f16)
-        const char* e = getenv("UMX_CHAIN_MB");
-        const double budget = (e ? atof(e) : 0.0) * 1e6;         // bytes of one chained layer's tensors kept cache-resident
-        const double big = 2.0e6;                                 // per-tile bytes that make a layer "full-resolution"
-        c->split_launch.name = "input.split";
-        const Buffer& b0 = c->bufs[0];
-        c->split_launch.bytes = (double)b0.S * b0.S * (4.0 * b0.C + 4.0 * b0.Cs);
-        std::vector<double> bytes = {c->split_launch.bytes};
-        for (auto& L : c->plan) {
-            double t = L.head ? L.bytes : 4.0 * L.outH * L.outW * round_up(L.Cout, 8);
-            if (!L.head)
-                for (int gi = 0; gi < L.ngroups; ++gi) t += 4.0 * L.H * L.W * round_up(L.g[gi].C, 8);
-            bytes.push_back(t);
-        }
-        const int nl = (int)bytes.size();
-        for (int i = 0; i < nl;) {
-            int j = i;
-            const bool hr = budget > 0 && bytes[i] >= big;
-            double mx = 0;
-            while (j < nl && (budget > 0 && bytes[j] >= big) == hr) { mx = std::max(mx, bytes[j]); ++j; }
-            int sub = 0;
-            if (hr && j - i >= 2) sub = std::max(1, (int)(budget / mx));
-            for (int l = i; l < j; ++l) c->plan16.push_back({l - 1, sub});
-            i = j;
-        }
-    }
+    if (f16) c->split_launch.name = "input.split";
     *out = ctx.release();
     return UMX_OK;
 }
