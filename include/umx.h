@@ -127,6 +127,16 @@ UMX_API int umx_infer_image(umx_ctx* ctx, const double* image_host, int C_img, i
 UMX_API int umx_infer_image_dev(umx_ctx* ctx, const double* image_dev, int C_img, int H, int W, double mean, double std,
                         int mode, int stitch, void* out_dev);
 
+/* The drivers' whole pre/post-processing around singleImageInference at --scalingFactor 1 and --outlier -1 (reference
+ * UnMicst1-5.py:807-821 and :848-854; UnMicst2.py:771-788,813-817; UnMicst.py:618-633,654-656), fused with the path:
+ *   raw [C_img,H,W] uint8 (bits 8) or uint16 (bits 16)  ->  float64 in [0,1] (skimage's resize at the identity grid:
+ *   multiply by 1/255 or 1/65535)  ->  rescale != 0: rescale_intensity(in (min,max) of the plane, out (0, 0.983)) per
+ *   plane (legacy / duo / cyto feed this; solo feeds the un-rescaled plane, rescale == 0)  ->  umx_infer_image (fp16-compat
+ *   stitch)  ->  uint8(255 * pm) -> resize (identity) -> uint8(255 * .): out [nClasses,H,W] uint8.
+ * Bit-identical to the host-side recipe (unmicst_amd/driver.py); saves the float64 upload and the fp16 download. */
+UMX_API int umx_infer_image_raw(umx_ctx* ctx, const void* raw_host, int bits, int C_img, int H, int W, int rescale,
+                        double mean, double std, int mode, uint8_t* out_host);
+
 /* The two halves of umx_infer_image, exposed for band sharding across GPUs (one process per GPU):
  * umx_band_tiles_dev: PI2D.getPatch + normalise + UNet for patch rows [pr0,pr1) -> probs
  *   [(pr1-pr0)*patch_cols, P,P,K] float32.  image_dev holds image rows [band_row0, band_row0+band_rows) of the

@@ -142,6 +142,14 @@ class _OracleEngine:
                                                        "replace" if mode else "accumulate", k)
                          for k in range(self.hp.nClasses)])
 
+    def infer_image_raw(self, raw, rescale, mean, std, mode=0):
+        """Host restatement of umx_infer_image_raw (the GPU test checks the real one against the general host recipe)."""
+        planes = raw[None] if raw.ndim == 2 else raw
+        pre = [driver.preprocess(p, 1, -1)[1 if rescale else 0] for p in planes]
+        image = np.stack(pre) if raw.ndim == 3 else pre[0]
+        pm = self.infer_image(image, mean, std, mode)
+        return np.stack([imtools.to_uint8_via_resize(pm[k], pm.shape[1:]) for k in range(pm.shape[0])])
+
     def close(self):
         pass
 
@@ -182,6 +190,7 @@ def test_driver_end_to_end_with_oracle_engine(tmp_path, monkeypatch):
         assert np.array_equal(stack[page], exp)
     # solo quirk: the network sees the UN-rescaled image (UnMicst1-5.py:816-821); duo duplicates a single channel
     seen = {}
+    monkeypatch.setenv("UMX_NO_RAW_PATH", "1")          # general host-side recipe: the engine sees the float64 image
     monkeypatch.setattr(_OracleEngine, "infer_image",
                         lambda self, image, *a, **k: (seen.setdefault("img", np.array(image)),
                                                       np.zeros((3,) + image.shape[-2:], np.float16))[1])
@@ -194,3 +203,18 @@ def test_driver_end_to_end_with_oracle_engine(tmp_path, monkeypatch):
                                 str(tmp_path / "o3")])
     assert np.array_equal(seen.pop("img"), raw[crop] * (1.0 / 65535))
     assert os.path.exists(tmp_path / "o3" / "s.1_ContoursPM_1.tif")    # solo: stem = text before the LAST dot
+    # fast path (scalingFactor 1, default range): raw planes + the tool's rescale flag go to umx_infer_image_raw
+    monkeypatch.delenv("UMX_NO_RAW_PATH")
+    monkeypatch.setattr(_OracleEngine, "infer_image_raw",
+                        lambda self, r, rescale, *a, **k: (seen.setdefault("raw", (np.array(r), rescale)),
+                                                           np.zeros((3,) + r.shape[-2:], np.uint8))[1])
+    driver.run("unmicst-solo", [str(reg / "s.1.tif"), "--model", str(models / "nucleiDAPI"), "--outputPath",
+                                str(tmp_path / "o4")])
+    r, flag = seen.pop("raw")
+    assert r.dtype == np.uint16 and np.array_equal(r, raw[crop]) and flag is False
+    driver.run("unmicst-legacy", [str(reg / "s.tif"), "--model", str(models / "nucleiDAPI"), "--outputPath",
+                                  str(tmp_path / "o5")])
+    assert seen.pop("raw")[1] is True
+    driver.run("unmicst-legacy", [str(reg / "s.tif"), "--model", str(models / "nucleiDAPI"), "--outputPath",
+                                  str(tmp_path / "o6"), "--scalingFactor", "0.5"])     # not the fast path
+    assert "raw" not in seen and seen.pop("img").shape == (150, 160)

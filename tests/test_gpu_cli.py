@@ -92,3 +92,31 @@ def test_default_output_dir_and_scaling(workspace):
     # at full resolution is only loosely comparable with the golden, so this is a plumbing check
     assert np.corrcoef(cont[0].ravel().astype(float), g_nuc.ravel().astype(float))[0, 1] > 0.5
     assert nuc.shape == (832, 960)
+
+
+def test_raw_fast_path_is_bit_identical_to_the_host_recipe(workspace):
+    """umx_infer_image_raw (im2double, min/max, rescale_intensity, inference, double uint8 cast on the GPU) against the
+    general host-side recipe of the driver, for the rescaled (legacy/duo) and un-rescaled (solo quirk) inputs, uint16 and
+    uint8 planes."""
+    from unmicst_amd import imtools, umx
+    hp, blob, mean, std = helpers.load_nuclei_dapi()
+    raw16 = helpers.load_sample_105()[0][:400, :530]
+    raw8 = np.uint8(raw16 >> 8)
+    with umx.Engine(hp, blob, max_batch=32) as eng:
+        for raw in (raw16, raw8):
+            for rescale in (True, False):
+                got = eng.infer_image_raw(raw, rescale, mean, std)
+                resized, rescaled = driver.preprocess(raw, 1, -1)
+                pm = eng.infer_image(rescaled if rescale else resized, mean, std)
+                want = np.stack([imtools.to_uint8_via_resize(pm[k], raw.shape) for k in range(hp.nClasses)])
+                assert got.dtype == np.uint8 and np.array_equal(got, want), (raw.dtype, rescale)
+        # two planes (duo-style input) are rescaled independently
+        hp2 = helpers.small_hps()["v2_duo_like"]
+    blob2 = model.random_blob(hp2, seed=8)
+    two = np.stack([raw16[:90, :70], raw16[100:190, 200:270] // 3])
+    with umx.Engine(hp2, blob2, max_batch=8) as eng:
+        got = eng.infer_image_raw(two, True, 0.2, 0.2)
+        pre = np.stack([driver.preprocess(p, 1, -1)[1] for p in two])
+        pm = eng.infer_image(pre, 0.2, 0.2)
+        want = np.stack([imtools.to_uint8_via_resize(pm[k], two.shape[1:]) for k in range(hp2.nClasses)])
+        assert np.array_equal(got, want)

@@ -1364,6 +1364,33 @@ int umx_infer_image(umx_ctx* ctx, const double* image_host, int C_img, int H, in
     return check_range_flag(ctx);
 }
 
+int umx_infer_image_raw(umx_ctx* ctx, const void* raw_host, int bits, int C_img, int H, int W, int rescale, double mean,
+                        double stdv, int mode, uint8_t* out_host) {
+    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    if (!raw_host || !out_host || H < 1 || W < 1 || C_img < 1) return fail(ctx, UMX_ERR_INVALID, "bad image/out/H/W");
+    if (bits != 8 && bits != 16) return fail(ctx, UMX_ERR_INVALID, "raw planes must be uint8 or uint16 (bits = %d)", bits);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t plane = (size_t)H * W, npx = plane * C_img;
+    const size_t raw_b = npx * (bits / 8), img_b = npx * sizeof(double);
+    const size_t K = ctx->hp.nClasses, pm_b = K * plane * 2, u8_b = K * plane;
+    int rc;
+    if ((rc = grow(ctx, (void**)&ctx->d_image, &ctx->image_cap, img_b))) return rc;
+    // one scratch buffer: [fp16 planes | uint8 planes | raw upload | min/max words]
+    const size_t raw_off = (pm_b + u8_b + 255) & ~(size_t)255, mm_off = (raw_off + raw_b + 255) & ~(size_t)255;
+    if ((rc = grow(ctx, &ctx->d_out, &ctx->out_cap, mm_off + 64 * (size_t)C_img))) return rc;
+    unsigned char* const base = (unsigned char*)ctx->d_out;
+    HIP_TRY(ctx, hipMemcpyAsync(base + raw_off, raw_host, raw_b, hipMemcpyHostToDevice, ctx->stream));
+    for (int c = 0; c < C_img; ++c)   // min/max and rescale are per plane (the drivers loop over channels)
+        HIP_TRY(ctx, launch_raw_to_double(base + raw_off + (size_t)c * plane * (bits / 8), bits, plane, rescale,
+                                          (unsigned*)(base + mm_off + 64 * (size_t)c), ctx->d_image + (size_t)c * plane,
+                                          ctx->stream));
+    if ((rc = umx_infer_image_dev(ctx, ctx->d_image, C_img, H, W, mean, stdv, mode, UMX_STITCH_FP16_COMPAT, base))) return rc;
+    HIP_TRY(ctx, launch_half_to_u8(base, K * plane, base + pm_b, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(out_host, base + pm_b, u8_b, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return check_range_flag(ctx);
+}
+
 int umx_profile_enable(umx_ctx* ctx, int on) {
     if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
     int rc = prof_fold(ctx);

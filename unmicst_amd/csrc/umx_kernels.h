@@ -132,6 +132,11 @@ hipError_t launch_head_softmax(const float* x, size_t npix, int C, int K, const 
 hipError_t launch_stitch(const float* probs, int tpr0, int tpr1, const TileGeom& g, int K, int mode, int stitch,
                          int y0, int y1, void* out, hipStream_t stream);
 
+// driver-side pre/post-processing at scalingFactor 1 (raw integer planes in, uint8 probability planes out)
+hipError_t launch_raw_to_double(const void* raw, int bits, size_t n, int rescale, unsigned* mm /*2 words*/, double* out,
+                                hipStream_t stream);
+hipError_t launch_half_to_u8(const void* pm_half, size_t n, unsigned char* out, hipStream_t stream);
+
 __host__ __device__ inline uint16_t double_to_half_rne(double d);
 
 }  // namespace umx

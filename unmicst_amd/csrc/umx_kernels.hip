@@ -539,4 +539,81 @@ hipError_t launch_stitch(const float* probs, int tpr0, int tpr1, const TileGeom&
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Driver-side pre/post-processing at --scalingFactor 1 (reference UnMicst1-5.py:807-821,848-854; toolbox/imtools.py:42-53):
+//   raw uint8/uint16 plane -> float64 in [0,1] (skimage's resize converts with a multiply by 1/max) -> optional
+//   rescale_intensity((min, max) -> (0, 0.983)); float16 probability plane -> uint8 by the reference's double cast.
+// Every operation is the same IEEE operation numpy performs, one rounding each (contraction is switched off), so the
+// results are bit-identical to the host path in unmicst_amd/driver.py.
+// ------------------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+
+template <typename T>
+__global__ void __launch_bounds__(256) minmax_kernel(const T* __restrict__ x, size_t n, unsigned* __restrict__ mm /*[min,max]*/) {
+    unsigned lo = 0xFFFFFFFFu, hi = 0u;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned v = x[i];
+        lo = min(lo, v);
+        hi = max(hi, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, (unsigned)__shfl_xor((int)lo, o));
+        hi = max(hi, (unsigned)__shfl_xor((int)hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&mm[0], lo);
+        atomicMax(&mm[1], hi);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) raw_to_double_kernel(const T* __restrict__ x, size_t n, double inv_max, int rescale,
+                                                           const unsigned* __restrict__ mm, double* __restrict__ out) {
+    const double lo = (double)mm[0] * inv_max, hi = (double)mm[1] * inv_max;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double v = (double)x[i] * inv_max;                    // np.multiply(I, 1.0 / imax)
+        if (rescale) {
+            if (lo != hi) v = ((v - lo) / (hi - lo)) * 0.983;   // (I - imin) / (imax - imin) * (omax - omin) + omin, omin = 0
+            else v = fmin(fmax(v, 0.0), 0.983);               // np.clip(I, omin, omax)
+        }
+        out[i] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) half_to_u8_kernel(const __half* __restrict__ pm, size_t n, unsigned char* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const __half p255 = __hmul(__float2half_rn(255.f), pm[i]);          // 255 * float16 -> float16 (numpy)
+        const unsigned char first = (unsigned char)(int)__half2float(p255);   // np.uint8: truncation
+        const double f = (double)first * (1.0 / 255);                       // resize at the identity grid: u8 * (1/255)
+        out[i] = (unsigned char)(int)(255.0 * f);                           // np.uint8(255 * PM)
+    }
+}
+
+hipError_t launch_raw_to_double(const void* raw, int bits, size_t n, int rescale, unsigned* mm, double* out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
+    const unsigned init[2] = {0xFFFFFFFFu, 0u};
+    hipError_t e = hipMemcpyAsync(mm, init, sizeof init, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    if (bits == 16) {
+        hipLaunchKernelGGL(minmax_kernel<unsigned short>, dim3(blocks), dim3(256), 0, stream, (const unsigned short*)raw, n, mm);
+        hipLaunchKernelGGL(raw_to_double_kernel<unsigned short>, dim3(blocks), dim3(256), 0, stream, (const unsigned short*)raw, n,
+                           1.0 / 65535, rescale, mm, out);
+    } else if (bits == 8) {
+        hipLaunchKernelGGL(minmax_kernel<unsigned char>, dim3(blocks), dim3(256), 0, stream, (const unsigned char*)raw, n, mm);
+        hipLaunchKernelGGL(raw_to_double_kernel<unsigned char>, dim3(blocks), dim3(256), 0, stream, (const unsigned char*)raw, n,
+                           1.0 / 255, rescale, mm, out);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_half_to_u8(const void* pm_half, size_t n, unsigned char* out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(half_to_u8_kernel, dim3(blocks), dim3(256), 0, stream, (const __half*)pm_half, n, out);
+    return hipGetLastError();
+}
+
 }  // namespace umx

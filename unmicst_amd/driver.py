@@ -143,14 +143,9 @@ def run(tool: str, argv=None, script_dir: str = None) -> int:
         parent = os.path.dirname(os.path.dirname(image_path))
         stem, file_type = split_name(os.path.basename(image_path), spec)
 
-        planes_in = []
-        raw = None
-        for ch in channels:
-            raw = read_plane(image_path, file_type, ch, spec)
-            resized, rescaled = preprocess(raw, args.scalingFactor, args.outlier)
-            planes_in.append(rescaled if spec.infer_rescaled else resized)
+        raws = [read_plane(image_path, file_type, ch, spec) for ch in channels]
+        raw = raws[-1]                        # the reference keeps the last plane read for the preview (rawI)
         raw_shape = raw.shape[:2]
-        cells = np.stack(planes_in) if spec.n_inputs == 2 else planes_in[0]
         class_order = range(n_class) if args.classOrder == -1 else args.classOrder
         rawI = imtools.im2double(raw)
         rawI = rawI / np.max(rawI)
@@ -162,8 +157,26 @@ def run(tool: str, argv=None, script_dir: str = None) -> int:
             os.makedirs(qc_dir, exist_ok=True)
         suffix = str(first + 1) if spec.suffix_plus_one else str(first)
 
-        def plane_u8(k):
-            return imtools.to_uint8_via_resize(UNet2D.singleImageInference(cells, "accumulate", k), raw_shape)
+        # fast path: at scalingFactor 1 with the default intensity range every pre/post-processing step is element-wise
+        # (+ one min/max), so it runs on the GPU next to the inference (umx_infer_image_raw) -- same bits, no float64
+        # upload / float16 download.  Anything else goes through the general host-side recipe.
+        fast = (float(args.scalingFactor) == 1.0 and args.outlier == -1 and all(r.dtype in (np.uint8, np.uint16) for r in raws)
+                and len({(r.shape, r.dtype) for r in raws}) == 1 and not os.environ.get("UMX_NO_RAW_PATH"))
+        if fast:
+            stack_raw = np.stack(raws) if spec.n_inputs == 2 else raws[0]
+            u8_planes = UNet2D.singleImageInferenceRaw(stack_raw, spec.infer_rescaled, "accumulate")
+
+            def plane_u8(k):
+                return u8_planes[k]
+        else:
+            planes_in = []
+            for r in raws:
+                resized, rescaled = preprocess(r, args.scalingFactor, args.outlier)
+                planes_in.append(rescaled if spec.infer_rescaled else resized)
+            cells = np.stack(planes_in) if spec.n_inputs == 2 else planes_in[0]
+
+            def plane_u8(k):
+                return imtools.to_uint8_via_resize(UNet2D.singleImageInference(cells, "accumulate", k), raw_shape)
 
         if args.stackOutput:
             stack = out_dir + "//" + stem + "_Probabilities_" + suffix + ".tif"

@@ -24,6 +24,7 @@ STITCH_FP16_COMPAT, STITCH_FP32 = 0, 1
 EXPORTS = [
     "umx_device_count", "umx_device_mem_info", "umx_create", "umx_create_opts", "umx_precision_of", "umx_destroy", "umx_last_error", "umx_set_stream", "umx_synchronize",
     "umx_forward_tiles", "umx_forward_tiles_dev", "umx_tile_grid", "umx_infer_image", "umx_infer_image_dev",
+    "umx_infer_image_raw",
     "umx_band_tiles_dev", "umx_stitch_dev", "umx_profile_enable", "umx_profile_read", "umx_test_double_to_half",
     "umx_describe", "umx_version",
 ]
@@ -118,6 +119,9 @@ def load(path: Optional[str] = None):
     L.umx_tile_grid.argtypes = [c_void_p, c_int, c_int, ip, ip, ip, ip]
     L.umx_infer_image.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_int, c_int, c_void_p]
     L.umx_infer_image_dev.argtypes = L.umx_infer_image.argtypes
+    L.umx_infer_image_raw.restype = c_int
+    L.umx_infer_image_raw.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_int,
+                                      c_void_p]
     L.umx_band_tiles_dev.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_double,
                                      c_int, c_int, c_void_p]
     L.umx_stitch_dev.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
@@ -256,6 +260,23 @@ class Engine:
         out = np.empty((self.hp.nClasses, H, W), np.float32 if stitch == STITCH_FP32 else np.float16)
         self._check(self._L.umx_infer_image(self._ctx, image.ctypes.data, C, H, W, float(mean), float(std), int(mode),
                                             int(stitch), out.ctypes.data))
+        return out
+
+    def infer_image_raw(self, raw: np.ndarray, rescale: bool, mean: float, std: float,
+                        mode: int = MODE_ACCUMULATE) -> np.ndarray:
+        """Driver fast path at scalingFactor 1: raw uint8/uint16 (H,W) or (C,H,W) -> uint8 [K,H,W] (see include/umx.h)."""
+        raw = np.ascontiguousarray(raw)
+        if raw.dtype not in (np.uint8, np.uint16):
+            raise TypeError("raw planes must be uint8 or uint16")
+        if raw.ndim == 2:
+            raw = raw[None]
+        if raw.ndim != 3:
+            raise ValueError("raw must be (H,W) or (C,H,W)")
+        C, H, W = raw.shape
+        raw = raw.astype(raw.dtype.newbyteorder("="), copy=False)
+        out = np.empty((self.hp.nClasses, H, W), np.uint8)
+        self._check(self._L.umx_infer_image_raw(self._ctx, raw.ctypes.data, raw.dtype.itemsize * 8, C, H, W,
+                                                1 if rescale else 0, float(mean), float(std), int(mode), out.ctypes.data))
         return out
 
     # -- device-pointer API (pointers are plain ints, e.g. torch.Tensor.data_ptr())

@@ -102,6 +102,22 @@ class UNet2D:
         return UNet2D.Engine.infer_image(image, UNet2D.DatasetMean, UNet2D.DatasetStDev, m, UNet2D.stitch)
 
     @staticmethod
+    def singleImageInferenceRaw(raw, rescale, mode="accumulate"):
+        """Driver fast path (``--scalingFactor 1``, ``--outlier -1``): raw uint8/uint16 plane(s) -> uint8 class planes
+        [nClasses, H, W], with the drivers' im2double / rescale_intensity / double uint8 cast done on the GPU
+        (reference UnMicst1-5.py:807-821,848-854).  ``rescale`` False reproduces solo's un-rescaled input."""
+        if UNet2D.Engine is None:
+            raise RuntimeError("call UNet2D.singleImageInferenceSetup first")
+        if mode not in ("accumulate", "replace"):
+            raise ValueError("mode must be 'accumulate' or 'replace'")
+        print("Inference...")
+        raw = np.asarray(raw)
+        if raw.ndim == 3 and raw.shape[0] != UNet2D.hparams.nChannels:
+            raise ValueError("image has %d planes, the model takes %d channels" % (raw.shape[0], UNet2D.hparams.nChannels))
+        m = _umx.MODE_ACCUMULATE if mode == "accumulate" else _umx.MODE_REPLACE
+        return UNet2D.Engine.infer_image_raw(raw, bool(rescale), UNet2D.DatasetMean, UNet2D.DatasetStDev, m)
+
+    @staticmethod
     def _pass_key(image, mode):
         a = np.asarray(image)
         flat = a.reshape(-1)
