@@ -6,9 +6,9 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # repo root
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # (this file lives in tests/: the oracle may only be used from there)
 
 import helpers  # noqa: E402
 from oracle import oracle, pi2d_oracle  # noqa: E402
