@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     const HPhase& ph = p.ph[NPH == 1 ? blockIdx.z : 0];
     // diagnostic stamps (shader-clock cycles), wave 0 only: [0] prologue, [1] waiting for loads + barriers, [2] MFMA
     // blocks, [3] epilogue, [4] whole kernel
-    long long t_in = 0, t_wait = 0, t_comp = 0, t_a = 0, t_b = 0, t_vm = 0;
+    long long t_in = 0, t_wait = 0, t_comp = 0, t_a = 0, t_b = 0, t_vm = 0, t_iss = 0;
     if (p.dbg) t_in = __builtin_amdgcn_s_memtime();
     // ---- halo slot -> source pixel, fixed for the whole kernel: slot e = c*64 + lane
     const int nch = (p.nhalo + 63) >> 6;
@@ -157,6 +157,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
         if (p.dbg) { t_b = __builtin_amdgcn_s_memtime(); t_wait += t_b - t_a; }
         if (s + 1 < ph.nstages) issue(nxt, (s + 1) & 1);
         else issue_econst((s + 1) & 1);
+        if (p.dbg) t_iss += (long long)__builtin_amdgcn_s_memtime() - t_b;
 
         const unsigned char* const wl = Bl + (s & 1) * p.wbuf_bytes;
         // k-map of the stage up front: one LDS round trip per stage instead of one on every k-step's critical path
@@ -200,16 +201,16 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
         if (p.dbg) { t_a = __builtin_amdgcn_s_memtime(); t_comp += t_a - t_b; }
     }
     struct DbgOut {   // written when the kernel returns (both epilogue paths)
-        const HConvParams& p; long long t_in, t_pro, t_wait, t_comp, t_epi; int tid; const long long& t_vm;
+        const HConvParams& p; long long t_in, t_pro, t_wait, t_comp, t_epi; int tid; const long long& t_vm; const long long& t_iss;
         __device__ ~DbgOut() {
             if (p.dbg && tid == 0) {
                 const long long t_end = __builtin_amdgcn_s_memtime();
                 const size_t w = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-                long long* d = p.dbg + w * 6;
-                d[0] = t_pro - t_in; d[1] = t_wait; d[2] = t_comp; d[3] = t_end - t_epi; d[4] = t_end - t_in; d[5] = t_vm;
+                long long* d = p.dbg + w * 7;
+                d[0] = t_pro - t_in; d[1] = t_wait; d[2] = t_comp; d[3] = t_end - t_epi; d[4] = t_end - t_in; d[5] = t_vm; d[6] = t_iss;
             }
         }
-    } dbg_out{p, t_in, t_pro, t_wait, t_comp, p.dbg ? (long long)__builtin_amdgcn_s_memtime() : 0, tid, t_vm};
+    } dbg_out{p, t_in, t_pro, t_wait, t_comp, p.dbg ? (long long)__builtin_amdgcn_s_memtime() : 0, tid, t_vm, t_iss};
 
     // ---- epilogue: (acc * pre_s + pre_b) -> activation -> (* post_s + post_b, output shift folded in) -> [2x2 max-pool]
     //      -> (hi, lo) binary16 NHWC, or fp32 NHWC for the tensor the softmax head reads.

@@ -929,19 +929,19 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
         if (dbg_layer && L.name == dbg_layer) {
             const size_t nwg = (size_t)((ns + p.imgs - 1) / p.imgs) * p.tiles_y * p.tiles_x * p.nblocks * p.nphase;
             long long* d = nullptr;
-            HIP_TRY(ctx, hipMalloc((void**)&d, nwg * 6 * sizeof(long long)));
+            HIP_TRY(ctx, hipMalloc((void**)&d, nwg * 7 * sizeof(long long)));
             p.dbg = d;
             HIP_TRY(ctx, launch_conv_f16(p, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            std::vector<long long> hst(nwg * 6);
+            std::vector<long long> hst(nwg * 7);
             HIP_TRY(ctx, hipMemcpy(hst.data(), d, hst.size() * sizeof(long long), hipMemcpyDeviceToHost));
             hipFree(d);
-            double m[6] = {0, 0, 0, 0, 0, 0};
+            double m[7] = {0, 0, 0, 0, 0, 0, 0};
             for (size_t w = 0; w < nwg; ++w)
-                for (int k = 0; k < 6; ++k) m[k] += (double)hst[w * 6 + k] / nwg;
+                for (int k = 0; k < 7; ++k) m[k] += (double)hst[w * 7 + k] / nwg;
             fprintf(stderr, "[umx stamps] %s: %zu workgroups, LDS %d B, wbuf %d B | shader cycles: prologue %.0f, stage waits %.0f "
-                            "(own loads %.0f, barrier %.0f), MFMA blocks %.0f, epilogue %.0f, total %.0f\n", L.name.c_str(), nwg,
-                    p.lds_bytes, p.wbuf_bytes, m[0], m[1], m[5], m[1] - m[5], m[2], m[3], m[4]);
+                            "(own loads %.0f, barrier %.0f), issuing the next stage's loads %.0f, MFMA blocks %.0f, epilogue %.0f, total %.0f\n",
+                    L.name.c_str(), nwg, p.lds_bytes, p.wbuf_bytes, m[0], m[1], m[5], m[1] - m[5], m[6], m[2] - m[6], m[3], m[4]);
             return UMX_OK;
         }
     }
