@@ -324,9 +324,14 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
                             }
                         const float inv = 1.f / sum;
                         float* const d = p.probs + ((long)(img * p.outH + y0 + ty) * p.outW + x0 + (li & (TWm - 1))) * K;
+                        if (K == 3) {   // one 12-byte store per pixel instead of three 4-byte ones
+                            struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
+                            *reinterpret_cast<F3*>(d) = F3{mine[0] * inv, mine[1] * inv, mine[2] * inv};
+                        } else {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (k < K) d[k] = mine[k] * inv;
+                            for (int k = 0; k < 4; ++k)
+                                if (k < K) d[k] = mine[k] * inv;
+                        }
                     }
                 }
             }
