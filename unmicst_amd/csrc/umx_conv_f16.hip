@@ -11,9 +11,9 @@
 //   weights      pre-packed on the host in the exact LDS image order, per (phase, N-block): for every stage, for every
 //                k-step, for every 16-wide N-tile: a hi image then a lo image of [64 lanes][8 halves] -- so staging is a
 //                linear copy and a lane's B-fragment read is base + lane*16 (conflict-free ds_read_b128).
-//   LDS          input halo, octet-planar: plane[octet][halo pixel] of 16-byte slots, hi planes then lo planes (an
-//                A-fragment read = 16 consecutive pixels of one plane per 16-lane group: conflict-free when the four
-//                groups read four planes at the same tap); then the stage's weight images.
+//   LDS          input halo, pixel-major: [halo pixel][OC octets] of 16-byte slots (OC odd: an activation-fragment read of
+//                16 consecutive pixels at one octet is conflict-free), a hi image then a lo image per halo slot, two
+//                slots; then the two weight buffers.
 // Staging is LDS-DMA (global_load_lds_dwordx4: no staging VGPRs) in a two-deep pipeline: two weight buffers and two halo
 // slots, the loads of stage s+1 in flight under the MFMAs of stage s, one barrier per stage; 2-3 workgroups per CU.  A k-step is any 4 (tap, octet) pairs (table built on the host), so channel counts
 // only need to be multiples of 8, not 32.
@@ -57,34 +57,13 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     // blocks, [3] epilogue, [4] whole kernel
     long long t_in = 0, t_wait = 0, t_comp = 0, t_a = 0, t_b = 0, t_vm = 0, t_iss = 0;
     if (p.dbg) t_in = __builtin_amdgcn_s_memtime();
-    // ---- halo slot -> source pixel, fixed for the whole kernel: slot e = c*64 + lane
-    const int nch = (p.nhalo + 63) >> 6;
-    int hsrc[kHaloChunks];   // >= 0: pixel index (img*H + y)*W + x;  -1: outside the image (zeros);  -2: no such slot
-#pragma unroll
-    for (int c = 0; c < kHaloChunks; ++c) {
-        int v = -2;
-        if (c < nch) {   // wave-uniform: unused chunks cost nothing
-            const int e = c * 64 + lane;
-            if (e < p.nhalo) {
-                // e < 1024: the float quotients are exact after truncation (error ~1e-4 << 0.5 / divisor)
-                const int il = (int)(((float)e + 0.5f) * p.inv_imgplane);
-                const int r = e - il * p.imgplane;
-                const int hy = (int)(((float)r + 0.5f) * p.inv_hw);
-                const int hx = r - hy * p.hw;
-                const int gy = y0 + p.ymin + hy, gx = x0 + p.xmin + hx, img = img0 + il;
-                v = (img < p.B && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? (img * p.H + gy) * p.W + gx : -1;
-            }
-        }
-        hsrc[c] = v;
-    }
-
     // ---- per-lane A-fragment pixel offsets (bytes) of this wave's M-tiles
     int abase[KMT];
 #pragma unroll
     for (int m = 0; m < KMT; ++m) {
         const int t = wave * KMT + m;
         const int ig = t >> p.th_log2, ty = t & (TH - 1);
-        abase[m] = ((ig * p.nimg_m + (li >> p.twm_log2)) * p.imgplane + ty * p.hw + (li & (TWm - 1))) << 4;
+        abase[m] = ((ig * p.nimg_m + (li >> p.twm_log2)) * p.imgplane + ty * p.hw + (li & (TWm - 1))) * p.pix_bytes;
     }
 
     f32x4 accs[NPH][KMT][NT];
@@ -95,7 +74,6 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) accs[h][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int plane_bytes = p.plane_slots << 4;
     const int lo_off = p.lo_off;   // byte offset of the lo planes
     unsigned char* const Bl = smem + p.b_off;
     const uint4* const wbase = ph.w + (size_t)nblk * ph.wblk_stride;
@@ -105,21 +83,35 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     // One barrier per stage: it orders "everyone's loads of stage s have landed" (each wave waits for its own first)
     // and "everyone is done computing stage s-1" (so the buffers stage s+1 loads into are free).
     auto issue = [&](const HStage& st, int buf) {
-        if (st.group >= 0) {   // halo chunk: octets [oct0, oct0+noct) of operand group `group` -> planes plane0..
+        if (st.group >= 0) {
+            // Halo chunk: octets [oct0, oct0+noct) of operand group `group` into halo slot `plane0` (0/1).  The LDS image is
+            // pixel-major -- [halo pixel][OC octets], 16-byte slots -- so consecutive lanes of a wave-instruction fetch
+            // consecutive octets of one pixel and then the next pixel: whole channel vectors (64..144 contiguous bytes,
+            // contiguous across the pixels of a halo row when the chunk is the whole tensor) instead of 64 scattered
+            // 16-byte pieces.  An odd OC keeps the fragment reads of 16 consecutive pixels conflict-free.
             const int g = st.group;
             const _Float16* const shi = p.src_hi[g];
             const _Float16* const slo = p.src_lo[g];
             const int Cs = p.Cs[g];
-            for (int t = wave; t < st.noct * 2; t += kWaves) {   // one (plane, hi|lo) per iteration, wave-uniform
-                const int pl = t >> 1;
-                const _Float16* const sb = ((t & 1) ? slo : shi) + (st.oct0 + pl) * 8;
-                unsigned char* const dst = smem + ((t & 1) ? lo_off : 0) + (st.plane0 + pl) * plane_bytes;
-#pragma unroll
-                for (int c = 0; c < kHaloChunks; ++c) {
-                    if (c < nch && hsrc[c] != -2) {
-                        const void* src = hsrc[c] >= 0 ? (const void*)(sb + (size_t)hsrc[c] * Cs) : (const void*)p.zeros;
-                        UMX_GLDS16(src, dst + c * 1024);
-                    }
+            const int nslots = p.nhalo * p.OC;                       // 16-byte slots of one plane (hi or lo) of a chunk
+            const int ninst = (nslots + 63) >> 6;
+            unsigned char* const slot = smem + st.plane0 * p.slot_bytes;
+            for (int t = wave; t < 2 * ninst; t += kWaves) {        // (instruction, hi|lo) pairs, wave-uniform
+                const int half = t & 1, idx = t >> 1;
+                const int sl = idx * 64 + lane;
+                const int px = (int)(((float)sl + 0.5f) * p.inv_OC);   // sl < 9216: exact after truncation
+                const int k = sl - px * p.OC;
+                if (sl < nslots && k < st.noct) {
+                    const int il = (int)(((float)px + 0.5f) * p.inv_imgplane);
+                    const int r = px - il * p.imgplane;
+                    const int hy = (int)(((float)r + 0.5f) * p.inv_hw);
+                    const int hx = r - hy * p.hw;
+                    const int gy = y0 + p.ymin + hy, gx = x0 + p.xmin + hx, img = img0 + il;
+                    const bool inside = img < p.B && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                    const _Float16* const sb = half ? slo : shi;
+                    const void* src = inside ? (const void*)(sb + ((size_t)(img * p.H + gy) * p.W + gx) * Cs + (st.oct0 + k) * 8)
+                                             : (const void*)p.zeros;
+                    UMX_GLDS16(src, slot + (half ? lo_off : 0) + idx * 1024);
                 }
             }
         }

@@ -616,10 +616,10 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     // pair count is not a multiple of 4 are carried into the first k-step of the next chunk instead of being padded:
     // the previous chunk's halo slot is still resident then (its reload is issued at the start of the next chunk's LAST
     // stage, so the next chunk must have >= 2 stages).  Not across the phases of the fused kernel (other accumulators).
-    struct Pair { int gi, ph, tap, oct, plane; };
+    struct Pair { int gi, ph, tap, oct, slot, k; };   // slot: halo slot (0/1) of the chunk; k: octet inside the chunk
     const bool carry_ok = !fused && !getenv("UMX_NO_KSTEP_CARRY");
     auto npairs_of = [&](const Chunk& k, int ph) { return (int)L.g[k.gi].taps[ph].size() * (k.o1 - k.o0); };
-    auto plan_list = [&](int OC, int S, int E, int list, std::vector<HStage>* stages_out,
+    auto plan_list = [&](int OC, int S, int list, std::vector<HStage>* stages_out,
                          std::vector<std::vector<Pair>>* steps_out, int* nchunks) {
         const auto pr = phases_of(list);
         const auto ch = chunks_for(OC, fused ? -1 : list);
@@ -628,7 +628,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         std::vector<Pair> carry;
         for (size_t c = 0; c < ch.size(); ++c) {
             const int gi = ch[c].gi, o0 = ch[c].o0, o1 = ch[c].o1;
-            const int plane0 = (c & 1) ? E : 0;
+            const int slot = (int)(c & 1);   // consecutive chunks alternate between the two halo slots
             bool first = true;   // the chunk's first stage carries its halo load
             for (int ph = pr.first; ph < pr.second; ++ph) {
                 const int nt = (int)L.g[gi].taps[ph].size();
@@ -636,7 +636,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                 std::vector<Pair> pairs = carry;
                 carry.clear();
                 for (int t = 0; t < nt; ++t)
-                    for (int o = o0; o < o1; ++o) pairs.push_back({gi, ph, t, o, plane0 + o - o0});
+                    for (int o = o0; o < o1; ++o) pairs.push_back({gi, ph, t, o, slot, o - o0});
                 const int rem = (int)pairs.size() % 4;
                 if (rem && carry_ok && c + 1 < ch.size() && (int)pairs.size() >= 4) {
                     // stages the next chunk will have if it takes the remainder (it pads or carries on in turn)
@@ -646,7 +646,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                         pairs.resize(pairs.size() - rem);
                     }
                 }
-                while (pairs.size() % 4) pairs.push_back({gi, ph, -1, o0, plane0});   // zero-weight filler on a loaded slot
+                while (pairs.size() % 4) pairs.push_back({gi, ph, -1, o0, slot, 0});   // zero-weight filler on a loaded slot
                 const int nk_chunk = (int)pairs.size() / 4;
                 nsteps += nk_chunk;
                 for (int k = 0; k < nk_chunk; k += S) {
@@ -656,7 +656,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                     first = false;
                     st.oct0 = (short)o0;
                     st.noct = (short)(o1 - o0);
-                    st.plane0 = (short)plane0;
+                    st.plane0 = (short)slot;
                     st.phase = (short)ph;
                     st.nk = (short)std::min(S, nk_chunk - k);
                     if (steps_out)
@@ -669,32 +669,41 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         return nsteps;
     };
 
-    int bestOC = 0, bestS = 0, bestE = 0, bestO = 0;
+    // (OC, S) search.  OC = octets per staged pixel (pixel pitch OC*16 B in the LDS image).  Odd OC maps 16 consecutive pixels
+    // at one octet to 16 distinct 16-byte bank groups (conflict-free fragment reads); even OC costs 2- to 4-way conflicts
+    // on those reads, which the kernels tolerate (LDS reads are not their limit) -- a mild penalty only.
+    int bestOC = 0, bestS = 0, bestSlots = 1;
     double bestCost = 1e30;
     for (int OC = 1; OC <= 9; ++OC) {
-        int E = 0, O = 0;
+        int nslots = 1;
+        double sectors = 0;   // 64-byte memory requests of the halo loads of one workgroup
         for (int list = 0; list < nlists; ++list) {
             const auto ch = chunks_for(OC, fused ? -1 : list);
-            for (size_t c = 0; c < ch.size(); ++c) ((c & 1) ? O : E) = std::max((c & 1) ? O : E, ch[c].o1 - ch[c].o0);
+            if (ch.size() >= 2) nslots = 2;
+            for (const auto& c : ch) sectors += 2.0 * h.nhalo * ((c.o1 - c.o0 + 3) / 4);
         }
         for (int S = 1; S <= kStageK; ++S) {
-            const int lds = (E + O) * plane_pair + 2 * (64 + S * nt16 * 2048);
+            const int lds = nslots * OC * plane_pair + 2 * (64 + S * nt16 * 2048);
             if (lds > lds_cap) continue;
             int ksteps = 0, nchunks = 0;
             for (int list = 0; list < nlists; ++list) {
                 int nc = 0;
-                ksteps += plan_list(OC, S, E, list, nullptr, nullptr, &nc);
+                ksteps += plan_list(OC, S, list, nullptr, nullptr, &nc);
                 nchunks += nc;
             }
-            // executed k-steps (exact), a barrier/latency charge per stage, a charge per halo chunk load (measured
-            // ~0.35 k-steps on the deep layers), slight preference for the conflict-free OC = 4
-            const double cost = (ksteps * (1.0 + 0.30 / S) + 0.35 * nchunks) * (OC == 4 ? 0.98 : 1.0);
-            if (cost < bestCost) { bestCost = cost; bestOC = OC; bestS = S; bestE = E; bestO = O; }
+            // executed k-steps (exact) with a barrier/latency charge per stage, a charge per halo chunk load (measured
+            // ~0.35 k-steps on the deep layers) and per 64-byte halo request (halo reloads measured at 8-22 % of a layer)
+            const double cost = (ksteps * (1.0 + 0.30 / S) + 0.35 * nchunks + sectors / 1500.0) * ((OC & 1) ? 1.0 : 1.03);
+            if (cost < bestCost) { bestCost = cost; bestOC = OC; bestS = S; bestSlots = nslots; }
         }
     }
     if (!bestOC) { *why = "LDS footprint too large for the split-precision kernel"; return UMX_ERR_INVALID; }
     const int OC = bestOC, S = bestS;
-    h.lo_off = (bestE + bestO) * h.plane_slots * 16;
+    h.OC = OC;
+    h.inv_OC = 1.f / (float)OC;
+    h.pix_bytes = OC * 16;
+    h.slot_bytes = h.plane_slots * OC * 16;
+    h.lo_off = bestSlots * h.slot_bytes;
     h.b_off = 2 * h.lo_off;
     h.wbuf_bytes = 64 + S * nt16 * 2048;
     h.lds_bytes = std::max(h.b_off + 2 * h.wbuf_bytes, epi_bytes);
@@ -708,7 +717,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         h.ph[list].ox_off = L.ox_off[list];
         h.ph[list].stage0 = (int)stages.size();
         std::vector<std::vector<Pair>> steps;   // k-steps of this list, each 4 pairs (padded ones have tap = -1)
-        plan_list(OC, S, bestE, list, &stages, &steps, nullptr);
+        plan_list(OC, S, list, &stages, &steps, nullptr);
         h.ph[list].nstages = (int)stages.size() - h.ph[list].stage0;
         L.n_ksteps += (int)steps.size();
         // weight slab of one N-block: per stage a block = 64-byte header (k-map) + nk * NT * (hi, lo) images
@@ -729,8 +738,9 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                     for (int qq = 0; qq < 4; ++qq) {
                         const Pair& pr2 = steps[ks][qq];
                         const auto& tp = L.g[pr2.gi].taps[pr2.ph][pr2.tap < 0 ? 0 : pr2.tap];
-                        const int slot = pr2.plane * h.plane_slots + (tp.first - g.ymin) * h.hw + (tp.second - g.xmin);
-                        if (slot < 0 || slot >= (bestE + bestO) * h.plane_slots || slot > 65535) {
+                        // 16-byte LDS slot of (halo pixel at this tap, octet k) in the pixel-major image of halo slot `slot`
+                        const int slot = pr2.slot * (h.plane_slots * OC) + ((tp.first - g.ymin) * h.hw + (tp.second - g.xmin)) * OC + pr2.k;
+                        if (slot < 0 || slot >= bestSlots * h.plane_slots * OC || slot > 65535) {
                             *why = "internal: k-map slot out of range";
                             return UMX_ERR_INVALID;
                         }
@@ -793,8 +803,8 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         h.econst = reinterpret_cast<const uint4*>(d);
     }
     if (getenv("UMX_DEBUG_PLAN"))
-        fprintf(stderr, "[umx plan] %-12s %sNT %d x %d blocks, OC %d (slots %d+%d planes), S %d, LDS %d B, k-steps %d, wshift %d\n",
-                L.name.c_str(), fused ? "fused-phase " : "", nt16, h.nblocks, OC, bestE, bestO, S, h.lds_bytes, L.n_ksteps,
+        fprintf(stderr, "[umx plan] %-12s %sNT %d x %d blocks, OC %d x %d halo slot(s), S %d, LDS %d B, k-steps %d, wshift %d\n",
+                L.name.c_str(), fused ? "fused-phase " : "", nt16, h.nblocks, OC, bestSlots, S, h.lds_bytes, L.n_ksteps,
                 L.wshift);
     h.inv_imgplane = 1.f / (float)h.imgplane;
     h.inv_hw = 1.f / (float)h.hw;

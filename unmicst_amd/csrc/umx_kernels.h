@@ -64,7 +64,7 @@ struct HStage {      // one pipeline stage: optional halo chunk load + one weigh
     short oct0;      // first octet (8 channels) of that group to load ...
     short noct;      // ... and how many ...
     short nk;        // k-steps in this stage (<= kStageK)
-    short plane0;    // ... into LDS planes plane0 .. plane0+noct-1 (consecutive chunks alternate between two slots)
+    short plane0;    // ... into halo slot plane0 (0 or 1: consecutive chunks alternate between the two slots)
     short phase;     // fused transposed convolution: the sub-pixel phase (accumulator set) this stage feeds
 };
 
@@ -83,7 +83,9 @@ struct HConvParams {
     int Cout, Cds, NT, nblocks;  // real / stored output channels; N-tiles per workgroup; N blocks
     int twm_log2, th_log2, nimg_m, imgs;
     int hh, hw, imgplane, nhalo; // halo geometry in pixels; nhalo = imgs * imgplane
-    int plane_slots;             // 16-byte slots per LDS plane (nhalo rounded up to a multiple of 16)
+    int plane_slots;             // halo pixels per LDS slot image, rounded up to a multiple of 16
+    int OC, pix_bytes, slot_bytes;   // octets per staged pixel (odd), OC*16, bytes of one halo slot's hi image
+    float inv_OC;
     int lo_off, b_off, lds_bytes;  // LDS byte offsets: lo planes, weight buffers; total dynamic LDS
     int wbuf_bytes;                // one weight buffer (there are two): 64 + S * NT * 2048
     int ymin, xmin, tiles_y, tiles_x;
