@@ -265,7 +265,7 @@ def loss_and_grads(hp, blob, data, labels, weights, o: TrainOptions, step: int, 
     loss, data_term, reg = loss_of(hp, P, probs, y, w, o)
     loss.backward()
     grads = {k: (P[k].grad.numpy() if trainable(k) and P[k].grad is not None else np.zeros(T[k].shape)) for k in T}
-    return (loss.item(), data_term.item(), float(reg), join_blob(hp, grads), probs.detach().numpy(),
+    return (loss.item(), data_term.item(), float(reg.detach()), join_blob(hp, grads), probs.detach().numpy(),
             {k: (m.numpy(), v.numpy(), n) for k, (m, v, n) in stats.items()})
 
 

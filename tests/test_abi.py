@@ -29,6 +29,34 @@ def test_exports_every_declared_symbol(lib):
         assert hasattr(raw, name), name
 
 
+def test_exports_every_symbol_of_the_training_header(lib):
+    from unmicst_amd import trainer
+    header = open(os.path.join(ROOT, "include", "umx_train.h")).read()
+    declared = sorted(set(re.findall(r"UMX_API\s+[\w\s\*]+?\b(umx_\w+)\s*\(", header)))
+    assert len(declared) >= 12
+    assert sorted(trainer.EXPORTS) == declared
+    raw = ctypes.CDLL(build.lib_path())
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert ctypes.sizeof(trainer._TrainOptions) == 22 * 4 + 8 + 8 * 4     # umx_train_options
+    for kind, py in (("solo", trainer.solo_options()), ("duo", trainer.duo_options())):
+        nat = trainer.native_options(kind)
+        for k, v in vars(py).items():
+            assert getattr(nat, k) == pytest.approx(v, rel=1e-6), (kind, k)
+
+
+def test_trainer_fails_loudly_without_a_gpu(lib):
+    from unmicst_amd import trainer
+    if umx.device_count() > 0:
+        pytest.skip("a GPU is present")
+    hp = helpers.small_hps()["v2_duo_like"]
+    with pytest.raises(umx.UmxError) as e:
+        trainer.Trainer(hp, model.random_blob(hp), batch=2)
+    assert e.value.code == 3
+    with pytest.raises(ValueError):
+        trainer.Trainer(helpers.small_hps()["legacy_k5"], model.random_blob(helpers.small_hps()["legacy_k5"]))
+
+
 def test_library_has_no_hip_runtime_dependency():
     """libumx must bind to the process's single HIP runtime at load time (see umx._bind_hip_runtime)."""
     import subprocess

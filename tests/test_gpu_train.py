@@ -1,0 +1,212 @@
+"""GPU parity tests of the training step (BASELINE.json configs[4]): the HIP path through the C ABI of
+include/umx_train.h against oracle/train_oracle.py (float64 autograd restatement of the reference's graph, loss and
+optimisers).
+
+Tolerances, fp32 arithmetic against a float64 oracle: loss 1e-5 relative; training-mode probabilities 2e-5 max-abs;
+gradients per tensor as max-abs error over that tensor's max-abs value:
+  TIGHT 2e-5  where no LeakyReLU / max-pool decision differs between fp32 and fp64 (measured 1e-7 .. 4e-6, the same
+              as the oracle itself evaluated in float32 by torch -- profiles/r01/train_parity_report.log);
+  LOOSE 5e-2  otherwise: the loss is continuous but its gradient is not -- an activation within rounding distance of 0
+              (or two pool candidates within rounding distance of each other) takes the other branch in fp32, and every
+              gradient below that point moves by 1e-4 .. 1e-2 of its scale (the oracle in float32 does the same, at
+              other elements; a float64 run with 1e-7 input noise does too).  A wrong kernel moves a tensor by O(1).
+The top of the graph (lt.*, lu0.bn.*, lu0.w2) must always be TIGHT; the small graphs must be TIGHT everywhere for at
+least one of three batches.  BN moving statistics 1e-5; optimiser slots like the gradients; the update itself is
+checked exactly against the kernel's own gradient (Adam divides by sqrt(v): where |g| is at rounding level the
+*direction* of a step is not determined by the maths, so parameters after Adam steps are compared with nsteps * lr)."""
+import numpy as np
+import pytest
+
+import helpers
+from unmicst_amd import model, trainer, umx
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(hp, B, seed):
+    rng = np.random.default_rng(seed)
+    data = rng.normal(0, 1, (B, hp.imSize, hp.imSize, hp.nChannels)).astype(np.float32)
+    cls = rng.integers(0, hp.nClasses, (B, hp.imSize, hp.imSize))
+    labels = np.eye(hp.nClasses, dtype=np.float32)[cls]
+    weights = rng.uniform(0.5, 3.0, labels.shape).astype(np.float32)
+    return data, labels, weights
+
+
+def _oracle_opts(o: trainer.TrainOptions):
+    from oracle import train_oracle as to
+    kw = {k: getattr(o, k) for k in ("lr0", "decay_steps", "decay_rate", "momentum", "beta1", "beta2", "adam_eps",
+                                      "reg_kind", "reg_down", "reg_bottom", "reg_up", "reg_top", "clip_eps",
+                                      "drop_down_step", "drop_bottom", "drop_up0", "drop_up_step", "bn_momentum", "seed")}
+    kw["optimizer"] = "adam" if o.optimizer == trainer.OPT_ADAM else "momentum"
+    return to.TrainOptions(**kw)
+
+
+TIGHT, LOOSE = 2e-5, 5e-2
+TOP = ("lt.w", "lt.bn.gamma", "lt.bn.beta", "lu0.bn.gamma", "lu0.bn.beta", "lu0.w2")
+
+
+def _per_tensor(hp, got, want, what, rel=LOOSE, top=TIGHT):
+    """-> worst relative error over the tensors; asserts rel on every tensor and `top` on the top of the graph."""
+    from oracle import train_oracle as to
+    G, W = to.split_blob(hp, got), to.split_blob(hp, want)
+    worst = 0.0
+    for name in W:
+        scale = np.abs(W[name]).max()
+        err = np.abs(G[name] - W[name]).max()
+        assert err <= (top if name in TOP else rel) * scale + 1e-7, (what, name, err, scale)
+        worst = max(worst, err / (scale + 1e-30))
+    return worst
+
+
+CASES = [("v2_solo_like", 4, "solo"), ("v2_duo_like", 4, "duo"), ("v2_deep", 3, "duo"), ("v2_wide", 2, "solo"),
+         ("v2_wide", 2, "duo")]
+
+
+@pytest.mark.parametrize("name,B,regime", CASES)
+def test_loss_gradients_and_probabilities_match_oracle(name, B, regime):
+    from oracle import train_oracle as to
+    hp = helpers.small_hps()[name]
+    opts = trainer.solo_options() if regime == "solo" else trainer.duo_options()
+    blob = model.random_blob(hp, seed=21)
+    data, labels, weights = _batch(hp, B, 3)
+    want_loss, want_data, want_reg, want_g, want_p, _ = to.loss_and_grads(hp, blob, data, labels, weights,
+                                                                         _oracle_opts(opts), step=0)
+    tr = trainer.Trainer(hp, blob, opts, batch=B)
+    loss, data_term, reg = tr.step(data, labels, weights, apply_update=False)
+    assert tr.step_count == 0
+    assert loss == pytest.approx(want_loss, rel=1e-5)
+    assert data_term == pytest.approx(want_data, rel=1e-5)
+    assert reg == pytest.approx(want_reg, rel=1e-5)
+    assert np.abs(tr.probs() - want_p).max() <= 2e-5
+    worst = _per_tensor(hp, tr.grads(), want_g, "grads")
+    assert np.array_equal(tr.blob(), blob)           # nothing moved, moving statistics included
+    if hp.imSize * hp.nOut0 <= 32 * 20:              # small graphs: few decisions, a flip-free batch exists
+        for seed in (4, 5):
+            if worst <= TIGHT:
+                break
+            data, labels, weights = _batch(hp, B, seed)
+            want_g = to.loss_and_grads(hp, blob, data, labels, weights, _oracle_opts(opts), step=0)[3]
+            tr.step(data, labels, weights, apply_update=False)
+            worst = _per_tensor(hp, tr.grads(), want_g, "grads seed %d" % seed)
+        assert worst <= TIGHT, worst
+    tr.close()
+
+
+@pytest.mark.parametrize("name,B,regime", [("v2_duo_like", 4, "duo"), ("v2_solo_like", 4, "solo")])
+def test_adam_steps_track_the_oracle(name, B, regime):
+    from oracle import train_oracle as to
+    hp = helpers.small_hps()[name]
+    opts = trainer.solo_options(decay_steps=2) if regime == "solo" else trainer.duo_options(decay_steps=2)
+    oo = _oracle_opts(opts)
+    blob = model.random_blob(hp, seed=8)
+    st = to.TrainState(blob)
+    tr = trainer.Trainer(hp, blob, opts, batch=B)
+    nsteps = 3
+    for s in range(nsteps):
+        data, labels, weights = _batch(hp, B, 40 + s)
+        before = tr.blob()
+        m0, v0 = tr.slots()
+        want = to.train_step(hp, st, data, labels, weights, oo)
+        got = tr.step(data, labels, weights)[0]
+        assert got == pytest.approx(want, rel=2e-4), s       # later steps inherit the Adam direction ambiguity
+        g = tr.grads().astype(np.float64)
+        # the update, exactly, from the kernel's own gradient (fp32 arithmetic restated in float64: 1e-6 relative)
+        lr = opts.lr0 * opts.decay_rate ** (s // opts.decay_steps)
+        t = s + 1
+        b1, b2 = np.float32(opts.beta1), np.float32(opts.beta2)      # the kernel forms 1 - beta in fp32, like TF's
+        m1 = float(b1) * m0 + float(np.float32(1) - b1) * g           # ApplyAdam does on float32 variables
+        v1 = float(b2) * v0 + float(np.float32(1) - b2) * g * g
+        w1 = before - lr * np.sqrt(1 - opts.beta2 ** t) / (1 - opts.beta1 ** t) * m1 / (np.sqrt(v1) + opts.adam_eps)
+        m_got, v_got = tr.slots()
+        after = tr.blob()
+        assert np.allclose(m_got, m1, rtol=1e-5, atol=2e-6 * np.abs(m1).max())     # fp32 fma with cancellation
+        assert np.allclose(v_got, v1, rtol=1e-5, atol=2e-6 * np.abs(v1).max())
+        T_after, T_w1 = to.split_blob(hp, after), to.split_blob(hp, w1)
+        for nm in T_after:
+            if to.trainable(nm):
+                assert np.abs(T_after[nm] - T_w1[nm]).max() <= 1e-6 * max(1.0, np.abs(T_w1[nm]).max()), nm
+        if s == 0:
+            _per_tensor(hp, tr.grads(), st.last["grads"], "grads step 0")
+            _per_tensor(hp, m_got, st.m, "slot m")
+        # BN moving statistics (UPDATE_OPS)
+        T_or = to.split_blob(hp, st.blob)
+        for nm in T_after:
+            if not to.trainable(nm):
+                assert np.allclose(T_after[nm], T_or[nm], rtol=1e-5, atol=1e-6), nm
+    assert tr.step_count == nsteps
+    assert np.abs(tr.blob() - st.blob).max() <= nsteps * opts.lr0 * 1.01 + 1e-6
+    tr.close()
+
+
+def test_momentum_steps_match_oracle_tightly():
+    """MomentumOptimizer (reference UnMicst.py:270-279) is linear in the gradient: parameters are comparable directly."""
+    from oracle import train_oracle as to
+    hp = helpers.small_hps()["v2_duo_like"]
+    opts = trainer.TrainOptions(optimizer=trainer.OPT_MOMENTUM, lr0=0.01, decay_steps=1000, decay_rate=0.95,
+                                reg_kind=trainer.REG_L2, reg_down=1e-3, reg_bottom=1e-3, reg_up=1e-3, reg_top=1e-3,
+                                clip_eps=0.0, drop_down_step=0.05, drop_bottom=0.3, drop_up0=0.25, drop_up_step=0.05)
+    blob = model.random_blob(hp, seed=4)
+    st = to.TrainState(blob)
+    tr = trainer.Trainer(hp, blob, opts, batch=4)
+    for s in range(3):
+        data, labels, weights = _batch(hp, 4, 70 + s)
+        want = to.train_step(hp, st, data, labels, weights, _oracle_opts(opts))
+        got = tr.step(data, labels, weights)[0]
+        assert got == pytest.approx(want, rel=5e-5), s
+    got_blob = tr.blob()
+    T_g, T_w = to.split_blob(hp, got_blob), to.split_blob(hp, st.blob)
+    for nm in T_w:
+        assert np.abs(T_g[nm] - T_w[nm]).max() <= LOOSE * np.abs(T_w[nm] - to.split_blob(hp, blob)[nm]).max() + 2e-6, nm
+    tr.close()
+
+
+def test_step_is_bit_reproducible_and_trained_blob_serves_inference():
+    from oracle import oracle
+    hp = helpers.small_hps()["v2_wide"]
+    blob = model.random_blob(hp, seed=2)
+    data, labels, weights = _batch(hp, 2, 6)
+    outs = []
+    for _ in range(2):
+        tr = trainer.Trainer(hp, blob, trainer.duo_options(), batch=2)
+        losses = [tr.step(data, labels, weights)[0] for _ in range(2)]
+        outs.append((losses, tr.grads(), tr.blob()))
+        tr.close()
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    assert outs[0][0][1] < outs[0][0][0]            # same batch twice: the loss goes down
+    trained = outs[0][2]
+    ref = oracle.forward(hp, trained, data)
+    with umx.Engine(hp, trained, max_batch=2, precision="f32") as eng:
+        got = eng.forward_tiles(data)
+    assert np.abs(got - ref).max() <= 1e-4
+
+
+def test_device_pointer_step_matches_host_step(torch_cuda=None):
+    import torch
+    hp = helpers.small_hps()["v2_duo_like"]
+    blob = model.random_blob(hp, seed=12)
+    data, labels, weights = _batch(hp, 4, 9)
+    a = trainer.Trainer(hp, blob, trainer.duo_options(), batch=4)
+    want = a.step(data, labels, weights)
+    b = trainer.Trainer(hp, blob, trainer.duo_options(), batch=4)
+    d, y, w = (torch.from_numpy(v).cuda() for v in (data, labels, weights))
+    torch.cuda.synchronize()
+    b.step_dev(d.data_ptr(), y.data_ptr(), w.data_ptr())
+    assert b.loss() == want
+    assert np.array_equal(a.blob(), b.blob())
+    a.close()
+    b.close()
+
+
+def test_errors():
+    hp = helpers.small_hps()["v2_duo_like"]
+    blob = model.random_blob(hp)
+    with pytest.raises(umx.UmxError) as e:
+        trainer.Trainer(hp, blob[:-1], batch=2)
+    assert e.value.code == 2
+    with pytest.raises(ValueError):
+        trainer.Trainer(helpers.small_hps()["legacy_k5"], model.random_blob(helpers.small_hps()["legacy_k5"]))
+    tr = trainer.Trainer(hp, blob, batch=2)
+    with pytest.raises(ValueError):
+        tr.step(np.zeros((3, 32, 32, 2)), np.zeros((3, 32, 32, 3)), np.zeros((3, 32, 32, 3)))
+    tr.close()

@@ -7,8 +7,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libumx.so")
-SOURCES = ["umx_kernels.hip", "umx_conv_f16.hip", "umx_engine.hip"]
-DEPS = SOURCES + ["umx_kernels.h", os.path.join("..", "..", "include", "umx.h")]
+SOURCES = ["umx_kernels.hip", "umx_conv_f16.hip", "umx_engine.hip", "umx_train_kernels.hip", "umx_train.hip"]
+DEPS = SOURCES + ["umx_kernels.h", os.path.join("..", "..", "include", "umx.h"),
+                  os.path.join("..", "..", "include", "umx_train.h")]
 
 
 def lib_path() -> str:

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+
 namespace umx {
 
 constexpr int kWaves = 4;        // waves per workgroup (256 threads)
@@ -138,6 +140,105 @@ hipError_t launch_stitch(const float* probs, int tpr0, int tpr1, const TileGeom&
 hipError_t launch_raw_to_double(const void* raw, int bits, size_t n, int rescale, unsigned* mm /*2 words*/, double* out,
                                 hipStream_t stream);
 hipError_t launch_half_to_u8(const void* pm_half, size_t n, unsigned char* out, hipStream_t stream);
+
+
+// ---- training step (umx_train_kernels.hip): fp32 everywhere, reductions in fp64 with a fixed summation order ----------
+constexpr int kMaxPackTaps = 25;
+
+// One packed operand of the fp32 conv kernel, rebuilt on the device from the master tensors every step:
+//   packed[t][c][n] ([ntaps][Cp][Np], zero outside C x N);  (par, c') = (c / Cblk, c % Cblk);  m = mtap[t*npar + par]
+//   transpose 0:  w[m][c_off + c'][n]        forward conv group / space-to-depth input-gradient of a transposed conv
+//   transpose 1:  w[m][c_off + n][c']        input-gradient of a conv (channel slice c_off..) / transposed conv phase
+//   (+ w2 at the same index when non-NULL: main filter + shortcut filter of a v2 down layer)
+struct PackDesc {
+    float* dst;
+    const float* w;
+    const float* w2;
+    int ntaps, Cp, Np, C, N;
+    int d2, d3;            // master tensor [taps][d2][d3]
+    int transpose, c_off;
+    int npar, Cblk;
+    short mtap[4 * kMaxPackTaps];
+};
+hipError_t launch_pack_weights(const PackDesc* descs_dev, int ndesc, size_t max_elems, hipStream_t stream);
+
+// per-channel sums over the rows of an NHWC tensor [N][C]: part[blk][2][C] = (sum, sum of squares), fp64
+int chan_blocks(size_t N, int C);
+hipError_t launch_chan_stats(const float* x, size_t N, int C, double* part, int nblk, hipStream_t stream);
+// batch statistics -> stat[4][C] = mean | rstd | scale = gamma*rstd | shift = beta - mean*scale; moving statistics
+// updated in place (momentum; the unbiased variance feeds the moving variance, like TF's fused kernel)
+hipError_t launch_bn_finalize(const double* part, int nblk, size_t N, int C, const float* gamma, const float* beta,
+                              float* mov_mean, float* mov_var, float momentum, float* stat, hipStream_t stream);
+
+struct ActParams {          // y = dropout(act(z*scale + shift)) [-> 2x2 max-pool]
+    const float* z;         // [B,H,W,C] pre-BN conv output
+    const float* stat;      // [4][C]
+    int B, H, W, C;
+    int pool, act;
+    float drop_rate;
+    unsigned long long drop_key;
+};
+hipError_t launch_act_fwd(const ActParams& a, float* out, hipStream_t stream);
+// backward of the same: g = d(loss)/d(BN output) written full-res [B,H,W,C]; part[blk][2][C] = (sum g, sum g*xhat)
+hipError_t launch_act_bwd(const ActParams& a, const float* dy0, const float* dy1, float* g, double* part, int nblk,
+                          hipStream_t stream);
+// sums -> m12[2][C] = (mean g, mean g*xhat); dgamma = sum g*xhat, dbeta = sum g
+hipError_t launch_bn_bwd_finalize(const double* part, int nblk, size_t N, int C, float* dgamma, float* dbeta, float* m12,
+                                  hipStream_t stream);
+// g <- scale * (g - m1 - xhat*m2)   (in place: gradient w.r.t. the conv output z)
+hipError_t launch_bn_bwd_apply(float* g, const float* z, const float* stat, const float* m12, size_t N, int C,
+                               hipStream_t stream);
+// gS[b,i,j,(pa*2+pb)*C + c] = d_us[b,2i+pa,2j+pb,c] * (us > 0 ? 1 : 0.2)
+hipError_t launch_leaky_bwd_s2d(const float* d_us, const float* us, int B, int S, int C, float* gS, hipStream_t stream);
+
+// top layer: t0 = x W (1x1 conv, K <= 8 classes)
+hipError_t launch_head_fwd(const float* x, size_t N, int C, int K, const float* w, float* t0, hipStream_t stream);
+// p = softmax(t0*scale + shift); loss partials; dt = d(mean loss)/dt;  part[blk] fp64
+int loss_blocks(size_t N);
+hipError_t launch_softmax_loss(const float* t0, const float* stat, const float* labels, const float* weights, size_t N,
+                               int K, float clip_eps, float* probs, float* dt, double* part, int nblk, hipStream_t stream);
+// dx = dt0 W^T ; part[blk][C][K] = sum_p x[p][c] dt0[p][k]
+hipError_t launch_head_bwd(const float* x, const float* dt0, const float* w, size_t N, int C, int K, float* dx,
+                           double* part, int nblk, hipStream_t stream);
+// dst[i] = scale * sum_b part[b][i] (+ reg'(w[i])) ; fixed order
+hipError_t launch_reduce_partials(const double* part, int nblk, int n, double scale, float* dst, const float* w,
+                                  int reg_kind, float reg_c, hipStream_t stream);
+// out[slot] (+)= scale * sum part[0..n)
+hipError_t launch_sum_to_scalar(const double* part, int n, double scale, double* out, int slot, int accumulate,
+                                hipStream_t stream);
+// part[blk] = sum |w| (kind 1) or sum w^2 (kind 2) -- 64 blocks
+hipError_t launch_reg_partials(const float* w, size_t n, int kind, double* part, hipStream_t stream);
+
+// weight gradient of a convolution on the fp32 matrix cores:  dW[s][ci][co] = sum_p X[p + (dy_s,dx_s)][coff_s + ci] * G[p][co]
+constexpr int kWgMaxSlabs = 32;
+struct WgradParams {
+    const float* X; int Cxt;      // NHWC, Cxt channels per pixel
+    const float* G; int Cg;       // NHWC [B,H,W,Cg]
+    int B, H, W;
+    int nslab, Cx;
+    short dy[kWgMaxSlabs], dx[kWgMaxSlabs];
+    short mslab[kWgMaxSlabs];     // slab -> tap index of the master tensor (row block of dW this slab produces)
+    int coff[kWgMaxSlabs];
+    int ngroups;                  // slabs are processed in groups of <= 9 that share one channel offset
+    short gstart[kWgMaxSlabs], gcount[kWgMaxSlabs];
+    int tw_log2, th_log2, imgs;   // pixel tile = imgs x TH x TW = 128 pixels
+    int hh, hw, imgplane, nhalo, ymin, xmin, tiles_y, tiles_x;
+    int ntiles, tiles_per_slice, nslices;
+    int vecx, vecg;               // 16-byte loads allowed
+    float* ws;                    // [slice][slab][Cx][Cg]
+};
+bool wgrad_setup(WgradParams* p, std::string* why);   // fills geometry, slab groups and slices from B,H,W,Cx,Cg,nslab,dy,dx,coff
+size_t wgrad_ws_floats(const WgradParams& p);
+hipError_t launch_wgrad(const WgradParams& p, hipStream_t stream);
+// g[(s*Ctot + c_off + ci)*Cg + co] = sum_slices ws (+ reg'(w)) ; optional second destination g2 (no reg) for the pair
+hipError_t launch_wgrad_reduce(const WgradParams& p, int Ctot, int c_off, float* g, const float* w, int reg_kind,
+                               float reg_c, float* g2, hipStream_t stream);
+
+struct OptParams {
+    int kind;                 // 0 Adam, 1 Momentum
+    float lr, lr_t, beta1, beta2, eps, momentum;
+};
+hipError_t launch_optimizer(const OptParams& o, float* w, const float* g, float* m, float* v, size_t n, hipStream_t stream);
 
 __host__ __device__ inline uint16_t double_to_half_rne(double d);
 

@@ -1,0 +1,843 @@
+// libumx training step: host side (plan, buffers, launch sequence) and the C ABI of include/umx_train.h.
+//
+// The step is written out layer by layer rather than as a generic autograd tape: the v2 graph is fixed
+// (reference UnMicst1-5.py:83-237), so every tensor the backward pass needs is known at create time and lives in a
+// preallocated HBM buffer (pre-BN conv outputs z, layer inputs, up-sampled tensors); nothing is recomputed except the
+// cheap element-wise BN/activation/dropout chain, and nothing is allocated during a step.
+//
+//   forward   conv (fp32 MFMA, raw) -> per-channel batch statistics -> BN + LeakyReLU + dropout (+ 2x2 max-pool)
+//   backward  activation/pool/dropout backward + BN reductions -> BN input gradient -> weight gradient (fp32 MFMA,
+//             umx_train_kernels.hip) and input gradient (the forward conv kernel on flipped/transposed filters; for a
+//             stride-2 transposed conv: a 2x2-tap conv over the space-to-depth form of the output gradient)
+//   update    Adam / Momentum over the flat parameter vector
+#include "../../include/umx_train.h"
+#include "umx_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace umx;
+
+namespace {
+
+thread_local std::string g_terr;
+
+struct TConv {                       // one launch of conv_mfma_f32 with device-packed operands
+    ConvParams cp;
+    int nt = 1, hpix = 2;
+    float* packed[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    double mac = 0.0;                // algorithmic multiply-accumulates per image
+    bool used = false;
+};
+
+struct TapSet {
+    std::vector<std::pair<int, int>> off;   // (dy, dx) input offsets
+    std::vector<int> m;                     // master tap index per (tap, parity) : size off.size() * npar
+};
+
+struct BnSite {            // one batch-normalised tensor
+    int C = 0, H = 0, W = 0;
+    size_t gamma = 0, beta = 0, mean = 0, var = 0;   // offsets in the parameter vector
+    float* z = nullptr;    // [B,H,W,C] pre-BN
+    float* stat = nullptr; // [4][C]
+    float* m12 = nullptr;  // [2][C]
+};
+
+struct Seg { std::string name; size_t off, n; float reg; };
+
+}  // namespace
+
+struct umx_trainer {
+    umx_hparams hp;
+    umx_train_options o;
+    int device = 0, B = 0, L = 0, K = 0, P = 0;
+    std::vector<int> n;                 // channel widths
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void*> allocs;
+    int64_t step = 0;
+    // parameters
+    size_t nparams = 0;
+    std::vector<Seg> segs;
+    float *d_w = nullptr, *d_g = nullptr, *d_m = nullptr, *d_v = nullptr;
+    // per-layer offsets into the parameter vector
+    std::vector<size_t> o_w1, o_ws, o_wt, o_w2;
+    size_t o_lb = 0, o_lt = 0;
+    // activations
+    std::vector<float*> ds;             // ds[0] = data, ds[i+1] = pooled output of down layer i
+    std::vector<BnSite> bn_d, bn_u;     // down layers / up layers (index = idx)
+    BnSite bn_b, bn_t;
+    float* act_b = nullptr;             // bottom output
+    std::vector<float*> us, cv;         // per up layer idx
+    float *d_labels = nullptr, *d_weights = nullptr, *d_probs = nullptr, *d_dt = nullptr;
+    std::vector<float*> dskip;          // gradient w.r.t. ds[idx] from the up path (idx >= 1)
+    float *DA = nullptr, *DB = nullptr, *DZ = nullptr, *GS = nullptr;
+    double* d_part = nullptr;  size_t part_doubles = 0;
+    double* d_loss = nullptr;           // [0] data term, [1] regularisation
+    float* d_ws = nullptr;  size_t ws_floats = 0;
+    // launches
+    std::vector<TConv> c_fwd_d, c_dg_d, c_T, c_fwd_u, c_dg_us, c_dg_skip, c_dg_T;
+    TConv c_fwd_b, c_dg_b;
+    std::vector<WgradParams> wg_d, wg_u0, wg_u1, wg_T;
+    WgradParams wg_b;
+    std::vector<PackDesc> packs;
+    PackDesc* d_packs = nullptr;
+    size_t max_pack = 0;
+    double flops_per_image = 0.0;
+    // profiling
+    bool prof = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    double t_fwd = 0, t_bwd = 0, t_opt = 0;
+    int t_steps = 0;
+    bool pending = false;
+};
+
+namespace {
+
+int tfail(umx_trainer* tr, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (tr) tr->err = buf; else g_terr = buf;
+    return code;
+}
+
+#define T_HIP(tr, call)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return tfail(tr, e_ == hipErrorOutOfMemory ? UMX_ERR_OOM : UMX_ERR_HIP, "%s failed: %s", #call, \
+                         hipGetErrorString(e_));                                                          \
+    } while (0)
+#define T_TRY(call)                  \
+    do {                             \
+        int rc_ = (call);            \
+        if (rc_ != UMX_OK) return rc_; \
+    } while (0)
+
+int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+template <typename T>
+int talloc(umx_trainer* tr, T** out, size_t count) {
+    void* d = nullptr;
+    T_HIP(tr, hipMalloc(&d, std::max<size_t>(16, count * sizeof(T))));
+    tr->allocs.push_back(d);
+    *out = reinterpret_cast<T*>(d);
+    return UMX_OK;
+}
+
+template <typename T>
+int tzero(umx_trainer* tr, T** out, size_t count) {
+    T_TRY(talloc(tr, out, count));
+    T_HIP(tr, hipMemset(*out, 0, std::max<size_t>(16, count * sizeof(T))));
+    return UMX_OK;
+}
+
+void choose_nt(int Cout, int* nt, int* Np) {
+    const int t16 = (Cout + 15) / 16;
+    int best = 1, best_pad = 1 << 30;
+    for (int c = 1; c <= kMaxNT; ++c) {
+        const int padded = round_up(t16, c);
+        if (padded < best_pad || (padded == best_pad && c > best)) { best = c; best_pad = padded; }
+    }
+    *nt = best;
+    *Np = best_pad * 16;
+}
+
+// Geometry + packed-operand buffers + pack descriptors of one conv launch.
+//   groups: ngroups sources with C[g] channels; per phase and group a TapSet (master taps of tensor w_off);
+//   pack_mode per group: transpose flag, channel offset on the master's d2 axis, (npar, Cblk), optional second tensor
+struct GroupSpec {
+    int C;                      // source channels seen by the kernel
+    size_t w_off, w2_off;       // master tensor(s) in the parameter vector (w2_off = SIZE_MAX: none)
+    int d2, d3;                 // master dims [taps][d2][d3]
+    int transpose, c_off, npar, Cblk;
+    TapSet taps[4];
+};
+
+int setup_conv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int Cout, int act, int nphase, int o_mul,
+               const int* oy, const int* ox, int ngroups, GroupSpec* gs) {
+    ConvParams& p = tc.cp;
+    memset(&p, 0, sizeof p);
+    choose_nt(Cout, &tc.nt, &p.Np);
+    int ymin = 0, ymax = 0, xmin = 0, xmax = 0, ntaps_total = 0;
+    for (int g = 0; g < ngroups; ++g)
+        for (int ph = 0; ph < nphase; ++ph)
+            for (auto& t : gs[g].taps[ph].off) {
+                ymin = std::min(ymin, t.first); ymax = std::max(ymax, t.first);
+                xmin = std::min(xmin, t.second); xmax = std::max(xmax, t.second);
+                ++ntaps_total;
+            }
+    if (ntaps_total > kMaxTaps) return tfail(tr, UMX_ERR_INVALID, "%s: too many filter taps", what);
+    auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    const int TWm = std::min(16, W), TH = std::min(16, H);
+    if ((TWm & (TWm - 1)) || (TH & (TH - 1)))
+        return tfail(tr, UMX_ERR_INVALID, "%s: layer size %d must be a power of two", what, H);
+    p.twm_log2 = lg2(TWm);
+    p.th_log2 = lg2(TH);
+    p.nimg_m = 16 / TWm;
+    p.imgs = p.nimg_m * (16 / TH);
+    p.hh = TH + ymax - ymin;
+    p.hw = TWm + xmax - xmin;
+    p.imgplane = p.hh * p.hw;
+    int plane = round_up(p.imgs * p.imgplane, 32) + 16;
+    if (plane - 32 >= p.imgs * p.imgplane) plane -= 32;
+    p.plane = plane;
+    p.ymin = ymin;
+    p.xmin = xmin;
+    p.tiles_y = H / TH;
+    p.tiles_x = W / TWm;
+    tc.hpix = (p.imgs * p.imgplane + 255) / 256;
+    if (tc.hpix > 4) return tfail(tr, UMX_ERR_INVALID, "%s: halo too large", what);
+    tc.hpix = tc.hpix <= 2 ? 2 : 4;
+    p.ngroups = ngroups;
+    p.H = H; p.W = W; p.Cout = Cout;
+    p.nphase = nphase; p.o_mul = o_mul;
+    p.outH = H * o_mul; p.outW = W * o_mul; p.pool = 0; p.act = act;
+    if (conv_lds_bytes(tc.nt, p.plane) > 160 * 1024) return tfail(tr, UMX_ERR_INVALID, "%s: LDS footprint too large", what);
+    int tpos = 0;
+    for (int ph = 0; ph < nphase; ++ph) {
+        p.ph[ph].oy_off = oy ? oy[ph] : 0;
+        p.ph[ph].ox_off = ox ? ox[ph] : 0;
+        for (int g = 0; g < ngroups; ++g) {
+            const TapSet& ts = gs[g].taps[ph];
+            p.ph[ph].tap0[g] = tpos;
+            p.ph[ph].ntaps[g] = (int)ts.off.size();
+            for (auto& t : ts.off) p.tapoff[tpos++] = (short)((t.first - ymin) * p.hw + (t.second - xmin));
+        }
+    }
+    for (int g = 0; g < ngroups; ++g) {
+        p.C[g] = gs[g].C;
+        p.Cp[g] = round_up(gs[g].C, 4);
+        p.vec4[g] = (gs[g].C % 4) == 0;
+    }
+    // packed operands + descriptors
+    for (int ph = 0; ph < nphase; ++ph)
+        for (int g = 0; g < ngroups; ++g) {
+            const TapSet& ts = gs[g].taps[ph];
+            const int nt = (int)ts.off.size();
+            if (nt == 0) continue;
+            if (nt * gs[g].npar > 4 * kMaxPackTaps) return tfail(tr, UMX_ERR_INVALID, "%s: too many taps to pack", what);
+            const size_t elems = (size_t)nt * p.Cp[g] * p.Np;
+            T_TRY(talloc(tr, &tc.packed[ph][g], elems));
+            p.ph[ph].w[g] = tc.packed[ph][g];
+            PackDesc d;
+            memset(&d, 0, sizeof d);
+            d.dst = tc.packed[ph][g];
+            d.w = tr->d_w + gs[g].w_off;
+            d.w2 = gs[g].w2_off == SIZE_MAX ? nullptr : tr->d_w + gs[g].w2_off;
+            d.ntaps = nt; d.Cp = p.Cp[g]; d.Np = p.Np; d.C = gs[g].C; d.N = Cout;
+            d.d2 = gs[g].d2; d.d3 = gs[g].d3;
+            d.transpose = gs[g].transpose; d.c_off = gs[g].c_off;
+            d.npar = gs[g].npar; d.Cblk = gs[g].Cblk;
+            for (size_t i = 0; i < ts.m.size(); ++i) d.mtap[i] = (short)ts.m[i];
+            tr->packs.push_back(d);
+            tr->max_pack = std::max(tr->max_pack, elems);
+            tc.mac += (double)H * W * nt * gs[g].C * Cout;
+        }
+    tc.used = true;
+    return UMX_OK;
+}
+
+int run_conv(umx_trainer* tr, TConv& tc, const float* src0, const float* src1, float* dst) {
+    ConvParams p = tc.cp;
+    p.src[0] = src0;
+    p.src[1] = src1;
+    p.dst = dst;
+    p.B = tr->B;
+    T_HIP(tr, launch_conv(p, tc.nt, tc.hpix, tr->stream));
+    return UMX_OK;
+}
+
+TapSet same_taps(int ks, bool flipped) {   // stride-1 SAME conv (or its input gradient: offsets negated)
+    TapSet t;
+    const int ph = (ks - 1) / 2;
+    for (int a = 0; a < ks; ++a)
+        for (int b = 0; b < ks; ++b) {
+            t.off.push_back(flipped ? std::make_pair(ph - a, ph - b) : std::make_pair(a - ph, b - ph));
+            t.m.push_back(a * ks + b);
+        }
+    return t;
+}
+
+int setup_wgrad(umx_trainer* tr, WgradParams& w, const char* what, int H, int Cxt, int Cx, int Cg, const TapSet& slabs,
+                const std::vector<int>& coff) {
+    memset(&w, 0, sizeof w);
+    w.B = tr->B; w.H = H; w.W = H;
+    w.Cxt = Cxt; w.Cx = Cx; w.Cg = Cg;
+    w.nslab = (int)slabs.off.size();
+    if (w.nslab > kWgMaxSlabs) return tfail(tr, UMX_ERR_INVALID, "%s: too many filter taps", what);
+    for (int s = 0; s < w.nslab; ++s) {
+        w.dy[s] = (short)slabs.off[s].first;
+        w.dx[s] = (short)slabs.off[s].second;
+        w.mslab[s] = (short)slabs.m[s];
+        w.coff[s] = coff.empty() ? 0 : coff[s];
+    }
+    std::string why;
+    if (!wgrad_setup(&w, &why)) return tfail(tr, UMX_ERR_INVALID, "%s: %s", what, why.c_str());
+    tr->ws_floats = std::max(tr->ws_floats, wgrad_ws_floats(w));
+    return UMX_OK;
+}
+
+unsigned long long mix64_host(unsigned long long x) {
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+unsigned long long drop_key(const umx_trainer* tr, int layer_id) {
+    return mix64_host(tr->o.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(64 * tr->step + layer_id + 1));
+}
+
+int bn_alloc(umx_trainer* tr, BnSite& s, int C, int H, size_t off_gamma) {
+    s.C = C; s.H = s.W = H;
+    s.gamma = off_gamma; s.beta = off_gamma + C; s.mean = off_gamma + 2 * (size_t)C; s.var = off_gamma + 3 * (size_t)C;
+    T_TRY(talloc(tr, &s.z, (size_t)tr->B * H * H * C));
+    T_TRY(talloc(tr, &s.stat, 4 * (size_t)C));
+    T_TRY(talloc(tr, &s.m12, 2 * (size_t)C));
+    return UMX_OK;
+}
+
+// z -> statistics -> stat (and the moving averages when updating)
+int bn_forward_stats(umx_trainer* tr, BnSite& s, bool update) {
+    const size_t N = (size_t)tr->B * s.H * s.W;
+    const int nblk = chan_blocks(N, s.C);
+    T_HIP(tr, launch_chan_stats(s.z, N, s.C, tr->d_part, nblk, tr->stream));
+    T_HIP(tr, launch_bn_finalize(tr->d_part, nblk, N, s.C, tr->d_w + s.gamma, tr->d_w + s.beta, tr->d_w + s.mean,
+                                 tr->d_w + s.var, update ? tr->o.bn_momentum : 1.0f, s.stat, tr->stream));
+    return UMX_OK;
+}
+
+ActParams act_params(const umx_trainer* tr, const BnSite& s, int pool, int act, float rate, int layer_id) {
+    ActParams a;
+    a.z = s.z; a.stat = s.stat;
+    a.B = tr->B; a.H = s.H; a.W = s.W; a.C = s.C;
+    a.pool = pool; a.act = act;
+    a.drop_rate = rate > 0.f ? rate : 0.f;
+    a.drop_key = drop_key(tr, layer_id);
+    return a;
+}
+
+// dy (+dy1) -> gradient w.r.t. z in tr->DZ ; BN parameter gradients into the gradient vector
+int bn_backward(umx_trainer* tr, BnSite& s, const ActParams& a, const float* dy0, const float* dy1, float* dz) {
+    const size_t N = (size_t)tr->B * s.H * s.W;
+    const size_t rows = a.pool ? N / 4 : N;
+    const int nblk = chan_blocks(rows, s.C);
+    T_HIP(tr, launch_act_bwd(a, dy0, dy1, dz, tr->d_part, nblk, tr->stream));
+    T_HIP(tr, launch_bn_bwd_finalize(tr->d_part, nblk, N, s.C, tr->d_g + s.gamma, tr->d_g + s.beta, s.m12, tr->stream));
+    T_HIP(tr, launch_bn_bwd_apply(dz, s.z, s.stat, s.m12, N, s.C, tr->stream));
+    return UMX_OK;
+}
+
+int run_wgrad(umx_trainer* tr, WgradParams& w, const float* X, const float* G, int Ctot, int c_off, size_t w_off,
+              float reg, size_t pair_off /* SIZE_MAX: none */) {
+    w.X = X;
+    w.G = G;
+    w.ws = tr->d_ws;
+    T_HIP(tr, launch_wgrad(w, tr->stream));
+    T_HIP(tr, launch_wgrad_reduce(w, Ctot, c_off, tr->d_g + w_off, tr->d_w + w_off, reg > 0.f ? tr->o.reg_kind : 0, reg,
+                                  pair_off == SIZE_MAX ? nullptr : tr->d_g + pair_off, tr->stream));
+    return UMX_OK;
+}
+
+float up_rate(const umx_trainer* tr, int idx) { return tr->o.drop_up0 - tr->o.drop_up_step * idx; }
+float down_rate(const umx_trainer* tr, int i) { return tr->o.drop_down_step * i; }
+
+enum { LAYER_DOWN = 0, LAYER_BOTTOM = 16, LAYER_UP = 32 };   // dropout stream ids (oracle/train_oracle.py)
+
+int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const float* weights, bool update) {
+    const int L = tr->L, K = tr->K, B = tr->B, P = tr->P;
+    hipStream_t st = tr->stream;
+    const umx_train_options& o = tr->o;
+    const size_t Npix = (size_t)B * P * P;
+    if (tr->prof) T_HIP(tr, hipEventRecord(tr->ev[0], st));
+    T_HIP(tr, hipMemsetAsync(tr->d_loss, 0, 2 * sizeof(double), st));
+    T_HIP(tr, launch_pack_weights(tr->d_packs, (int)tr->packs.size(), tr->max_pack, st));
+
+    // ------------------------------------------------------------------ forward (UnMicst1-5.py:83-237)
+    tr->ds[0] = const_cast<float*>(data);
+    for (int i = 0; i < L; ++i) {
+        BnSite& s = tr->bn_d[i];
+        T_TRY(run_conv(tr, tr->c_fwd_d[i], tr->ds[i], nullptr, s.z));
+        T_TRY(bn_forward_stats(tr, s, update));
+        T_HIP(tr, launch_act_fwd(act_params(tr, s, 1, ACT_LEAKY, down_rate(tr, i), LAYER_DOWN + i), tr->ds[i + 1], st));
+    }
+    T_TRY(run_conv(tr, tr->c_fwd_b, tr->ds[L], nullptr, tr->bn_b.z));
+    T_TRY(bn_forward_stats(tr, tr->bn_b, update));
+    T_HIP(tr, launch_act_fwd(act_params(tr, tr->bn_b, 0, ACT_LEAKY, o.drop_bottom, LAYER_BOTTOM), tr->act_b, st));
+    const float* cur = tr->act_b;
+    for (int idx = L - 1; idx >= 0; --idx) {
+        BnSite& s = tr->bn_u[idx];
+        T_TRY(run_conv(tr, tr->c_T[idx], cur, nullptr, tr->us[idx]));
+        T_TRY(run_conv(tr, tr->c_fwd_u[idx], tr->ds[idx], tr->us[idx], s.z));
+        T_TRY(bn_forward_stats(tr, s, update));
+        T_HIP(tr, launch_act_fwd(act_params(tr, s, 0, ACT_LEAKY, up_rate(tr, idx), LAYER_UP + idx), tr->cv[idx], st));
+        cur = tr->cv[idx];
+    }
+    BnSite& t = tr->bn_t;
+    T_HIP(tr, launch_head_fwd(tr->cv[0], Npix, tr->n[1], K, tr->d_w + tr->o_lt, t.z, st));
+    T_TRY(bn_forward_stats(tr, t, update));
+    {
+        const int nblk = loss_blocks(Npix);
+        T_HIP(tr, launch_softmax_loss(t.z, t.stat, labels, weights, Npix, K, o.clip_eps, tr->d_probs, tr->d_dt, tr->d_part,
+                                      nblk, st));
+        T_HIP(tr, launch_sum_to_scalar(tr->d_part, nblk, 1.0 / (double)Npix, tr->d_loss, 0, 0, st));
+    }
+    if (o.reg_kind != UMX_REG_NONE)
+        for (const Seg& sg : tr->segs)
+            if (sg.reg > 0.f) {
+                T_HIP(tr, launch_reg_partials(tr->d_w + sg.off, sg.n, o.reg_kind, tr->d_part, st));
+                T_HIP(tr, launch_sum_to_scalar(tr->d_part, 64, (double)sg.reg, tr->d_loss, 1, 1, st));
+            }
+    if (tr->prof) T_HIP(tr, hipEventRecord(tr->ev[1], st));
+
+    // ------------------------------------------------------------------ backward
+    {   // top layer: softmax/CE gradient -> BN -> 1x1 conv
+        ActParams a = act_params(tr, t, 0, ACT_NONE, 0.f, 0);
+        T_TRY(bn_backward(tr, t, a, tr->d_dt, nullptr, tr->d_dt));   // in place: dt -> dt0
+        const int nblk = chan_blocks(Npix, tr->n[1]);
+        T_HIP(tr, launch_head_bwd(tr->cv[0], tr->d_dt, tr->d_w + tr->o_lt, Npix, tr->n[1], K, tr->DA, tr->d_part, nblk, st));
+        T_HIP(tr, launch_reduce_partials(tr->d_part, nblk, tr->n[1] * K, 1.0, tr->d_g + tr->o_lt, tr->d_w + tr->o_lt,
+                                         o.reg_top > 0.f ? o.reg_kind : 0, o.reg_top, st));
+    }
+    int S = P;
+    for (int idx = 0; idx < L; ++idx) {    // up layers, output side first
+        BnSite& s = tr->bn_u[idx];
+        const int Cskip = tr->n[idx], Cup = tr->n[idx + 1];
+        const float* layer_in = idx == L - 1 ? tr->act_b : tr->cv[idx + 1];
+        ActParams a = act_params(tr, s, 0, ACT_LEAKY, up_rate(tr, idx), LAYER_UP + idx);
+        T_TRY(bn_backward(tr, s, a, tr->DA, nullptr, tr->DZ));
+        T_TRY(run_wgrad(tr, tr->wg_u0[idx], tr->ds[idx], tr->DZ, Cskip + Cup, 0, tr->o_w2[idx], o.reg_up, SIZE_MAX));
+        T_TRY(run_wgrad(tr, tr->wg_u1[idx], tr->us[idx], tr->DZ, Cskip + Cup, Cskip, tr->o_w2[idx], o.reg_up, SIZE_MAX));
+        T_TRY(run_conv(tr, tr->c_dg_us[idx], tr->DZ, nullptr, tr->DB));
+        if (idx >= 1) T_TRY(run_conv(tr, tr->c_dg_skip[idx], tr->DZ, nullptr, tr->dskip[idx]));
+        T_HIP(tr, launch_leaky_bwd_s2d(tr->DB, tr->us[idx], B, S / 2, Cup, tr->GS, st));
+        T_TRY(run_wgrad(tr, tr->wg_T[idx], tr->GS, layer_in, Cup, 0, tr->o_wt[idx], o.reg_up, SIZE_MAX));
+        T_TRY(run_conv(tr, tr->c_dg_T[idx], tr->GS, nullptr, tr->DA));
+        S /= 2;
+    }
+    {   // bottom layer
+        ActParams a = act_params(tr, tr->bn_b, 0, ACT_LEAKY, o.drop_bottom, LAYER_BOTTOM);
+        T_TRY(bn_backward(tr, tr->bn_b, a, tr->DA, nullptr, tr->DZ));
+        T_TRY(run_wgrad(tr, tr->wg_b, tr->ds[L], tr->DZ, tr->n[L], 0, tr->o_lb, o.reg_bottom, SIZE_MAX));
+        T_TRY(run_conv(tr, tr->c_dg_b, tr->DZ, nullptr, tr->DB));
+    }
+    for (int i = L - 1; i >= 0; --i) {     // down layers
+        BnSite& s = tr->bn_d[i];
+        ActParams a = act_params(tr, s, 1, ACT_LEAKY, down_rate(tr, i), LAYER_DOWN + i);
+        const float* dy1 = (i + 1 <= L - 1) ? tr->dskip[i + 1] : nullptr;
+        T_TRY(bn_backward(tr, s, a, tr->DB, dy1, tr->DZ));
+        // c00 + shortcut = conv(x, W1 + Wshort): both filters receive the same data gradient (UnMicst1-5.py:102-114)
+        T_TRY(run_wgrad(tr, tr->wg_d[i], tr->ds[i], tr->DZ, tr->n[i], 0, tr->o_ws[i], o.reg_down, tr->o_w1[i]));
+        if (i >= 1) T_TRY(run_conv(tr, tr->c_dg_d[i], tr->DZ, nullptr, tr->DB));
+    }
+    if (tr->prof) T_HIP(tr, hipEventRecord(tr->ev[2], st));
+
+    // ------------------------------------------------------------------ update (UnMicst1-5.py:361-380)
+    if (update) {
+        OptParams op;
+        op.kind = o.optimizer;
+        const double lr = (double)o.lr0 * std::pow((double)o.decay_rate, (double)(tr->step / std::max(1, o.decay_steps)));
+        const double tt = (double)(tr->step + 1);
+        op.lr = (float)lr;
+        op.lr_t = (float)(lr * std::sqrt(1.0 - std::pow((double)o.beta2, tt)) / (1.0 - std::pow((double)o.beta1, tt)));
+        op.beta1 = o.beta1; op.beta2 = o.beta2; op.eps = o.adam_eps; op.momentum = o.momentum;
+        T_HIP(tr, launch_optimizer(op, tr->d_w, tr->d_g, tr->d_m, tr->d_v, tr->nparams, st));
+        tr->step += 1;
+    }
+    if (tr->prof) {
+        T_HIP(tr, hipEventRecord(tr->ev[3], st));
+        tr->pending = true;
+    }
+    return UMX_OK;
+}
+
+int fold_profile(umx_trainer* tr) {
+    if (!tr->pending) return UMX_OK;
+    T_HIP(tr, hipEventSynchronize(tr->ev[3]));
+    float a = 0, b = 0, c = 0;
+    T_HIP(tr, hipEventElapsedTime(&a, tr->ev[0], tr->ev[1]));
+    T_HIP(tr, hipEventElapsedTime(&b, tr->ev[1], tr->ev[2]));
+    T_HIP(tr, hipEventElapsedTime(&c, tr->ev[2], tr->ev[3]));
+    tr->t_fwd += a; tr->t_bwd += b; tr->t_opt += c;
+    tr->t_steps += 1;
+    tr->pending = false;
+    return UMX_OK;
+}
+
+void fill_common(umx_train_options* o) {
+    memset(o, 0, sizeof *o);
+    o->optimizer = UMX_OPT_ADAM;
+    o->momentum = 0.9f;
+    o->beta1 = 0.9f; o->beta2 = 0.999f; o->adam_eps = 1e-8f;
+    o->bn_momentum = 0.99f;
+    o->seed = 1234;
+}
+
+int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
+    const umx_hparams& hp = tr->hp;
+    const int L = hp.nLayers, ks = hp.ks, P = hp.imSize, K = hp.nClasses, B = tr->B;
+    tr->L = L; tr->K = K; tr->P = P;
+    tr->n = {hp.nChannels, hp.nOut0};
+    for (int i = 0; i < L; ++i) tr->n.push_back(tr->n.back() * hp.featMapsFact);
+    const std::vector<int>& n = tr->n;
+    const umx_train_options& o = tr->o;
+
+    // ---- parameter vector layout (== unmicst_amd/model.py tensor_specs, nExtraConvs == 0)
+    size_t pos = 0;
+    auto seg = [&](const std::string& name, size_t cnt, float reg) { tr->segs.push_back({name, pos, cnt, reg}); pos += cnt; return pos - cnt; };
+    std::vector<size_t> bn_d_off(L), bn_u_off(L);
+    size_t bn_b_off, bn_t_off;
+    tr->o_w1.resize(L); tr->o_ws.resize(L); tr->o_wt.resize(L); tr->o_w2.resize(L);
+    char nm[64];
+    for (int i = 0; i < L; ++i) {
+        snprintf(nm, sizeof nm, "ld%d", i);
+        tr->o_w1[i] = seg(std::string(nm) + ".w1", (size_t)ks * ks * n[i] * n[i + 1], 0.f);
+        tr->o_ws[i] = seg(std::string(nm) + ".wshort", (size_t)ks * ks * n[i] * n[i + 1], o.reg_down);
+        bn_d_off[i] = seg(std::string(nm) + ".bn", 4 * (size_t)n[i + 1], 0.f);
+    }
+    tr->o_lb = seg("lb.w", (size_t)ks * ks * n[L] * n[L + 1], o.reg_bottom);
+    bn_b_off = seg("lb.bn", 4 * (size_t)n[L + 1], 0.f);
+    for (int idx = L - 1; idx >= 0; --idx) {
+        snprintf(nm, sizeof nm, "lu%d", idx);
+        tr->o_wt[idx] = seg(std::string(nm) + ".wt", (size_t)ks * ks * n[idx + 1] * n[idx + 2], o.reg_up);
+        tr->o_w2[idx] = seg(std::string(nm) + ".w2", (size_t)ks * ks * (n[idx] + n[idx + 1]) * n[idx + 1], o.reg_up);
+        bn_u_off[idx] = seg(std::string(nm) + ".bn", 4 * (size_t)n[idx + 1], 0.f);
+    }
+    tr->o_lt = seg("lt.w", (size_t)n[1] * K, o.reg_top);
+    bn_t_off = seg("lt.bn", 4 * (size_t)K, 0.f);
+    tr->nparams = pos;
+    if (blob_floats != pos)
+        return tfail(tr, UMX_ERR_BLOB, "weight blob has %zu floats, the graph needs %zu", blob_floats, pos);
+
+    T_TRY(talloc(tr, &tr->d_w, pos));
+    T_HIP(tr, hipMemcpy(tr->d_w, blob, pos * sizeof(float), hipMemcpyHostToDevice));
+    T_TRY(tzero(tr, &tr->d_g, pos));
+    T_TRY(tzero(tr, &tr->d_m, pos));
+    T_TRY(tzero(tr, &tr->d_v, pos));
+
+    // ---- activations
+    tr->ds.assign(L + 1, nullptr);
+    tr->bn_d.resize(L); tr->bn_u.resize(L);
+    tr->us.assign(L, nullptr); tr->cv.assign(L, nullptr); tr->dskip.assign(L, nullptr);
+    size_t max_act = (size_t)B * P * P * std::max(n[0], K);
+    int S = P;
+    for (int i = 0; i < L; ++i) {
+        T_TRY(bn_alloc(tr, tr->bn_d[i], n[i + 1], S, bn_d_off[i]));
+        max_act = std::max(max_act, (size_t)B * S * S * n[i + 1]);
+        T_TRY(talloc(tr, &tr->ds[i + 1], (size_t)B * (S / 2) * (S / 2) * n[i + 1]));
+        if (i + 1 <= L - 1) T_TRY(talloc(tr, &tr->dskip[i + 1], (size_t)B * (S / 2) * (S / 2) * n[i + 1]));
+        S /= 2;
+    }
+    T_TRY(bn_alloc(tr, tr->bn_b, n[L + 1], S, bn_b_off));
+    T_TRY(talloc(tr, &tr->act_b, (size_t)B * S * S * n[L + 1]));
+    max_act = std::max(max_act, (size_t)B * S * S * n[L + 1]);
+    for (int idx = L - 1; idx >= 0; --idx) {
+        S *= 2;
+        T_TRY(talloc(tr, &tr->us[idx], (size_t)B * S * S * n[idx + 1]));
+        T_TRY(bn_alloc(tr, tr->bn_u[idx], n[idx + 1], S, bn_u_off[idx]));
+        T_TRY(talloc(tr, &tr->cv[idx], (size_t)B * S * S * n[idx + 1]));
+        max_act = std::max(max_act, (size_t)B * S * S * n[idx + 1]);
+    }
+    T_TRY(bn_alloc(tr, tr->bn_t, K, P, bn_t_off));
+    T_TRY(talloc(tr, &tr->d_labels, (size_t)B * P * P * K));
+    T_TRY(talloc(tr, &tr->d_weights, (size_t)B * P * P * K));
+    T_TRY(talloc(tr, &tr->d_probs, (size_t)B * P * P * K));
+    T_TRY(talloc(tr, &tr->d_dt, (size_t)B * P * P * K));
+    T_TRY(talloc(tr, &tr->ds[0], (size_t)B * P * P * n[0]));
+    T_TRY(talloc(tr, &tr->DA, max_act));
+    T_TRY(talloc(tr, &tr->DB, max_act));
+    T_TRY(talloc(tr, &tr->DZ, max_act));
+    T_TRY(talloc(tr, &tr->GS, max_act));
+    int maxC = K;
+    for (int v : n) maxC = std::max(maxC, v);
+    tr->part_doubles = std::max<size_t>((size_t)1024 * 2 * maxC, (size_t)1024 * n[1] * K) + 1024;
+    T_TRY(talloc(tr, &tr->d_part, tr->part_doubles));
+    T_TRY(tzero(tr, &tr->d_loss, 2));
+
+    // ---- conv launches
+    tr->c_fwd_d.resize(L); tr->c_dg_d.resize(L); tr->c_T.resize(L); tr->c_fwd_u.resize(L);
+    tr->c_dg_us.resize(L); tr->c_dg_skip.resize(L); tr->c_dg_T.resize(L);
+    tr->wg_d.resize(L); tr->wg_u0.resize(L); tr->wg_u1.resize(L); tr->wg_T.resize(L);
+    const TapSet fwd = same_taps(ks, false), flp = same_taps(ks, true);
+    auto group = [&](int C, size_t w_off, size_t w2_off, int d2, int d3, int transpose, int c_off, const TapSet& ts) {
+        GroupSpec g;
+        g.C = C; g.w_off = w_off; g.w2_off = w2_off; g.d2 = d2; g.d3 = d3; g.transpose = transpose; g.c_off = c_off;
+        g.npar = 1; g.Cblk = std::max(C, 1);
+        g.taps[0] = ts;
+        return g;
+    };
+    double mac_total = 0.0;
+    S = P;
+    for (int i = 0; i < L; ++i) {
+        snprintf(nm, sizeof nm, "ld%d", i);
+        GroupSpec g = group(n[i], tr->o_w1[i], tr->o_ws[i], n[i], n[i + 1], 0, 0, fwd);
+        T_TRY(setup_conv(tr, tr->c_fwd_d[i], nm, S, S, n[i + 1], ACT_NONE, 1, 1, nullptr, nullptr, 1, &g));
+        mac_total += tr->c_fwd_d[i].mac;
+        if (i >= 1) {
+            GroupSpec gd = group(n[i + 1], tr->o_w1[i], tr->o_ws[i], n[i], n[i + 1], 1, 0, flp);
+            T_TRY(setup_conv(tr, tr->c_dg_d[i], nm, S, S, n[i], ACT_NONE, 1, 1, nullptr, nullptr, 1, &gd));
+            mac_total += tr->c_dg_d[i].mac;
+        }
+        T_TRY(setup_wgrad(tr, tr->wg_d[i], nm, S, n[i], n[i], n[i + 1], fwd, {}));
+        mac_total += (double)S * S * ks * ks * n[i] * n[i + 1];
+        S /= 2;
+    }
+    {
+        GroupSpec g = group(n[L], tr->o_lb, SIZE_MAX, n[L], n[L + 1], 0, 0, fwd);
+        T_TRY(setup_conv(tr, tr->c_fwd_b, "lb", S, S, n[L + 1], ACT_NONE, 1, 1, nullptr, nullptr, 1, &g));
+        GroupSpec gd = group(n[L + 1], tr->o_lb, SIZE_MAX, n[L], n[L + 1], 1, 0, flp);
+        T_TRY(setup_conv(tr, tr->c_dg_b, "lb", S, S, n[L], ACT_NONE, 1, 1, nullptr, nullptr, 1, &gd));
+        T_TRY(setup_wgrad(tr, tr->wg_b, "lb", S, n[L], n[L], n[L + 1], fwd, {}));
+        mac_total += tr->c_fwd_b.mac + tr->c_dg_b.mac + (double)S * S * ks * ks * n[L] * n[L + 1];
+    }
+    const int pb = (ks - 2) / 2;   // pad_before of the stride-2 SAME conv whose gradient the transposed conv is
+    for (int idx = L - 1; idx >= 0; --idx) {
+        snprintf(nm, sizeof nm, "lu%d", idx);
+        const int Cskip = n[idx], Cup = n[idx + 1], Cin = n[idx + 2];
+        {   // transposed conv forward: 4 sub-pixel phases (out[2i+a-pb] += in[i] * Wt[a]); LeakyReLU fused
+            GroupSpec g;
+            g.C = Cin; g.w_off = tr->o_wt[idx]; g.w2_off = SIZE_MAX; g.d2 = Cup; g.d3 = Cin; g.transpose = 1; g.c_off = 0;
+            g.npar = 1; g.Cblk = Cin;
+            int oy[4], ox[4];
+            for (int p = 0; p < 4; ++p) {
+                const int pu = p >> 1, pv = p & 1;
+                oy[p] = pu; ox[p] = pv;
+                for (int a = 0; a < ks; ++a) {
+                    if (((a - pb - pu) & 1) != 0) continue;
+                    for (int b = 0; b < ks; ++b) {
+                        if (((b - pb - pv) & 1) != 0) continue;
+                        g.taps[p].off.push_back({(pu + pb - a) / 2, (pv + pb - b) / 2});
+                        g.taps[p].m.push_back(a * ks + b);
+                    }
+                }
+            }
+            T_TRY(setup_conv(tr, tr->c_T[idx], nm, S, S, Cup, ACT_LEAKY, 4, 2, oy, ox, 1, &g));
+            mac_total += (double)S * S * ks * ks * Cin * Cup;
+        }
+        {   // transposed conv backward on the space-to-depth gradient gS[.., (pa,pb)*Cup + c] = dY[2i+pa, 2j+pb, c]:
+            // dX[i] = sum_a dY[2i + a - pb] Wt[a]  ->  q = a - pb = 2*di + pa
+            auto split = [](int q, int* d, int* par) { *par = ((q % 2) + 2) % 2; *d = (q - *par) / 2; };
+            std::vector<std::pair<int, int>> offs;
+            for (int a = 0; a < ks; ++a)
+                for (int b = 0; b < ks; ++b) {
+                    int di, pa, dj, pbb;
+                    split(a - pb, &di, &pa);
+                    split(b - pb, &dj, &pbb);
+                    std::pair<int, int> od{di, dj};
+                    if (std::find(offs.begin(), offs.end(), od) == offs.end()) offs.push_back(od);
+                }
+            GroupSpec g;
+            g.C = 4 * Cup; g.w_off = tr->o_wt[idx]; g.w2_off = SIZE_MAX; g.d2 = Cup; g.d3 = Cin; g.transpose = 0; g.c_off = 0;
+            g.npar = 4; g.Cblk = Cup;
+            g.taps[0].off = offs;
+            g.taps[0].m.assign(offs.size() * 4, -1);
+            TapSet slabs;                 // weight-gradient slabs, grouped by parity block
+            std::vector<int> coff;
+            for (int par = 0; par < 4; ++par)
+                for (int a = 0; a < ks; ++a)
+                    for (int b = 0; b < ks; ++b) {
+                        int di, pa, dj, pbb;
+                        split(a - pb, &di, &pa);
+                        split(b - pb, &dj, &pbb);
+                        if (pa * 2 + pbb != par) continue;
+                        const size_t t = std::find(offs.begin(), offs.end(), std::make_pair(di, dj)) - offs.begin();
+                        g.taps[0].m[t * 4 + par] = a * ks + b;
+                        slabs.off.push_back({di, dj});
+                        slabs.m.push_back(a * ks + b);
+                        coff.push_back(par * Cup);
+                    }
+            T_TRY(setup_conv(tr, tr->c_dg_T[idx], nm, S, S, Cin, ACT_NONE, 1, 1, nullptr, nullptr, 1, &g));
+            T_TRY(setup_wgrad(tr, tr->wg_T[idx], nm, S, 4 * Cup, Cup, Cin, slabs, coff));
+            mac_total += 2.0 * S * S * ks * ks * Cin * Cup;
+        }
+        S *= 2;
+        {
+            GroupSpec g2[2] = {group(Cskip, tr->o_w2[idx], SIZE_MAX, Cskip + Cup, Cup, 0, 0, fwd),
+                               group(Cup, tr->o_w2[idx], SIZE_MAX, Cskip + Cup, Cup, 0, Cskip, fwd)};
+            T_TRY(setup_conv(tr, tr->c_fwd_u[idx], nm, S, S, Cup, ACT_NONE, 1, 1, nullptr, nullptr, 2, g2));
+            mac_total += tr->c_fwd_u[idx].mac;
+            GroupSpec gu = group(Cup, tr->o_w2[idx], SIZE_MAX, Cskip + Cup, Cup, 1, Cskip, flp);
+            T_TRY(setup_conv(tr, tr->c_dg_us[idx], nm, S, S, Cup, ACT_NONE, 1, 1, nullptr, nullptr, 1, &gu));
+            mac_total += tr->c_dg_us[idx].mac;
+            if (idx >= 1) {
+                GroupSpec gk = group(Cup, tr->o_w2[idx], SIZE_MAX, Cskip + Cup, Cup, 1, 0, flp);
+                T_TRY(setup_conv(tr, tr->c_dg_skip[idx], nm, S, S, Cskip, ACT_NONE, 1, 1, nullptr, nullptr, 1, &gk));
+                mac_total += tr->c_dg_skip[idx].mac;
+            }
+            T_TRY(setup_wgrad(tr, tr->wg_u0[idx], nm, S, Cskip, Cskip, Cup, fwd, {}));
+            T_TRY(setup_wgrad(tr, tr->wg_u1[idx], nm, S, Cup, Cup, Cup, fwd, {}));
+            mac_total += (double)S * S * ks * ks * (Cskip + Cup) * Cup;
+        }
+    }
+    mac_total += 3.0 * P * P * n[1] * K;
+    tr->flops_per_image = 2.0 * mac_total;
+    T_TRY(talloc(tr, &tr->d_ws, tr->ws_floats));
+    T_TRY(talloc(tr, &tr->d_packs, tr->packs.size()));
+    T_HIP(tr, hipMemcpy(tr->d_packs, tr->packs.data(), tr->packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
+    return UMX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void umx_train_options_solo(umx_train_options* o) {
+    fill_common(o);
+    o->lr0 = 5e-5f; o->decay_steps = 5000; o->decay_rate = 0.98f;          // UnMicst1-5.py:362-365
+    o->reg_kind = UMX_REG_L1;                                               // :84,125,160,213
+    o->reg_down = o->reg_bottom = o->reg_up = o->reg_top = 0.00008f;
+    o->clip_eps = 1e-7f;                                                    // :369-370
+    o->drop_bottom = 0.35f;                                                 // :139
+}
+
+void umx_train_options_duo(umx_train_options* o) {
+    fill_common(o);
+    o->lr0 = 0.00006f; o->decay_steps = 4000; o->decay_rate = 0.99f;       // UnMicst2.py:357-360
+    o->reg_kind = UMX_REG_L2;                                               // :82,123,158,211
+    o->reg_down = o->reg_bottom = 0.01f;
+    o->reg_up = o->reg_top = 0.005f;
+    o->clip_eps = 0.f;                                                      // :364-366 (no clip)
+    o->drop_down_step = 0.05f; o->drop_bottom = 0.3f;                       // :114,137
+    o->drop_up0 = 0.25f; o->drop_up_step = 0.05f;                           // :203
+}
+
+const char* umx_trainer_last_error(const umx_trainer* tr) { return tr ? tr->err.c_str() : g_terr.c_str(); }
+
+int umx_trainer_create(const umx_hparams* hp, const float* weight_blob, size_t blob_floats, const umx_train_options* opts,
+                       umx_trainer** out) {
+    if (!hp || !weight_blob || !opts || !out) return tfail(nullptr, UMX_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (hp->graph != UMX_GRAPH_V2 || hp->nExtraConvs != 0)
+        return tfail(nullptr, UMX_ERR_INVALID, "the training step covers the v2 graph with nExtraConvs == 0");
+    if (hp->nClasses < 1 || hp->nClasses > 8) return tfail(nullptr, UMX_ERR_INVALID, "nClasses must be 1..8");
+    if (hp->nLayers < 1 || hp->nLayers > 8 || hp->ks % 2 != 1 || hp->ks < 1 || hp->ks > 5 || hp->featMapsFact < 1 ||
+        hp->nChannels < 1 || hp->nOut0 < 1)
+        return tfail(nullptr, UMX_ERR_INVALID, "unsupported hyper-parameters");
+    if ((hp->imSize & (hp->imSize - 1)) || (hp->imSize >> hp->nLayers) < 1)
+        return tfail(nullptr, UMX_ERR_INVALID, "imSize must be a power of two, at least 2^nLayers");
+    for (int i = 0; i < 8; ++i)
+        if (opts->reserved[i]) return tfail(nullptr, UMX_ERR_INVALID, "umx_train_options.reserved must be zero");
+    auto bad_rate = [](float r) { return !(r < 1.0f); };
+    if (bad_rate(opts->drop_bottom) || bad_rate(opts->drop_up0) || bad_rate(opts->drop_down_step * hp->nLayers))
+        return tfail(nullptr, UMX_ERR_INVALID, "dropout rates must be below 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return tfail(nullptr, UMX_ERR_NO_DEVICE, "no HIP device");
+    if (opts->device_ordinal < 0 || opts->device_ordinal >= ndev)
+        return tfail(nullptr, UMX_ERR_INVALID, "device ordinal %d out of range", opts->device_ordinal);
+    umx_trainer* tr = new umx_trainer();
+    tr->hp = *hp;
+    tr->o = *opts;
+    tr->device = opts->device_ordinal;
+    tr->B = opts->batch > 0 ? opts->batch : 8;
+    int rc = UMX_OK;
+    if (hipSetDevice(tr->device) != hipSuccess) rc = tfail(tr, UMX_ERR_HIP, "hipSetDevice failed");
+    if (rc == UMX_OK && hipStreamCreateWithFlags(&tr->stream, hipStreamNonBlocking) != hipSuccess)
+        rc = tfail(tr, UMX_ERR_HIP, "hipStreamCreate failed");
+    if (rc == UMX_OK) rc = build_trainer(tr, weight_blob, blob_floats);
+    if (rc == UMX_OK)
+        for (int i = 0; i < 4; ++i)
+            if (hipEventCreate(&tr->ev[i]) != hipSuccess) rc = tfail(tr, UMX_ERR_HIP, "hipEventCreate failed");
+    if (rc != UMX_OK) {
+        g_terr = tr->err;
+        umx_trainer_destroy(tr);
+        return rc;
+    }
+    *out = tr;
+    return UMX_OK;
+}
+
+void umx_trainer_destroy(umx_trainer* tr) {
+    if (!tr) return;
+    (void)hipSetDevice(tr->device);
+    if (tr->stream) (void)hipStreamSynchronize(tr->stream);
+    for (void* p : tr->allocs) (void)hipFree(p);
+    for (int i = 0; i < 4; ++i)
+        if (tr->ev[i]) (void)hipEventDestroy(tr->ev[i]);
+    if (tr->stream) (void)hipStreamDestroy(tr->stream);
+    delete tr;
+}
+
+int umx_train_step_dev(umx_trainer* tr, const float* data_dev, const float* labels_dev, const float* weights_dev,
+                       int apply_update) {
+    if (!tr || !data_dev || !labels_dev || !weights_dev) return tfail(tr, UMX_ERR_INVALID, "null argument");
+    T_HIP(tr, hipSetDevice(tr->device));
+    T_TRY(fold_profile(tr));
+    float* own = tr->ds[0];
+    const int rc = enqueue_step(tr, data_dev, labels_dev, weights_dev, apply_update != 0);
+    tr->ds[0] = own;
+    return rc;
+}
+
+int umx_trainer_loss(umx_trainer* tr, double* loss3) {
+    if (!tr || !loss3) return tfail(tr, UMX_ERR_INVALID, "null argument");
+    T_HIP(tr, hipSetDevice(tr->device));
+    double h[2] = {0, 0};
+    T_HIP(tr, hipMemcpyAsync(h, tr->d_loss, sizeof h, hipMemcpyDeviceToHost, tr->stream));
+    T_HIP(tr, hipStreamSynchronize(tr->stream));
+    loss3[0] = h[0] + h[1];
+    loss3[1] = h[0];
+    loss3[2] = h[1];
+    return UMX_OK;
+}
+
+int umx_train_step(umx_trainer* tr, const float* data, const float* labels, const float* weights, int apply_update,
+                   double* loss3) {
+    if (!tr || !data || !labels || !weights) return tfail(tr, UMX_ERR_INVALID, "null argument");
+    T_HIP(tr, hipSetDevice(tr->device));
+    const size_t npx = (size_t)tr->B * tr->P * tr->P;
+    T_HIP(tr, hipMemcpyAsync(tr->ds[0], data, npx * tr->n[0] * sizeof(float), hipMemcpyHostToDevice, tr->stream));
+    T_HIP(tr, hipMemcpyAsync(tr->d_labels, labels, npx * tr->K * sizeof(float), hipMemcpyHostToDevice, tr->stream));
+    T_HIP(tr, hipMemcpyAsync(tr->d_weights, weights, npx * tr->K * sizeof(float), hipMemcpyHostToDevice, tr->stream));
+    T_TRY(umx_train_step_dev(tr, tr->ds[0], tr->d_labels, tr->d_weights, apply_update));
+    double l[3];
+    T_TRY(umx_trainer_loss(tr, l));
+    if (loss3) { loss3[0] = l[0]; loss3[1] = l[1]; loss3[2] = l[2]; }
+    return UMX_OK;
+}
+
+int umx_trainer_read(umx_trainer* tr, int which, float* out, size_t n_floats) {
+    if (!tr || !out) return tfail(tr, UMX_ERR_INVALID, "null argument");
+    if (n_floats != tr->nparams) return tfail(tr, UMX_ERR_INVALID, "vector has %zu floats, asked for %zu", tr->nparams, n_floats);
+    const float* src = which == UMX_TV_PARAMS ? tr->d_w : which == UMX_TV_GRADS ? tr->d_g : which == UMX_TV_SLOT_M ? tr->d_m
+                     : which == UMX_TV_SLOT_V ? tr->d_v : nullptr;
+    if (!src) return tfail(tr, UMX_ERR_INVALID, "unknown vector %d", which);
+    T_HIP(tr, hipSetDevice(tr->device));
+    T_HIP(tr, hipStreamSynchronize(tr->stream));
+    T_HIP(tr, hipMemcpy(out, src, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+    return UMX_OK;
+}
+
+int umx_trainer_probs(umx_trainer* tr, float* probs_host) {
+    if (!tr || !probs_host) return tfail(tr, UMX_ERR_INVALID, "null argument");
+    T_HIP(tr, hipSetDevice(tr->device));
+    T_HIP(tr, hipStreamSynchronize(tr->stream));
+    T_HIP(tr, hipMemcpy(probs_host, tr->d_probs, (size_t)tr->B * tr->P * tr->P * tr->K * sizeof(float), hipMemcpyDeviceToHost));
+    return UMX_OK;
+}
+
+int64_t umx_trainer_step_count(const umx_trainer* tr) { return tr ? tr->step : -1; }
+int umx_trainer_batch(const umx_trainer* tr) { return tr ? tr->B : 0; }
+double umx_trainer_flops_per_image(const umx_trainer* tr) { return tr ? tr->flops_per_image : 0.0; }
+
+int umx_trainer_profile(umx_trainer* tr, int enable, double* fwd_ms, double* bwd_ms, double* opt_ms, int* steps) {
+    if (!tr) return tfail(tr, UMX_ERR_INVALID, "null argument");
+    T_HIP(tr, hipSetDevice(tr->device));
+    T_TRY(fold_profile(tr));
+    if (fwd_ms) *fwd_ms = tr->t_fwd;
+    if (bwd_ms) *bwd_ms = tr->t_bwd;
+    if (opt_ms) *opt_ms = tr->t_opt;
+    if (steps) *steps = tr->t_steps;
+    tr->t_fwd = tr->t_bwd = tr->t_opt = 0.0;
+    tr->t_steps = 0;
+    tr->prof = enable != 0;
+    return UMX_OK;
+}
+
+}  // extern "C"

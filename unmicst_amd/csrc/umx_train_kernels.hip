@@ -1,0 +1,773 @@
+// Kernels of the training step of libumx (gfx950 only): weight repacking, batch-statistics BN forward/backward,
+// activation / dropout / max-pool forward and backward, the top layer with the weighted cross-entropy, the weight
+// gradient of a convolution on the fp32 matrix cores, and the optimiser.  The convolutions themselves (forward,
+// input gradient, transposed forward, transposed input gradient on a space-to-depth tensor) run on conv_mfma_f32
+// (umx_kernels.hip) with operands packed by pack_weights_kernel.
+//
+// Every reduction has a fixed summation order (per-thread serial sums, in-block sums in thread order, partials summed
+// in block order, fp64): a step is bit-reproducible from run to run.  No floating-point atomics anywhere.
+#include "umx_kernels.h"
+
+#include <algorithm>
+
+#pragma clang fp contract(off)
+
+namespace umx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------ weight packing
+__global__ void __launch_bounds__(256) pack_weights_kernel(const PackDesc* __restrict__ descs) {
+    const PackDesc& d = descs[blockIdx.y];
+    const size_t n = (size_t)d.ntaps * d.Cp * d.Np;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const int nn = (int)(e % d.Np);
+        const size_t r = e / d.Np;
+        const int c = (int)(r % d.Cp);
+        const int t = (int)(r / d.Cp);
+        float v = 0.f;
+        if (c < d.C && nn < d.N) {
+            const int par = c / d.Cblk, cc = c - par * d.Cblk;
+            const int m = d.mtap[t * d.npar + par];
+            if (m >= 0) {
+                const size_t idx = d.transpose ? ((size_t)m * d.d2 + d.c_off + nn) * d.d3 + cc
+                                               : ((size_t)m * d.d2 + d.c_off + cc) * d.d3 + nn;
+                v = d.w[idx];
+                if (d.w2) v += d.w2[idx];
+            }
+        }
+        d.dst[e] = v;
+    }
+}
+
+hipError_t launch_pack_weights(const PackDesc* descs_dev, int ndesc, size_t max_elems, hipStream_t stream) {
+    if (ndesc <= 0) return hipSuccess;
+    const unsigned gx = (unsigned)std::min<size_t>(512, (max_elems + 255) / 256);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(gx ? gx : 1, (unsigned)ndesc), dim3(256), 0, stream, descs_dev);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ channel layout
+// An NHWC tensor is [N rows][C channels].  A block of Cb*k threads (Cb = min(C, 256), k = 256 / Cb) walks k rows at
+// a time: thread (r, c) always sees channel c, so per-channel sums live in registers and the loads are contiguous.
+struct ChanLayout { int Cb, k, threads, cblocks; };
+static inline ChanLayout chan_layout(int C) {
+    ChanLayout l;
+    l.Cb = std::min(C, 256);
+    l.k = std::max(1, 256 / l.Cb);
+    l.threads = l.Cb * l.k;
+    l.cblocks = (C + 255) / 256;
+    return l;
+}
+
+int chan_blocks(size_t N, int C) {
+    const ChanLayout l = chan_layout(C);
+    const size_t want = N / ((size_t)l.k * 32) + 1;
+    return (int)std::min<size_t>(1024, std::max<size_t>(1, want));
+}
+
+__global__ void __launch_bounds__(256) chan_stats_kernel(const float* __restrict__ x, size_t N, int C, int Cb, int k,
+                                                         double* __restrict__ part) {
+    __shared__ double sm[2][256];
+    const int tid = threadIdx.x;
+    const int r = tid / Cb, cl = tid - r * Cb;
+    const int c = cl + blockIdx.y * 256;
+    const size_t rpb = (N + gridDim.x - 1) / gridDim.x;
+    const size_t r0 = (size_t)blockIdx.x * rpb, r1 = std::min(N, r0 + rpb);
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (size_t row = r0 + r; row < r1; row += k) {
+            const double v = (double)x[row * C + c];
+            s += v;
+            q += v * v;
+        }
+    sm[0][tid] = s;
+    sm[1][tid] = q;
+    __syncthreads();
+    if (r == 0 && c < C) {
+        for (int j = 1; j < k; ++j) { s += sm[0][j * Cb + cl]; q += sm[1][j * Cb + cl]; }
+        part[((size_t)blockIdx.x * 2 + 0) * C + c] = s;
+        part[((size_t)blockIdx.x * 2 + 1) * C + c] = q;
+    }
+}
+
+hipError_t launch_chan_stats(const float* x, size_t N, int C, double* part, int nblk, hipStream_t stream) {
+    const ChanLayout l = chan_layout(C);
+    hipLaunchKernelGGL(chan_stats_kernel, dim3((unsigned)nblk, (unsigned)l.cblocks), dim3((unsigned)l.threads), 0, stream,
+                       x, N, C, l.Cb, l.k, part);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const double* __restrict__ part, int nblk, double N, int C,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* mov_mean, float* mov_var, float momentum,
+                                                          float* __restrict__ stat) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += part[((size_t)b * 2 + 0) * C + c];
+        q += part[((size_t)b * 2 + 1) * C + c];
+    }
+    const double mean = s / N;
+    double var = q / N - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + 1e-3);   // eps of tf.layers.batch_normalization in the reference graphs
+    const double scale = (double)gamma[c] * rstd;
+    stat[c] = (float)mean;
+    stat[C + c] = (float)rstd;
+    stat[2 * C + c] = (float)scale;
+    stat[3 * C + c] = (float)((double)beta[c] - mean * scale);
+    const double mom = (double)momentum;
+    const double unbiased = N > 1.0 ? var * (N / (N - 1.0)) : var;
+    mov_mean[c] = (float)((double)mov_mean[c] * mom + mean * (1.0 - mom));
+    mov_var[c] = (float)((double)mov_var[c] * mom + unbiased * (1.0 - mom));
+}
+
+hipError_t launch_bn_finalize(const double* part, int nblk, size_t N, int C, const float* gamma, const float* beta,
+                              float* mov_mean, float* mov_var, float momentum, float* stat, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, part, nblk, (double)N,
+                       C, gamma, beta, mov_mean, mov_var, momentum, stat);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ dropout stream
+// == oracle/train_oracle.py dropout_mask: u = top 24 bits of mix(key ^ flat NHWC index); keep iff u >= rate
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ float drop_mul(unsigned long long key, size_t idx, float rate, float keep_scale) {
+    if (rate <= 0.f) return 1.f;
+    const unsigned long long h = mix64((unsigned long long)idx ^ key);
+    const float u = (float)(unsigned)(h >> 40) * (1.0f / 16777216.0f);
+    return u >= rate ? keep_scale : 0.f;
+}
+__device__ __forceinline__ float act_of(float v, int act) {
+    if (act == ACT_LEAKY) return v > 0.f ? v : 0.2f * v;
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
+    return v;
+}
+__device__ __forceinline__ float dact_of(float v, int act) {
+    if (act == ACT_LEAKY) return v > 0.f ? 1.f : 0.2f;
+    if (act == ACT_RELU) return v > 0.f ? 1.f : 0.f;
+    return 1.f;
+}
+
+__global__ void __launch_bounds__(256) act_fwd_kernel(const ActParams a, float* __restrict__ out, size_t nout) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nout) return;
+    const int C = a.C;
+    const int c = (int)(e % C);
+    const float sc = a.stat[2 * C + c], sh = a.stat[3 * C + c];
+    const float ks = 1.0f / (1.0f - a.drop_rate);
+    if (!a.pool) {
+        const float v = a.z[e] * sc + sh;
+        out[e] = act_of(v, a.act) * drop_mul(a.drop_key, e, a.drop_rate, ks);
+        return;
+    }
+    size_t r = e / C;
+    const int OW = a.W >> 1, OH = a.H >> 1;
+    const int ox = (int)(r % OW); r /= OW;
+    const int oy = (int)(r % OH);
+    const int b = (int)(r / OH);
+    float best = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const size_t idx = (((size_t)b * a.H + 2 * oy + (j >> 1)) * a.W + 2 * ox + (j & 1)) * C + c;
+        const float v = a.z[idx] * sc + sh;
+        const float y = act_of(v, a.act) * drop_mul(a.drop_key, idx, a.drop_rate, ks);
+        if (j == 0 || y > best) best = y;
+    }
+    out[e] = best;
+}
+
+hipError_t launch_act_fwd(const ActParams& a, float* out, hipStream_t stream) {
+    const size_t nout = (size_t)a.B * (a.pool ? a.H / 2 : a.H) * (a.pool ? a.W / 2 : a.W) * a.C;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, stream, a, out, nout);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) act_bwd_kernel(const ActParams a, const float* __restrict__ dy0,
+                                                      const float* __restrict__ dy1, float* __restrict__ g, size_t Nrows,
+                                                      int Cb, int k, double* __restrict__ part) {
+    __shared__ double sm[2][256];
+    const int tid = threadIdx.x;
+    const int r = tid / Cb, cl = tid - r * Cb;
+    const int C = a.C;
+    const int c = cl + blockIdx.y * 256;
+    const size_t rpb = (Nrows + gridDim.x - 1) / gridDim.x;
+    const size_t r0 = (size_t)blockIdx.x * rpb, r1 = std::min(Nrows, r0 + rpb);
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        const float mean = a.stat[c], rstd = a.stat[C + c], sc = a.stat[2 * C + c], sh = a.stat[3 * C + c];
+        const float ks = 1.0f / (1.0f - a.drop_rate);
+        const int OW = a.W >> 1, OH = a.H >> 1;
+        for (size_t row = r0 + r; row < r1; row += k) {
+            const size_t e = row * C + c;
+            float d = dy0[e];
+            if (dy1) d += dy1[e];
+            if (!a.pool) {
+                const float zz = a.z[e];
+                const float v = zz * sc + sh;
+                const float gg = d * drop_mul(a.drop_key, e, a.drop_rate, ks) * dact_of(v, a.act);
+                g[e] = gg;
+                s1 += (double)gg;
+                s2 += (double)gg * (double)((zz - mean) * rstd);
+            } else {
+                size_t q = row;
+                const int ox = (int)(q % OW); q /= OW;
+                const int oy = (int)(q % OH);
+                const int b = (int)(q / OH);
+                size_t idx[4];
+                float zz[4], dm[4], vv[4];
+                int arg = 0;
+                float best = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    idx[j] = (((size_t)b * a.H + 2 * oy + (j >> 1)) * a.W + 2 * ox + (j & 1)) * C + c;
+                    zz[j] = a.z[idx[j]];
+                    vv[j] = zz[j] * sc + sh;
+                    dm[j] = drop_mul(a.drop_key, idx[j], a.drop_rate, ks);
+                    const float y = act_of(vv[j], a.act) * dm[j];
+                    if (j == 0 || y > best) { best = y; arg = j; }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float gg = j == arg ? d * dm[j] * dact_of(vv[j], a.act) : 0.f;
+                    g[idx[j]] = gg;
+                    if (j == arg) {
+                        s1 += (double)gg;
+                        s2 += (double)gg * (double)((zz[j] - mean) * rstd);
+                    }
+                }
+            }
+        }
+    }
+    sm[0][tid] = s1;
+    sm[1][tid] = s2;
+    __syncthreads();
+    if (r == 0 && c < C) {
+        for (int j = 1; j < k; ++j) { s1 += sm[0][j * Cb + cl]; s2 += sm[1][j * Cb + cl]; }
+        part[((size_t)blockIdx.x * 2 + 0) * C + c] = s1;
+        part[((size_t)blockIdx.x * 2 + 1) * C + c] = s2;
+    }
+}
+
+hipError_t launch_act_bwd(const ActParams& a, const float* dy0, const float* dy1, float* g, double* part, int nblk,
+                          hipStream_t stream) {
+    const ChanLayout l = chan_layout(a.C);
+    const size_t rows = (size_t)a.B * (a.pool ? a.H / 2 : a.H) * (a.pool ? a.W / 2 : a.W);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)nblk, (unsigned)l.cblocks), dim3((unsigned)l.threads), 0, stream, a,
+                       dy0, dy1, g, rows, l.Cb, l.k, part);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const double* __restrict__ part, int nblk, double N, int C,
+                                                              float* dgamma, float* dbeta, float* __restrict__ m12) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s1 += part[((size_t)b * 2 + 0) * C + c];
+        s2 += part[((size_t)b * 2 + 1) * C + c];
+    }
+    m12[c] = (float)(s1 / N);
+    m12[C + c] = (float)(s2 / N);
+    dgamma[c] = (float)s2;
+    dbeta[c] = (float)s1;
+}
+
+hipError_t launch_bn_bwd_finalize(const double* part, int nblk, size_t N, int C, float* dgamma, float* dbeta, float* m12,
+                                  hipStream_t stream) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, part, nblk,
+                       (double)N, C, dgamma, dbeta, m12);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ z,
+                                                           const float* __restrict__ stat, const float* __restrict__ m12,
+                                                           size_t n, int C) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int c = (int)(e % C);
+    const float xh = (z[e] - stat[c]) * stat[C + c];
+    g[e] = stat[2 * C + c] * (g[e] - m12[c] - xh * m12[C + c]);
+}
+
+hipError_t launch_bn_bwd_apply(float* g, const float* z, const float* stat, const float* m12, size_t N, int C,
+                               hipStream_t stream) {
+    const size_t n = N * C;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, z, stat, m12, n, C);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) leaky_bwd_s2d_kernel(const float* __restrict__ d_us, const float* __restrict__ us,
+                                                            int S, int C, float* __restrict__ gS, size_t n) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int c = (int)(e % C);
+    size_t r = e / C;
+    const int q = (int)(r & 3); r >>= 2;
+    const int j = (int)(r % S); r /= S;
+    const int i = (int)(r % S);
+    const size_t b = r / S;
+    const size_t src = ((b * (2 * S) + 2 * i + (q >> 1)) * (size_t)(2 * S) + 2 * j + (q & 1)) * C + c;
+    gS[e] = d_us[src] * (us[src] > 0.f ? 1.f : 0.2f);
+}
+
+hipError_t launch_leaky_bwd_s2d(const float* d_us, const float* us, int B, int S, int C, float* gS, hipStream_t stream) {
+    const size_t n = (size_t)B * S * S * 4 * C;
+    hipLaunchKernelGGL(leaky_bwd_s2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_us, us, S, C, gS, n);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ top layer
+constexpr int kMaxK = 8;
+
+__global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__ x, size_t N, int C, int K,
+                                                       const float* __restrict__ w, float* __restrict__ t0) {
+    extern __shared__ float wl[];   // [C][K]
+    for (int i = threadIdx.x; i < C * K; i += 256) wl[i] = w[i];
+    __syncthreads();
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= N) return;
+    float acc[kMaxK];
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k) acc[k] = 0.f;
+    const float* xp = x + p * C;
+    for (int c = 0; c < C; ++c) {
+        const float v = xp[c];
+#pragma unroll
+        for (int k = 0; k < kMaxK; ++k)
+            if (k < K) acc[k] = fmaf(v, wl[c * K + k], acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k)
+        if (k < K) t0[p * K + k] = acc[k];
+}
+
+hipError_t launch_head_fwd(const float* x, size_t N, int C, int K, const float* w, float* t0, hipStream_t stream) {
+    if (K > kMaxK) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), sizeof(float) * C * K, stream, x, N, C,
+                       K, w, t0);
+    return hipGetLastError();
+}
+
+int loss_blocks(size_t N) { return (int)std::min<size_t>(1024, (N + 255) / 256); }
+
+// reference UnMicst1-5.py:362-367: mean over pixels of -sum_k weights*labels*log(clip(p, eps, 1-eps)); duo: log(p)
+__global__ void __launch_bounds__(256) softmax_loss_kernel(const float* __restrict__ t0, const float* __restrict__ stat,
+                                                           const float* __restrict__ labels,
+                                                           const float* __restrict__ weights, size_t N, int K,
+                                                           float clip_eps, float* __restrict__ probs,
+                                                           float* __restrict__ dt, double* __restrict__ part) {
+    __shared__ double sm[256];
+    double lsum = 0.0;
+    const float invN = (float)(1.0 / (double)N);
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < N; p += (size_t)gridDim.x * 256) {
+        float t[kMaxK], pr[kMaxK], dp[kMaxK];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < kMaxK; ++k)
+            if (k < K) { t[k] = t0[p * K + k] * stat[2 * K + k] + stat[3 * K + k]; mx = fmaxf(mx, t[k]); }
+        float den = 0.f;
+#pragma unroll
+        for (int k = 0; k < kMaxK; ++k)
+            if (k < K) { pr[k] = expf(t[k] - mx); den += pr[k]; }
+        float dot = 0.f, L = 0.f;
+#pragma unroll
+        for (int k = 0; k < kMaxK; ++k)
+            if (k < K) {
+                pr[k] = pr[k] / den;
+                const float wy = weights[p * K + k] * labels[p * K + k];
+                float pc = pr[k];
+                bool pass = true;
+                if (clip_eps > 0.f) {
+                    pass = pc >= clip_eps && pc <= 1.0f - clip_eps;
+                    pc = fminf(fmaxf(pc, clip_eps), 1.0f - clip_eps);
+                }
+                L -= wy * logf(pc);
+                dp[k] = (pass && wy != 0.f) ? -wy / pc : 0.f;
+                dot += dp[k] * pr[k];
+                if (probs) probs[p * K + k] = pr[k];
+            }
+#pragma unroll
+        for (int k = 0; k < kMaxK; ++k)
+            if (k < K) dt[p * K + k] = pr[k] * (dp[k] - dot) * invN;
+        lsum += (double)L;
+    }
+    sm[threadIdx.x] = lsum;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+}
+
+hipError_t launch_softmax_loss(const float* t0, const float* stat, const float* labels, const float* weights, size_t N,
+                               int K, float clip_eps, float* probs, float* dt, double* part, int nblk, hipStream_t stream) {
+    if (K > kMaxK) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(softmax_loss_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, t0, stat, labels, weights, N, K,
+                       clip_eps, probs, dt, part);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dt0,
+                                                       const float* __restrict__ w, size_t N, int C, int K, int Cb, int k,
+                                                       float* __restrict__ dx, double* __restrict__ part) {
+    __shared__ double sm[kMaxK][256];
+    const int tid = threadIdx.x;
+    const int r = tid / Cb, cl = tid - r * Cb;
+    const int c = cl + blockIdx.y * 256;
+    const size_t rpb = (N + gridDim.x - 1) / gridDim.x;
+    const size_t r0 = (size_t)blockIdx.x * rpb, r1 = std::min(N, r0 + rpb);
+    double acc[kMaxK];
+    float wk[kMaxK];
+#pragma unroll
+    for (int j = 0; j < kMaxK; ++j) { acc[j] = 0.0; wk[j] = (c < C && j < K) ? w[c * K + j] : 0.f; }
+    if (c < C)
+        for (size_t row = r0 + r; row < r1; row += k) {
+            const float xv = x[row * C + c];
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < kMaxK; ++j)
+                if (j < K) {
+                    const float g = dt0[row * K + j];
+                    acc[j] += (double)xv * (double)g;
+                    d = fmaf(g, wk[j], d);
+                }
+            dx[row * C + c] = d;
+        }
+#pragma unroll
+    for (int j = 0; j < kMaxK; ++j) sm[j][tid] = acc[j];
+    __syncthreads();
+    if (r == 0 && c < C) {
+#pragma unroll
+        for (int j = 0; j < kMaxK; ++j)
+            if (j < K) {
+                double s = acc[j];
+                for (int i = 1; i < k; ++i) s += sm[j][i * Cb + cl];
+                part[((size_t)blockIdx.x * C + c) * K + j] = s;
+            }
+    }
+}
+
+hipError_t launch_head_bwd(const float* x, const float* dt0, const float* w, size_t N, int C, int K, float* dx,
+                           double* part, int nblk, hipStream_t stream) {
+    if (K > kMaxK) return hipErrorInvalidValue;
+    const ChanLayout l = chan_layout(C);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)nblk, (unsigned)l.cblocks), dim3((unsigned)l.threads), 0, stream, x,
+                       dt0, w, N, C, K, l.Cb, l.k, dx, part);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ float reg_grad(float w, int kind, float c) {
+    if (kind == 1) return w > 0.f ? c : (w < 0.f ? -c : 0.f);
+    if (kind == 2) return 2.0f * c * w;
+    return 0.f;
+}
+
+__global__ void __launch_bounds__(256) reduce_partials_kernel(const double* __restrict__ part, int nblk, int n,
+                                                              double scale, float* __restrict__ dst,
+                                                              const float* __restrict__ w, int reg_kind, float reg_c) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * n + i];
+    float v = (float)(s * scale);
+    if (w && reg_kind) v += reg_grad(w[i], reg_kind, reg_c);
+    dst[i] = v;
+}
+
+hipError_t launch_reduce_partials(const double* part, int nblk, int n, double scale, float* dst, const float* w,
+                                  int reg_kind, float reg_c, hipStream_t stream) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part, nblk, n, scale,
+                       dst, w, reg_kind, reg_c);
+    return hipGetLastError();
+}
+
+__global__ void sum_to_scalar_kernel(const double* __restrict__ part, int n, double scale, double* out, int slot,
+                                     int accumulate) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += part[i];
+    s *= scale;
+    out[slot] = accumulate ? out[slot] + s : s;
+}
+
+hipError_t launch_sum_to_scalar(const double* part, int n, double scale, double* out, int slot, int accumulate,
+                                hipStream_t stream) {
+    hipLaunchKernelGGL(sum_to_scalar_kernel, dim3(1), dim3(1), 0, stream, part, n, scale, out, slot, accumulate);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) reg_partials_kernel(const float* __restrict__ w, size_t n, int kind,
+                                                           double* __restrict__ part) {
+    __shared__ double sm[256];
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double v = (double)w[i];
+        s += kind == 1 ? fabs(v) : v * v;
+    }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) sm[threadIdx.x] += sm[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+}
+
+hipError_t launch_reg_partials(const float* w, size_t n, int kind, double* part, hipStream_t stream) {
+    hipLaunchKernelGGL(reg_partials_kernel, dim3(64), dim3(256), 0, stream, w, n, kind, part);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// GEMM view: M = input channels of a slab (32 per workgroup), N = output channels (64 per workgroup, 16 per wave),
+// K = pixels.  A workgroup walks pixel tiles of 128 pixels (imgs x TH x TW) of its slice: the X halo tile and the G
+// tile are staged in LDS once and serve every slab (filter tap) of the group -- 9 taps x 2 channel tiles = 18
+// accumulator tiles per wave, one ds_read_b32 per MFMA.  LDS pitches (48 / 80 floats per pixel) put the four pixels
+// of a 16x16x4 fragment on disjoint bank quarters.  Partial sums go to ws[slice]; wgrad_reduce_kernel adds the slices
+// in order.
+constexpr int kWgCI = 32, kWgCO = 64, kWgPX = 48, kWgPG = 80, kWgNS = 9, kWgPix = 128;
+
+__global__ void __launch_bounds__(256, 2) wgrad_mfma_f32(const WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const Xl = smem;                      // [nhalo][kWgPX]
+    float* const Gl = smem + p.nhalo * kWgPX;    // [128][kWgPG]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = lane >> 4, li = lane & 15;
+    const int TW = 1 << p.tw_log2, TH = 1 << p.th_log2;
+
+    const int slice = blockIdx.x;
+    const int nco = (p.Cg + kWgCO - 1) / kWgCO;
+    const int ci0 = (blockIdx.y / nco) * kWgCI, co0 = (blockIdx.y % nco) * kWgCO;
+    const int slab0 = p.gstart[blockIdx.z], ns = p.gcount[blockIdx.z];
+    const int coff = p.coff[slab0];
+    const bool wave_live = co0 + wave * 16 < p.Cg;
+
+    f32x4 acc[kWgNS][2];
+#pragma unroll
+    for (int s = 0; s < kWgNS; ++s) { acc[s][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[s][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    const int t_end = min(p.ntiles, (slice + 1) * p.tiles_per_slice);
+    for (int t = slice * p.tiles_per_slice; t < t_end; ++t) {
+        const int tx = t % p.tiles_x;
+        const int ty = (t / p.tiles_x) % p.tiles_y;
+        const int img0 = (t / (p.tiles_x * p.tiles_y)) * p.imgs;
+        const int y0 = ty * TH, x0 = tx * TW;
+        __syncthreads();   // the previous tile's fragment reads are done
+        for (int e = tid; e < p.nhalo * (kWgCI / 4); e += 256) {
+            const int hp = e >> 3, q = e & 7;
+            const int il = hp / p.imgplane;
+            const int rr = hp - il * p.imgplane;
+            const int hy = rr / p.hw, hx = rr - hy * p.hw;
+            const int gy = y0 + p.ymin + hy, gx = x0 + p.xmin + hx, img = img0 + il;
+            const int c = ci0 + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (img < p.B && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && c < p.Cx) {
+                const float* src = p.X + ((size_t)(img * p.H + gy) * p.W + gx) * p.Cxt + coff + c;
+                if (p.vecx && c + 3 < p.Cx) v = *reinterpret_cast<const float4*>(src);
+                else {
+                    v.x = src[0];
+                    if (c + 1 < p.Cx) v.y = src[1];
+                    if (c + 2 < p.Cx) v.z = src[2];
+                    if (c + 3 < p.Cx) v.w = src[3];
+                }
+            }
+            *reinterpret_cast<float4*>(Xl + hp * kWgPX + 4 * q) = v;
+        }
+        for (int e = tid; e < kWgPix * (kWgCO / 4); e += 256) {
+            const int px = e >> 4, q = e & 15;
+            const int il = px >> (p.th_log2 + p.tw_log2);
+            const int y = (px >> p.tw_log2) & (TH - 1), x = px & (TW - 1);
+            const int img = img0 + il;
+            const int co = co0 + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (img < p.B && co < p.Cg) {
+                const float* src = p.G + ((size_t)(img * p.H + y0 + y) * p.W + x0 + x) * p.Cg + co;
+                if (p.vecg && co + 3 < p.Cg) v = *reinterpret_cast<const float4*>(src);
+                else {
+                    v.x = src[0];
+                    if (co + 1 < p.Cg) v.y = src[1];
+                    if (co + 2 < p.Cg) v.z = src[2];
+                    if (co + 3 < p.Cg) v.w = src[3];
+                }
+            }
+            *reinterpret_cast<float4*>(Gl + px * kWgPG + 4 * q) = v;
+        }
+        __syncthreads();
+        if (wave_live) {
+            for (int ks = 0; ks < kWgPix / 4; ++ks) {
+                const int px = 4 * ks + kq;
+                const int il = px >> (p.th_log2 + p.tw_log2);
+                const int y = (px >> p.tw_log2) & (TH - 1), x = px & (TW - 1);
+                const float* ap = Xl + (il * p.imgplane + y * p.hw + x) * kWgPX + li;
+                const float b = Gl[px * kWgPG + wave * 16 + li];
+#pragma unroll
+                for (int s = 0; s < kWgNS; ++s) {
+                    if (s < ns) {
+                        const int so = ((p.dy[slab0 + s] - p.ymin) * p.hw + (p.dx[slab0 + s] - p.xmin)) * kWgPX;
+                        acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[so], b, acc[s][0], 0, 0, 0);
+                        acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[so + 16], b, acc[s][1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // D tile: row (input channel) = 4*kq + r, column (output channel) = li
+    const size_t slab_sz = (size_t)p.Cx * p.Cg;
+    const int co = co0 + wave * 16 + li;
+#pragma unroll
+    for (int s = 0; s < kWgNS; ++s) {
+        if (s < ns && co < p.Cg) {
+            float* dst = p.ws + ((size_t)slice * p.nslab + slab0 + s) * slab_sz;
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = ci0 + t2 * 16 + 4 * kq + r;
+                    if (ci < p.Cx) dst[(size_t)ci * p.Cg + co] = acc[s][t2][r];
+                }
+        }
+    }
+}
+
+bool wgrad_setup(WgradParams* p, std::string* why) {
+    auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    if (p->nslab < 1 || p->nslab > kWgMaxSlabs) { *why = "wgrad: too many filter taps"; return false; }
+    const int TW = std::min(16, p->W), TH = std::min(8, p->H);
+    if ((TW & (TW - 1)) || (TH & (TH - 1)) || p->H % TH || p->W % TW || kWgPix % (TH * TW)) {
+        *why = "wgrad: layer size must be a power of two";
+        return false;
+    }
+    p->tw_log2 = lg2(TW);
+    p->th_log2 = lg2(TH);
+    p->imgs = kWgPix / (TH * TW);
+    int ymin = 0, ymax = 0, xmin = 0, xmax = 0;
+    for (int s = 0; s < p->nslab; ++s) {
+        ymin = std::min<int>(ymin, p->dy[s]); ymax = std::max<int>(ymax, p->dy[s]);
+        xmin = std::min<int>(xmin, p->dx[s]); xmax = std::max<int>(xmax, p->dx[s]);
+    }
+    p->ymin = ymin;
+    p->xmin = xmin;
+    p->hh = TH + ymax - ymin;
+    p->hw = TW + xmax - xmin;
+    p->imgplane = p->hh * p->hw;
+    p->nhalo = p->imgs * p->imgplane;
+    p->tiles_y = p->H / TH;
+    p->tiles_x = p->W / TW;
+    p->ntiles = ((p->B + p->imgs - 1) / p->imgs) * p->tiles_y * p->tiles_x;
+    // slab groups: runs of <= 9 consecutive slabs with one channel offset
+    p->ngroups = 0;
+    for (int s = 0; s < p->nslab;) {
+        int n = 1;
+        while (s + n < p->nslab && n < kWgNS && p->coff[s + n] == p->coff[s]) ++n;
+        p->gstart[p->ngroups] = (short)s;
+        p->gcount[p->ngroups] = (short)n;
+        ++p->ngroups;
+        s += n;
+    }
+    const int chunks = ((p->Cx + kWgCI - 1) / kWgCI) * ((p->Cg + kWgCO - 1) / kWgCO) * p->ngroups;
+    int nslices = std::max(1, std::min(p->ntiles, 1024 / std::max(1, chunks)));
+    p->tiles_per_slice = (p->ntiles + nslices - 1) / nslices;
+    p->nslices = (p->ntiles + p->tiles_per_slice - 1) / p->tiles_per_slice;
+    p->vecx = (p->Cxt % 4 == 0);
+    for (int s = 0; s < p->nslab; ++s)
+        if (p->coff[s] % 4) p->vecx = 0;
+    p->vecg = (p->Cg % 4 == 0);
+    const size_t lds = sizeof(float) * ((size_t)p->nhalo * kWgPX + (size_t)kWgPix * kWgPG);
+    if (lds > 160 * 1024) { *why = "wgrad: halo too large for the LDS"; return false; }
+    return true;
+}
+
+size_t wgrad_ws_floats(const WgradParams& p) { return (size_t)p.nslices * p.nslab * p.Cx * p.Cg; }
+
+hipError_t launch_wgrad(const WgradParams& p, hipStream_t stream) {
+    const size_t lds = sizeof(float) * ((size_t)p.nhalo * kWgPX + (size_t)kWgPix * kWgPG);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_f32),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const unsigned chunks = (unsigned)(((p.Cx + kWgCI - 1) / kWgCI) * ((p.Cg + kWgCO - 1) / kWgCO));
+    hipLaunchKernelGGL(wgrad_mfma_f32, dim3((unsigned)p.nslices, chunks, (unsigned)p.ngroups), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+struct WgReduce {
+    const float* ws;
+    int nslices, nslab, Cx, Cg, Ctot, c_off;
+    float* g;
+    const float* w;
+    int reg_kind;
+    float reg_c;
+    float* g2;
+    short mslab[kWgMaxSlabs];
+};
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WgReduce q) {
+    const size_t n = (size_t)q.nslab * q.Cx * q.Cg;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    double s = 0.0;
+    for (int sl = 0; sl < q.nslices; ++sl) s += (double)q.ws[(size_t)sl * n + e];
+    const int co = (int)(e % q.Cg);
+    const size_t r = e / q.Cg;
+    const int ci = (int)(r % q.Cx);
+    const int sb = (int)(r / q.Cx);
+    const size_t o = ((size_t)q.mslab[sb] * q.Ctot + q.c_off + ci) * q.Cg + co;
+    float v = (float)s;
+    if (q.g2) q.g2[o] = v;
+    if (q.w && q.reg_kind) v += reg_grad(q.w[o], q.reg_kind, q.reg_c);
+    q.g[o] = v;
+}
+
+hipError_t launch_wgrad_reduce(const WgradParams& p, int Ctot, int c_off, float* g, const float* w, int reg_kind,
+                               float reg_c, float* g2, hipStream_t stream) {
+    WgReduce q;
+    q.ws = p.ws; q.nslices = p.nslices; q.nslab = p.nslab; q.Cx = p.Cx; q.Cg = p.Cg; q.Ctot = Ctot; q.c_off = c_off;
+    q.g = g; q.w = w; q.reg_kind = reg_kind; q.reg_c = reg_c; q.g2 = g2;
+    for (int s = 0; s < kWgMaxSlabs; ++s) q.mslab[s] = s < p.nslab ? p.mslab[s] : 0;
+    const size_t n = (size_t)p.nslab * p.Cx * p.Cg;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, q);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ optimiser
+// Adam as tf.train.AdamOptimizer applies it (reference UnMicst1-5.py:371): m, v slots, lr_t = lr*sqrt(1-b2^t)/(1-b1^t)
+// formed on the host, w -= lr_t * m / (sqrt(v) + eps).  Momentum as tf.train.MomentumOptimizer (UnMicst.py:279).
+// Positions whose gradient is always zero (BN moving statistics) are left untouched by both rules.
+__global__ void __launch_bounds__(256) optimizer_kernel(const OptParams o, float* __restrict__ w,
+                                                        const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    if (o.kind == 0) {
+        const float mi = o.beta1 * m[i] + (1.0f - o.beta1) * gi;
+        const float vi = o.beta2 * v[i] + (1.0f - o.beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        w[i] = w[i] - o.lr_t * mi / (sqrtf(vi) + o.eps);
+    } else {
+        const float mi = o.momentum * m[i] + gi;
+        m[i] = mi;
+        w[i] = w[i] - o.lr * mi;
+    }
+}
+
+hipError_t launch_optimizer(const OptParams& o, float* w, const float* g, float* m, float* v, size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(optimizer_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, o, w, g, m, v, n);
+    return hipGetLastError();
+}
+
+}  // namespace umx
