@@ -73,7 +73,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="wsi-synth256", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="wsi-synth256", choices=sorted(WORKLOADS) + ["train-synth256"])
+    ap.add_argument("--train-batch", type=int, default=8, help="train-synth256: images per optimisation step")
     ap.add_argument("--batch", type=int, default=256, help="tiles per UNet launch group")
     ap.add_argument("--precision", default="default", choices=["default", "f32", "f16x3"],
                     help="conv arithmetic: exact fp32 MFMA, or 3 binary16 MFMA products per fp32 product (default)")
@@ -90,6 +91,8 @@ def main():
     import torch.distributed as dist
     from unmicst_amd import model, sharding, umx
 
+    if args.workload == "train-synth256":
+        return bench_train(args, torch)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -217,6 +220,91 @@ def main():
     eng.close()
     if sharded:
         dist.destroy_process_group()
+
+
+def bench_train(args, torch):
+    """BASELINE.json configs[4]: forward + backward + Adam on random 256x256x2 batches (synthetic-256 hp, the duo
+    script's regime), 1 x MI355X.  A step = one umx_train_step on device-resident batches.  Not the headline metric:
+    select it with --workload train-synth256.  N > 1 would need a gradient all-reduce the reference does not have
+    (it trains on one GPU): replicas only, not run here."""
+    from unmicst_amd import model, trainer
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+        print("bench.py: the training workload runs on one GPU (the reference trains on one)", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a MI355X (there is no CPU fallback)", file=sys.stderr)
+        sys.exit(3)
+    dev = torch.device("cuda", 0)
+    hp = model.KNOWN_HP["synthetic-256"]
+    blob = model.random_blob(hp, seed=20260101)
+    B = args.train_batch
+    opts = trainer.duo_options()
+    tr = trainer.Trainer(hp, blob, opts, batch=B, device=0)
+    g = torch.Generator(device="cpu").manual_seed(20260101)
+    nb = 4                                       # distinct batches, cycled
+    data = torch.randn((nb, B, hp.imSize, hp.imSize, hp.nChannels), generator=g).to(dev)
+    cls = torch.randint(0, hp.nClasses, (nb, B, hp.imSize, hp.imSize), generator=g)
+    labels = torch.nn.functional.one_hot(cls, hp.nClasses).float().to(dev)
+    weights = (0.5 + 2.5 * torch.rand((nb, B, hp.imSize, hp.imSize, hp.nClasses), generator=g)).to(dev)
+    torch.cuda.synchronize(dev)
+
+    def step(i):
+        j = i % nb
+        tr.step_dev(data[j].data_ptr(), labels[j].data_ptr(), weights[j].data_ptr())
+
+    for i in range(args.warmup):
+        step(i)
+    first = tr.loss()[0]
+    tr.profile(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    last = tr.loss()[0]                          # synchronises the trainer's stream
+    elapsed = time.perf_counter() - t0
+    ph = tr.profile(False)
+    flops_step = tr.flops_per_image * B
+    tflops = flops_step * args.steps / elapsed / 1e12
+    cpu = None
+    if args.cpu_seconds > 0:
+        cpu = cpu_baseline_train(hp, blob, data[0].cpu().numpy(), labels[0].cpu().numpy(), weights[0].cpu().numpy(),
+                                 args.cpu_seconds)
+    line = {
+        "metric": "training images/sec (%dx%dx%d) forward+backward+Adam" % (hp.imSize, hp.imSize, hp.nChannels),
+        "value": round(B * args.steps / elapsed, 3), "unit": "images/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "train-synth256: synthetic-256 hp (v2 graph, seeded weights), batch %d, duo regime "
+                               "(Adam 6e-5, L2, dropout), random 256x256x2 batches resident in HBM" % B,
+                   "batch": B, "flop_per_image": tr.flops_per_image, "loss_first": first, "loss_last": last,
+                   "phase_ms_per_step": {k: round(v / max(ph["steps"], 1), 3) for k, v in ph.items() if k != "steps"}},
+        # whole step against the fp32 matrix peak: forward + input-gradient + weight-gradient convolutions are
+        # ~all of the algorithmic FLOPs; the element-wise BN/activation passes are HBM-bound and show up as lost fraction
+        "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "kernel": "whole training step",
+                     "flop_per_launch": flops_step},
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(line))
+    tr.close()
+
+
+def cpu_baseline_train(hp, blob, data, labels, weights, budget_s):
+    """The training oracle (torch autograd on the host cores, float32) on the first images of the same batch."""
+    import torch
+    from oracle import train_oracle as to
+    n = 1
+    o = to.duo_options()
+    t = time.perf_counter()
+    to.loss_and_grads(hp, blob, data[:n], labels[:n], weights[:n], o, 0, dtype=torch.float32)
+    dt = time.perf_counter() - t
+    if dt < budget_s / 3 and data.shape[0] >= 2:
+        n = int(min(data.shape[0], max(2, budget_s / dt / 2)))
+        t = time.perf_counter()
+        to.loss_and_grads(hp, blob, data[:n], labels[:n], weights[:n], o, 0, dtype=torch.float32)
+        dt = time.perf_counter() - t
+    return {"value": round(n / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "forward+backward of %d image(s) of the same batch (oracle/train_oracle.py, torch CPU float32, no "
+                      "optimiser update), %.1f s" % (n, dt)}
 
 
 def cpu_baseline(hp, blob, band, mean, std, budget_s):

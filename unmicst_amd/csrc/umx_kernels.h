@@ -45,6 +45,9 @@ struct ConvParams {
     const float* post_s;
     const float* post_b;
     int act;                             // 0 none, 1 ReLU, 2 LeakyReLU(0.2)
+    int ksplit;                          // > 1 (training, small batches): the K loop is split over ksplit workgroups by
+    size_t split_stride;                 // input-channel chunk; workgroup s writes raw partial sums to dst + s*split_stride
+                                         // (no epilogue, no pool) and launch_split_reduce adds them in order
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
@@ -206,8 +209,10 @@ hipError_t launch_reduce_partials(const double* part, int nblk, int n, double sc
 // out[slot] (+)= scale * sum part[0..n)
 hipError_t launch_sum_to_scalar(const double* part, int n, double scale, double* out, int slot, int accumulate,
                                 hipStream_t stream);
-// part[blk] = sum |w| (kind 1) or sum w^2 (kind 2) -- 64 blocks
-hipError_t launch_reg_partials(const float* w, size_t n, int kind, double* part, hipStream_t stream);
+// out[slot] += sum over the segments of coef * (sum |w| (kind 1) or sum w^2 (kind 2)); part: 64 doubles per segment
+struct RegSeg { const float* w; size_t n; float coef; };
+hipError_t launch_reg_loss(const RegSeg* segs_dev, int nseg, int kind, double* part, double* out, int slot,
+                           hipStream_t stream);
 
 // weight gradient of a convolution on the fp32 matrix cores:  dW[s][ci][co] = sum_p X[p + (dy_s,dx_s)][coff_s + ci] * G[p][co]
 constexpr int kWgMaxSlabs = 32;
@@ -224,6 +229,7 @@ struct WgradParams {
     int tw_log2, th_log2, imgs;   // pixel tile = imgs x TH x TW = 128 pixels
     int hh, hw, imgplane, nhalo, ymin, xmin, tiles_y, tiles_x;
     int ntiles, tiles_per_slice, nslices;
+    int mi;                       // input-channel tiles (of 16) per workgroup: 1..3
     int vecx, vecg;               // 16-byte loads allowed
     float* ws;                    // [slice][slab][Cx][Cg]
 };
@@ -238,6 +244,9 @@ struct OptParams {
     int kind;                 // 0 Adam, 1 Momentum
     float lr, lr_t, beta1, beta2, eps, momentum;
 };
+// dst[i] = act(sum_s part[s*stride + i]) : the second half of a K-split convolution
+hipError_t launch_split_reduce(const float* part, int nsplit, size_t stride, size_t n, int act, float* dst,
+                               hipStream_t stream);
 hipError_t launch_optimizer(const OptParams& o, float* w, const float* g, float* m, float* v, size_t n, hipStream_t stream);
 
 __host__ __device__ inline uint16_t double_to_half_rne(double d);

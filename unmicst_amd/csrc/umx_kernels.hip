@@ -51,7 +51,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32(const ConvParams p) {
     const int ty_i = bid % p.tiles_y; bid /= p.tiles_y;
     const int img0 = bid * p.imgs;
     const int y0 = ty_i * TH, x0 = tx_i * TWm;
-    const int nblk = blockIdx.y;
+    const int ksn = p.ksplit > 1 ? p.ksplit : 1;
+    const int nblk = blockIdx.y / ksn;
+    const int ksi = blockIdx.y - nblk * ksn;   // K split: this workgroup takes channel chunks ksi, ksi + ksn, ...
     const ConvPhase& ph = p.ph[blockIdx.z];
 
     // ---- per-thread halo staging slots (constant for the whole kernel)
@@ -93,14 +95,17 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32(const ConvParams p) {
     // ---- stage iterator: (group, channel chunk, tap group)
     struct Stage { int g, c0, t0; };
     auto stage_valid = [&](const Stage& s) { return s.g < p.ngroups; };
+    auto stage_skip = [&](Stage s) {   // move past groups without taps in this phase / without a chunk for this split
+        while (s.g < p.ngroups && (ph.ntaps[s.g] == 0 || s.c0 >= p.Cp[s.g])) { s.g += 1; s.c0 = ksi * kCC; }
+        return s;
+    };
     auto stage_next = [&](Stage s) {
         s.t0 += kTapG;
         if (s.t0 >= ph.ntaps[s.g]) {
             s.t0 = 0;
-            s.c0 += kCC;
-            if (s.c0 >= p.Cp[s.g]) { s.c0 = 0; s.g += 1; }
+            s.c0 += kCC * ksn;
         }
-        return s;
+        return stage_skip(s);
     };
 
     float4 hreg[HPIX][2];
@@ -187,15 +192,13 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32(const ConvParams p) {
         }
     };
 
-    Stage cur = {0, 0, 0};
-    while (stage_valid(cur) && ph.ntaps[cur.g] == 0) { cur.g += 1; }  // (a phase may have no taps in a group)
+    Stage cur = stage_skip(Stage{0, ksi * kCC, 0});  // (a phase may have no taps in a group)
     if (stage_valid(cur)) load_stage(cur);
     while (stage_valid(cur)) {
         __syncthreads();  // previous stage's LDS reads are done
         store_stage(cur);
         __syncthreads();
         Stage nxt = stage_next(cur);
-        while (stage_valid(nxt) && ph.ntaps[nxt.g] == 0) { nxt.g += 1; }
         if (stage_valid(nxt)) load_stage(nxt);  // in flight during the MFMA block below
 
         const int g = cur.g;
@@ -247,6 +250,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32(const ConvParams p) {
                 acc[m][n][r] = v * qs[n] + qb[n];
             }
 
+    float* const dstp = p.dst + (size_t)ksi * p.split_stride;
     if (p.pool) {
 #pragma unroll
         for (int m = 0; m < kMT; m += 2) {
@@ -258,7 +262,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32(const ConvParams p) {
                 const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
                 const int oy = (y0 + ty) >> 1, ox = (x0 + (i & (TWm - 1))) >> 1;
                 if (img < p.B) {
-                    float* d = p.dst + ((size_t)(img * p.outH + oy) * p.outW + ox) * p.Cout;
+                    float* d = dstp + ((size_t)(img * p.outH + oy) * p.outW + ox) * p.Cout;
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
                         const int co = ncol0 + n * 16;
@@ -280,7 +284,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32(const ConvParams p) {
                 const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
                 const int oy = (y0 + ty) * p.o_mul + ph.oy_off, ox = (x0 + (i & (TWm - 1))) * p.o_mul + ph.ox_off;
                 if (img < p.B) {
-                    float* d = p.dst + ((size_t)(img * p.outH + oy) * p.outW + ox) * p.Cout;
+                    float* d = dstp + ((size_t)(img * p.outH + oy) * p.outW + ox) * p.Cout;
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
                         const int co = ncol0 + n * 16;
@@ -295,7 +299,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32(const ConvParams p) {
 template <int NT>
 static hipError_t launch_conv_nt(const ConvParams& p, int hpix, hipStream_t stream) {
     const int img_groups = (p.B + p.imgs - 1) / p.imgs;
-    dim3 grid((unsigned)(img_groups * p.tiles_y * p.tiles_x), (unsigned)((p.Np / 16 + NT - 1) / NT), (unsigned)p.nphase);
+    const int ksn = p.ksplit > 1 ? p.ksplit : 1;
+    dim3 grid((unsigned)(img_groups * p.tiles_y * p.tiles_x), (unsigned)(((p.Np / 16 + NT - 1) / NT) * ksn),
+              (unsigned)p.nphase);
     const size_t lds = conv_lds_bytes(NT, p.plane);
     auto go = [&](auto kern) -> hipError_t {
         if (lds > 48 * 1024) {  // opt in to large dynamic LDS (160 KiB per CU on gfx950)

@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -80,6 +81,7 @@ struct umx_trainer {
     double* d_part = nullptr;  size_t part_doubles = 0;
     double* d_loss = nullptr;           // [0] data term, [1] regularisation
     float* d_ws = nullptr;  size_t ws_floats = 0;
+    float* d_split = nullptr;  size_t split_floats = 0;   // partial outputs of K-split convolutions
     // launches
     std::vector<TConv> c_fwd_d, c_dg_d, c_T, c_fwd_u, c_dg_us, c_dg_skip, c_dg_T;
     TConv c_fwd_b, c_dg_b;
@@ -87,6 +89,7 @@ struct umx_trainer {
     WgradParams wg_b;
     std::vector<PackDesc> packs;
     PackDesc* d_packs = nullptr;
+    RegSeg* d_regsegs = nullptr;  int n_regsegs = 0;
     size_t max_pack = 0;
     double flops_per_image = 0.0;
     // profiling
@@ -140,15 +143,20 @@ int tzero(umx_trainer* tr, T** out, size_t count) {
     return UMX_OK;
 }
 
-void choose_nt(int Cout, int* nt, int* Np) {
+// N-tiles per workgroup.  A training batch is small (8 images): the deep layers have a handful of 256-pixel M-tiles, so
+// wide N blocks would leave most of the 256 CUs idle.  Cost model: rounds of 512 resident workgroups (2 per CU) times
+// the work of one workgroup (NT MFMAs per fragment pair + a fixed staging share); padded N counts as work.
+void choose_nt(int Cout, int mtiles, int* nt, int* Np) {
     const int t16 = (Cout + 15) / 16;
-    int best = 1, best_pad = 1 << 30;
+    int best = 1;
+    double best_cost = 1e300;
     for (int c = 1; c <= kMaxNT; ++c) {
-        const int padded = round_up(t16, c);
-        if (padded < best_pad || (padded == best_pad && c > best)) { best = c; best_pad = padded; }
+        const long wgs = (long)mtiles * ((t16 + c - 1) / c);
+        const double cost = (double)((wgs + 511) / 512) * (c + 0.5);
+        if (cost < best_cost - 1e-9 || (std::fabs(cost - best_cost) <= 1e-9 && c > best)) { best = c; best_cost = cost; }
     }
     *nt = best;
-    *Np = best_pad * 16;
+    *Np = round_up(t16, best) * 16;
 }
 
 // Geometry + packed-operand buffers + pack descriptors of one conv launch.
@@ -166,7 +174,11 @@ int setup_conv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int C
                const int* oy, const int* ox, int ngroups, GroupSpec* gs) {
     ConvParams& p = tc.cp;
     memset(&p, 0, sizeof p);
-    choose_nt(Cout, &tc.nt, &p.Np);
+    {
+        const int TWm0 = std::min(16, W), TH0 = std::min(16, H);
+        const int imgs0 = (16 / TWm0) * (16 / TH0);
+        choose_nt(Cout, ((tr->B + imgs0 - 1) / imgs0) * (H / TH0) * (W / TWm0) * nphase, &tc.nt, &p.Np);
+    }
     int ymin = 0, ymax = 0, xmin = 0, xmax = 0, ntaps_total = 0;
     for (int g = 0; g < ngroups; ++g)
         for (int ph = 0; ph < nphase; ++ph)
@@ -201,6 +213,18 @@ int setup_conv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int C
     p.H = H; p.W = W; p.Cout = Cout;
     p.nphase = nphase; p.o_mul = o_mul;
     p.outH = H * o_mul; p.outW = W * o_mul; p.pool = 0; p.act = act;
+    {   // K split: a deep layer of a small batch has a few dozen workgroups, each walking thousands of K steps with
+        // exposed staging latency -- spread the channel chunks over more workgroups (partials + ordered reduce)
+        const int img_groups = (tr->B + p.imgs - 1) / p.imgs;
+        const long wgs = (long)img_groups * p.tiles_y * p.tiles_x * nphase * (p.Np / 16 / tc.nt);
+        int min_chunks = 1 << 30;
+        for (int g = 0; g < ngroups; ++g) min_chunks = std::min(min_chunks, (round_up(gs[g].C, 4) + kCC - 1) / kCC);
+        int S = 1;
+        if (wgs < 384 && !getenv("UMX_TRAIN_NO_KSPLIT")) S = (int)std::max<long>(1, std::min<long>(std::min<long>(8, 768 / wgs), min_chunks / 4));
+        p.ksplit = S;
+        p.split_stride = (size_t)tr->B * p.outH * p.outW * Cout;
+        if (S > 1) tr->split_floats = std::max(tr->split_floats, (size_t)S * p.split_stride);
+    }
     if (conv_lds_bytes(tc.nt, p.plane) > 160 * 1024) return tfail(tr, UMX_ERR_INVALID, "%s: LDS footprint too large", what);
     int tpos = 0;
     for (int ph = 0; ph < nphase; ++ph) {
@@ -252,6 +276,13 @@ int run_conv(umx_trainer* tr, TConv& tc, const float* src0, const float* src1, f
     p.src[1] = src1;
     p.dst = dst;
     p.B = tr->B;
+    if (p.ksplit > 1) {
+        p.dst = tr->d_split;
+        p.act = ACT_NONE;
+        T_HIP(tr, launch_conv(p, tc.nt, tc.hpix, tr->stream));
+        T_HIP(tr, launch_split_reduce(tr->d_split, p.ksplit, p.split_stride, p.split_stride, tc.cp.act, dst, tr->stream));
+        return UMX_OK;
+    }
     T_HIP(tr, launch_conv(p, tc.nt, tc.hpix, tr->stream));
     return UMX_OK;
 }
@@ -390,11 +421,7 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         T_HIP(tr, launch_sum_to_scalar(tr->d_part, nblk, 1.0 / (double)Npix, tr->d_loss, 0, 0, st));
     }
     if (o.reg_kind != UMX_REG_NONE)
-        for (const Seg& sg : tr->segs)
-            if (sg.reg > 0.f) {
-                T_HIP(tr, launch_reg_partials(tr->d_w + sg.off, sg.n, o.reg_kind, tr->d_part, st));
-                T_HIP(tr, launch_sum_to_scalar(tr->d_part, 64, (double)sg.reg, tr->d_loss, 1, 1, st));
-            }
+        T_HIP(tr, launch_reg_loss(tr->d_regsegs, tr->n_regsegs, o.reg_kind, tr->d_part, tr->d_loss, 1, st));
     if (tr->prof) T_HIP(tr, hipEventRecord(tr->ev[1], st));
 
     // ------------------------------------------------------------------ backward
@@ -679,6 +706,15 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
     mac_total += 3.0 * P * P * n[1] * K;
     tr->flops_per_image = 2.0 * mac_total;
     T_TRY(talloc(tr, &tr->d_ws, tr->ws_floats));
+    T_TRY(talloc(tr, &tr->d_split, tr->split_floats));
+    {
+        std::vector<RegSeg> rs;
+        for (const Seg& sg : tr->segs)
+            if (sg.reg > 0.f) rs.push_back(RegSeg{tr->d_w + sg.off, sg.n, sg.reg});
+        tr->n_regsegs = (int)rs.size();
+        T_TRY(talloc(tr, &tr->d_regsegs, rs.size()));
+        if (!rs.empty()) T_HIP(tr, hipMemcpy(tr->d_regsegs, rs.data(), rs.size() * sizeof(RegSeg), hipMemcpyHostToDevice));
+    }
     T_TRY(talloc(tr, &tr->d_packs, tr->packs.size()));
     T_HIP(tr, hipMemcpy(tr->d_packs, tr->packs.data(), tr->packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
     return UMX_OK;

@@ -63,7 +63,8 @@ static inline ChanLayout chan_layout(int C) {
 int chan_blocks(size_t N, int C) {
     const ChanLayout l = chan_layout(C);
     const size_t want = N / ((size_t)l.k * 32) + 1;
-    return (int)std::min<size_t>(1024, std::max<size_t>(1, want));
+    const size_t cap = std::max(64, 1024 / l.cblocks);
+    return (int)std::min<size_t>(cap, std::max<size_t>(1, want));
 }
 
 __global__ void __launch_bounds__(256) chan_stats_kernel(const float* __restrict__ x, size_t N, int C, int Cb, int k,
@@ -98,17 +99,34 @@ hipError_t launch_chan_stats(const float* x, size_t N, int C, double* part, int 
     return hipGetLastError();
 }
 
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const double* __restrict__ part, int nblk, double N, int C,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float* mov_mean, float* mov_var, float momentum,
-                                                          float* __restrict__ stat) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+// fixed-order sum of the per-block partials of one channel by a 64-lane block: lane l adds partials l, l+64, ... in
+// order, then a binary tree over the lanes
+__device__ __forceinline__ void block64_sum2(double& a, double& b, double (*sm)[64]) {
+    const int l = threadIdx.x;
+    sm[0][l] = a;
+    sm[1][l] = b;
+    __syncthreads();
+    for (int st = 32; st > 0; st >>= 1) {
+        if (l < st) { sm[0][l] += sm[0][l + st]; sm[1][l] += sm[1][l + st]; }
+        __syncthreads();
+    }
+    a = sm[0][0];
+    b = sm[1][0];
+}
+
+__global__ void __launch_bounds__(64) bn_finalize_kernel(const double* __restrict__ part, int nblk, double N, int C,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* mov_mean, float* mov_var, float momentum,
+                                                         float* __restrict__ stat) {
+    __shared__ double sm[2][64];
+    const int c = blockIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = threadIdx.x; b < nblk; b += 64) {
         s += part[((size_t)b * 2 + 0) * C + c];
         q += part[((size_t)b * 2 + 1) * C + c];
     }
+    block64_sum2(s, q, sm);
+    if (threadIdx.x != 0) return;
     const double mean = s / N;
     double var = q / N - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -126,8 +144,8 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const double* __restri
 
 hipError_t launch_bn_finalize(const double* part, int nblk, size_t N, int C, const float* gamma, const float* beta,
                               float* mov_mean, float* mov_var, float momentum, float* stat, hipStream_t stream) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, part, nblk, (double)N,
-                       C, gamma, beta, mov_mean, mov_var, momentum, stat);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)C), dim3(64), 0, stream, part, nblk, (double)N, C, gamma, beta,
+                       mov_mean, mov_var, momentum, stat);
     return hipGetLastError();
 }
 
@@ -264,15 +282,17 @@ hipError_t launch_act_bwd(const ActParams& a, const float* dy0, const float* dy1
     return hipGetLastError();
 }
 
-__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const double* __restrict__ part, int nblk, double N, int C,
-                                                              float* dgamma, float* dbeta, float* __restrict__ m12) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+__global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const double* __restrict__ part, int nblk, double N, int C,
+                                                             float* dgamma, float* dbeta, float* __restrict__ m12) {
+    __shared__ double sm[2][64];
+    const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = threadIdx.x; b < nblk; b += 64) {
         s1 += part[((size_t)b * 2 + 0) * C + c];
         s2 += part[((size_t)b * 2 + 1) * C + c];
     }
+    block64_sum2(s1, s2, sm);
+    if (threadIdx.x != 0) return;
     m12[c] = (float)(s1 / N);
     m12[C + c] = (float)(s2 / N);
     dgamma[c] = (float)s2;
@@ -281,8 +301,8 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const double* __re
 
 hipError_t launch_bn_bwd_finalize(const double* part, int nblk, size_t N, int C, float* dgamma, float* dbeta, float* m12,
                                   hipStream_t stream) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, part, nblk,
-                       (double)N, C, dgamma, dbeta, m12);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(64), 0, stream, part, nblk, (double)N, C, dgamma,
+                       dbeta, m12);
     return hipGetLastError();
 }
 
@@ -470,13 +490,15 @@ __device__ __forceinline__ float reg_grad(float w, int kind, float c) {
     return 0.f;
 }
 
-__global__ void __launch_bounds__(256) reduce_partials_kernel(const double* __restrict__ part, int nblk, int n,
-                                                              double scale, float* __restrict__ dst,
-                                                              const float* __restrict__ w, int reg_kind, float reg_c) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * n + i];
+__global__ void __launch_bounds__(64) reduce_partials_kernel(const double* __restrict__ part, int nblk, int n,
+                                                             double scale, float* __restrict__ dst,
+                                                             const float* __restrict__ w, int reg_kind, float reg_c) {
+    __shared__ double sm[2][64];
+    const int i = blockIdx.x;
+    double s = 0.0, unused = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 64) s += part[(size_t)b * n + i];
+    block64_sum2(s, unused, sm);
+    if (threadIdx.x != 0) return;
     float v = (float)(s * scale);
     if (w && reg_kind) v += reg_grad(w[i], reg_kind, reg_c);
     dst[i] = v;
@@ -484,8 +506,8 @@ __global__ void __launch_bounds__(256) reduce_partials_kernel(const double* __re
 
 hipError_t launch_reduce_partials(const double* part, int nblk, int n, double scale, float* dst, const float* w,
                                   int reg_kind, float reg_c, hipStream_t stream) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part, nblk, n, scale,
-                       dst, w, reg_kind, reg_c);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)n), dim3(64), 0, stream, part, nblk, n, scale, dst, w,
+                       reg_kind, reg_c);
     return hipGetLastError();
 }
 
@@ -503,12 +525,15 @@ hipError_t launch_sum_to_scalar(const double* part, int n, double scale, double*
     return hipGetLastError();
 }
 
-__global__ void __launch_bounds__(256) reg_partials_kernel(const float* __restrict__ w, size_t n, int kind,
+// regularisation loss of every regularised tensor in two launches: part[seg][64] = sum |w| or w^2 over a strided share,
+// then out[slot] += sum_seg coef[seg] * sum_b part[seg][b]
+__global__ void __launch_bounds__(256) reg_partials_kernel(const RegSeg* __restrict__ segs, int kind,
                                                            double* __restrict__ part) {
     __shared__ double sm[256];
+    const RegSeg sg = segs[blockIdx.y];
     double s = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const double v = (double)w[i];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < sg.n; i += (size_t)gridDim.x * 256) {
+        const double v = (double)sg.w[i];
         s += kind == 1 ? fabs(v) : v * v;
     }
     sm[threadIdx.x] = s;
@@ -517,27 +542,48 @@ __global__ void __launch_bounds__(256) reg_partials_kernel(const float* __restri
         if ((int)threadIdx.x < st) sm[threadIdx.x] += sm[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+    if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = sm[0];
 }
 
-hipError_t launch_reg_partials(const float* w, size_t n, int kind, double* part, hipStream_t stream) {
-    hipLaunchKernelGGL(reg_partials_kernel, dim3(64), dim3(256), 0, stream, w, n, kind, part);
+__global__ void reg_finalize_kernel(const RegSeg* __restrict__ segs, int nseg, const double* __restrict__ part, int nb,
+                                    double* out, int slot) {
+    double total = 0.0;
+    for (int g = 0; g < nseg; ++g) {
+        double s = 0.0;
+        for (int b = 0; b < nb; ++b) s += part[(size_t)g * nb + b];
+        total += (double)segs[g].coef * s;
+    }
+    out[slot] += total;
+}
+
+hipError_t launch_reg_loss(const RegSeg* segs_dev, int nseg, int kind, double* part, double* out, int slot,
+                           hipStream_t stream) {
+    if (nseg <= 0) return hipSuccess;
+    hipLaunchKernelGGL(reg_partials_kernel, dim3(64, (unsigned)nseg), dim3(256), 0, stream, segs_dev, kind, part);
+    hipLaunchKernelGGL(reg_finalize_kernel, dim3(1), dim3(1), 0, stream, segs_dev, nseg, part, 64, out, slot);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
-// GEMM view: M = input channels of a slab (32 per workgroup), N = output channels (64 per workgroup, 16 per wave),
-// K = pixels.  A workgroup walks pixel tiles of 128 pixels (imgs x TH x TW) of its slice: the X halo tile and the G
-// tile are staged in LDS once and serve every slab (filter tap) of the group -- 9 taps x 2 channel tiles = 18
-// accumulator tiles per wave, one ds_read_b32 per MFMA.  LDS pitches (48 / 80 floats per pixel) put the four pixels
-// of a 16x16x4 fragment on disjoint bank quarters.  Partial sums go to ws[slice]; wgrad_reduce_kernel adds the slices
-// in order.
-constexpr int kWgCI = 32, kWgCO = 64, kWgPX = 48, kWgPG = 80, kWgNS = 9, kWgPix = 128;
+// GEMM view: M = input channels of a slab (16*MI per workgroup, MI = 1..3 chosen per layer), N = output channels
+// (64 per workgroup, 16 per wave), K = pixels.  A workgroup walks pixel tiles of 128 pixels (imgs x TH x TW) of its
+// slice: the X halo tile and the G tile are staged in LDS once and serve every slab (filter tap) of the group --
+// 9 taps x MI channel tiles accumulator tiles per wave, one ds_read_b32 per MFMA.  LDS pitches (16 or 48 / 80 floats
+// per pixel) put the four pixels of a 16x16x4 fragment on disjoint bank quarters.  Partial sums go to ws[slice];
+// wgrad_reduce_kernel adds the slices in order.
+constexpr int kWgCO = 64, kWgPG = 80, kWgNS = 9, kWgPix = 128;
+__host__ __device__ constexpr int wg_px(int mi) { return mi == 1 ? 16 : 48; }   // X pitch: = 16 or 48 (mod 64)
+// halo pixels of one tile: 10 x 18 = 180 (8 x 16 tile, 3 x 3 taps), 2 x 10 x 10 = 200; the 4 x 4 layers (8 images
+// x 6 x 6 = 288) use the BIG variants, which exist for MI <= 2 only (register budget of the staging slots)
+constexpr int kWgHalo = 208, kWgHaloBig = 288;
+__host__ __device__ constexpr int wg_hx(int mi, bool big) { return ((big ? kWgHaloBig : kWgHalo) * 4 * mi + 255) / 256; }
 
+template <int MI, bool BIG>
 __global__ void __launch_bounds__(256, 2) wgrad_mfma_f32(const WgradParams p) {
+    constexpr int CI = 16 * MI, PX = wg_px(MI);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const Xl = smem;                      // [nhalo][kWgPX]
-    float* const Gl = smem + p.nhalo * kWgPX;    // [128][kWgPG]
+    float* const Xl = smem;                  // [nhalo][PX]
+    float* const Gl = smem + p.nhalo * PX;   // [128][kWgPG]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -546,43 +592,56 @@ __global__ void __launch_bounds__(256, 2) wgrad_mfma_f32(const WgradParams p) {
 
     const int slice = blockIdx.x;
     const int nco = (p.Cg + kWgCO - 1) / kWgCO;
-    const int ci0 = (blockIdx.y / nco) * kWgCI, co0 = (blockIdx.y % nco) * kWgCO;
+    const int ci0 = (blockIdx.y / nco) * CI, co0 = (blockIdx.y % nco) * kWgCO;
     const int slab0 = p.gstart[blockIdx.z], ns = p.gcount[blockIdx.z];
     const int coff = p.coff[slab0];
     const bool wave_live = co0 + wave * 16 < p.Cg;
 
-    f32x4 acc[kWgNS][2];
+    f32x4 acc[kWgNS][MI];
 #pragma unroll
-    for (int s = 0; s < kWgNS; ++s) { acc[s][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[s][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    for (int s = 0; s < kWgNS; ++s)
+#pragma unroll
+        for (int t2 = 0; t2 < MI; ++t2) acc[s][t2] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int t_end = min(p.ntiles, (slice + 1) * p.tiles_per_slice);
-    for (int t = slice * p.tiles_per_slice; t < t_end; ++t) {
+    // register-staged pipeline: the next tile's global loads are issued before the MFMA block of the current tile and
+    // written to LDS after it
+    constexpr int HX = wg_hx(MI, BIG);
+    float4 xr[HX], gr[kWgPix * (kWgCO / 4) / 256];
+    const int nx4 = p.nhalo * (CI / 4);
+    auto load_tile = [&](int t) {
         const int tx = t % p.tiles_x;
         const int ty = (t / p.tiles_x) % p.tiles_y;
         const int img0 = (t / (p.tiles_x * p.tiles_y)) * p.imgs;
         const int y0 = ty * TH, x0 = tx * TW;
-        __syncthreads();   // the previous tile's fragment reads are done
-        for (int e = tid; e < p.nhalo * (kWgCI / 4); e += 256) {
-            const int hp = e >> 3, q = e & 7;
-            const int il = hp / p.imgplane;
-            const int rr = hp - il * p.imgplane;
-            const int hy = rr / p.hw, hx = rr - hy * p.hw;
-            const int gy = y0 + p.ymin + hy, gx = x0 + p.xmin + hx, img = img0 + il;
-            const int c = ci0 + 4 * q;
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));   // opaque per call: keeps the slot decode out of the tile loop's live registers
+#pragma unroll
+        for (int i = 0; i < HX; ++i) {
+            const int e = tid_o + i * 256;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (img < p.B && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && c < p.Cx) {
-                const float* src = p.X + ((size_t)(img * p.H + gy) * p.W + gx) * p.Cxt + coff + c;
-                if (p.vecx && c + 3 < p.Cx) v = *reinterpret_cast<const float4*>(src);
-                else {
-                    v.x = src[0];
-                    if (c + 1 < p.Cx) v.y = src[1];
-                    if (c + 2 < p.Cx) v.z = src[2];
-                    if (c + 3 < p.Cx) v.w = src[3];
+            if (e < nx4) {
+                const int hp = e / (CI / 4), q = e - hp * (CI / 4);
+                const int il = hp / p.imgplane;
+                const int rr = hp - il * p.imgplane;
+                const int hy = rr / p.hw, hx = rr - hy * p.hw;
+                const int gy = y0 + p.ymin + hy, gx = x0 + p.xmin + hx, img = img0 + il;
+                const int c = ci0 + 4 * q;
+                if (img < p.B && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && c < p.Cx) {
+                    const float* src = p.X + ((size_t)(img * p.H + gy) * p.W + gx) * p.Cxt + coff + c;
+                    if (p.vecx && c + 3 < p.Cx) v = *reinterpret_cast<const float4*>(src);
+                    else {
+                        v.x = src[0];
+                        if (c + 1 < p.Cx) v.y = src[1];
+                        if (c + 2 < p.Cx) v.z = src[2];
+                        if (c + 3 < p.Cx) v.w = src[3];
+                    }
                 }
             }
-            *reinterpret_cast<float4*>(Xl + hp * kWgPX + 4 * q) = v;
+            xr[i] = v;
         }
-        for (int e = tid; e < kWgPix * (kWgCO / 4); e += 256) {
+#pragma unroll
+        for (int i = 0; i < kWgPix * (kWgCO / 4) / 256; ++i) {
+            const int e = tid_o + i * 256;
             const int px = e >> 4, q = e & 15;
             const int il = px >> (p.th_log2 + p.tw_log2);
             const int y = (px >> p.tw_log2) & (TH - 1), x = px & (TW - 1);
@@ -599,24 +658,62 @@ __global__ void __launch_bounds__(256, 2) wgrad_mfma_f32(const WgradParams p) {
                     if (co + 3 < p.Cg) v.w = src[3];
                 }
             }
-            *reinterpret_cast<float4*>(Gl + px * kWgPG + 4 * q) = v;
+            gr[i] = v;
         }
+    };
+    auto store_tile = [&]() {
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+#pragma unroll
+        for (int i = 0; i < HX; ++i) {
+            const int e = tid_o + i * 256;
+            if (e < nx4) {
+                const int hp = e / (CI / 4), q = e - hp * (CI / 4);
+                *reinterpret_cast<float4*>(Xl + hp * PX + 4 * q) = xr[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kWgPix * (kWgCO / 4) / 256; ++i) {
+            const int e = tid_o + i * 256;
+            *reinterpret_cast<float4*>(Gl + (e >> 4) * kWgPG + 4 * (e & 15)) = gr[i];
+        }
+    };
+
+    int so[kWgNS];   // LDS offset of each slab of the group (wave-uniform)
+#pragma unroll
+    for (int s = 0; s < kWgNS; ++s) {
+        const int sb = slab0 + (s < ns ? s : 0);
+        so[s] = __builtin_amdgcn_readfirstlane(((p.dy[sb] - p.ymin) * p.hw + (p.dx[sb] - p.xmin)) * PX);
+    }
+    const int t_begin = slice * p.tiles_per_slice;
+    const int t_end = min(p.ntiles, (slice + 1) * p.tiles_per_slice);
+    if (t_begin < t_end) load_tile(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        __syncthreads();   // the previous tile's fragment reads are done
+        store_tile();
         __syncthreads();
+        if (t + 1 < t_end) load_tile(t + 1);
         if (wave_live) {
             for (int ks = 0; ks < kWgPix / 4; ++ks) {
                 const int px = 4 * ks + kq;
                 const int il = px >> (p.th_log2 + p.tw_log2);
                 const int y = (px >> p.tw_log2) & (TH - 1), x = px & (TW - 1);
-                const float* ap = Xl + (il * p.imgplane + y * p.hw + x) * kWgPX + li;
+                const float* ap = Xl + (il * p.imgplane + y * p.hw + x) * PX + li;
                 const float b = Gl[px * kWgPG + wave * 16 + li];
+                float a[kWgNS][MI];
 #pragma unroll
-                for (int s = 0; s < kWgNS; ++s) {
+                for (int s = 0; s < kWgNS; ++s)
                     if (s < ns) {
-                        const int so = ((p.dy[slab0 + s] - p.ymin) * p.hw + (p.dx[slab0 + s] - p.xmin)) * kWgPX;
-                        acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[so], b, acc[s][0], 0, 0, 0);
-                        acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[so + 16], b, acc[s][1], 0, 0, 0);
+#pragma unroll
+                        for (int t2 = 0; t2 < MI; ++t2) a[s][t2] = ap[so[s] + 16 * t2];
                     }
-                }
+#pragma unroll
+                for (int s = 0; s < kWgNS; ++s)
+                    if (s < ns) {
+#pragma unroll
+                        for (int t2 = 0; t2 < MI; ++t2)
+                            acc[s][t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][t2], b, acc[s][t2], 0, 0, 0);
+                    }
             }
         }
     }
@@ -629,7 +726,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_mfma_f32(const WgradParams p) {
         if (s < ns && co < p.Cg) {
             float* dst = p.ws + ((size_t)slice * p.nslab + slab0 + s) * slab_sz;
 #pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
+            for (int t2 = 0; t2 < MI; ++t2)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ci = ci0 + t2 * 16 + 4 * kq + r;
@@ -642,6 +739,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_mfma_f32(const WgradParams p) {
 bool wgrad_setup(WgradParams* p, std::string* why) {
     auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
     if (p->nslab < 1 || p->nslab > kWgMaxSlabs) { *why = "wgrad: too many filter taps"; return false; }
+    p->vecx = (p->Cxt % 4 == 0);
+    for (int s = 0; s < p->nslab; ++s)
+        if (p->coff[s] % 4) p->vecx = 0;
+    p->vecg = (p->Cg % 4 == 0);
     const int TW = std::min(16, p->W), TH = std::min(8, p->H);
     if ((TW & (TW - 1)) || (TH & (TH - 1)) || p->H % TH || p->W % TW || kWgPix % (TH * TW)) {
         *why = "wgrad: layer size must be a power of two";
@@ -674,33 +775,52 @@ bool wgrad_setup(WgradParams* p, std::string* why) {
         ++p->ngroups;
         s += n;
     }
-    const int chunks = ((p->Cx + kWgCI - 1) / kWgCI) * ((p->Cg + kWgCO - 1) / kWgCO) * p->ngroups;
+    // input-channel tiles per workgroup: fewest padded tiles, each chunk charged one tile for its G traffic
+    if (p->nhalo > kWgHaloBig) { *why = "wgrad: halo too large"; return false; }
+    const int mi_max = p->nhalo > kWgHalo ? 2 : 3;
+    int best = 1;
+    double best_cost = 1e300;
+    for (int mi = 1; mi <= mi_max; ++mi) {
+        const double cost = (double)((p->Cx + 16 * mi - 1) / (16 * mi)) * (mi + 1.0);
+        if (cost <= best_cost) { best = mi; best_cost = cost; }
+    }
+    p->mi = best;
+    const int chunks = ((p->Cx + 16 * p->mi - 1) / (16 * p->mi)) * ((p->Cg + kWgCO - 1) / kWgCO) * p->ngroups;
     int nslices = std::max(1, std::min(p->ntiles, 1024 / std::max(1, chunks)));
     p->tiles_per_slice = (p->ntiles + nslices - 1) / nslices;
     p->nslices = (p->ntiles + p->tiles_per_slice - 1) / p->tiles_per_slice;
-    p->vecx = (p->Cxt % 4 == 0);
-    for (int s = 0; s < p->nslab; ++s)
-        if (p->coff[s] % 4) p->vecx = 0;
-    p->vecg = (p->Cg % 4 == 0);
-    const size_t lds = sizeof(float) * ((size_t)p->nhalo * kWgPX + (size_t)kWgPix * kWgPG);
+    const size_t lds = sizeof(float) * ((size_t)p->nhalo * wg_px(p->mi) + (size_t)kWgPix * kWgPG);
     if (lds > 160 * 1024) { *why = "wgrad: halo too large for the LDS"; return false; }
     return true;
 }
 
 size_t wgrad_ws_floats(const WgradParams& p) { return (size_t)p.nslices * p.nslab * p.Cx * p.Cg; }
 
-hipError_t launch_wgrad(const WgradParams& p, hipStream_t stream) {
-    const size_t lds = sizeof(float) * ((size_t)p.nhalo * kWgPX + (size_t)kWgPix * kWgPG);
+template <int MI, bool BIG>
+static hipError_t launch_wgrad_mi(const WgradParams& p, hipStream_t stream) {
+    const size_t lds = sizeof(float) * ((size_t)p.nhalo * wg_px(MI) + (size_t)kWgPix * kWgPG);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_f32),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_f32<MI, BIG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const unsigned chunks = (unsigned)(((p.Cx + kWgCI - 1) / kWgCI) * ((p.Cg + kWgCO - 1) / kWgCO));
-    hipLaunchKernelGGL(wgrad_mfma_f32, dim3((unsigned)p.nslices, chunks, (unsigned)p.ngroups), dim3(256), lds, stream, p);
+    const unsigned chunks = (unsigned)(((p.Cx + 16 * MI - 1) / (16 * MI)) * ((p.Cg + kWgCO - 1) / kWgCO));
+    hipLaunchKernelGGL((wgrad_mfma_f32<MI, BIG>), dim3((unsigned)p.nslices, chunks, (unsigned)p.ngroups), dim3(256), lds,
+                       stream, p);
     return hipGetLastError();
+}
+
+hipError_t launch_wgrad(const WgradParams& p, hipStream_t stream) {
+    const bool big = p.nhalo > kWgHalo;
+    if (p.nhalo > kWgHaloBig || (big && p.mi > 2)) return hipErrorInvalidValue;
+    switch (p.mi) {
+        case 1: return big ? launch_wgrad_mi<1, true>(p, stream) : launch_wgrad_mi<1, false>(p, stream);
+        case 2: return big ? launch_wgrad_mi<2, true>(p, stream) : launch_wgrad_mi<2, false>(p, stream);
+        case 3: return launch_wgrad_mi<3, false>(p, stream);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 struct WgReduce {
@@ -714,21 +834,30 @@ struct WgReduce {
     short mslab[kWgMaxSlabs];
 };
 
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WgReduce q) {
+// 256 threads = OUT outputs x SP slice partitions (SP a power of two chosen by the host): thread (o, sp) adds slices
+// sp, sp+SP, ... in order; the SP partial sums are then added in order by the sp == 0 thread.
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WgReduce q, int SP) {
+    __shared__ double sm[256];
+    const int OUT = 256 / SP;
+    const int o = threadIdx.x % OUT, sp = threadIdx.x / OUT;
     const size_t n = (size_t)q.nslab * q.Cx * q.Cg;
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
+    const size_t e = (size_t)blockIdx.x * OUT + o;
     double s = 0.0;
-    for (int sl = 0; sl < q.nslices; ++sl) s += (double)q.ws[(size_t)sl * n + e];
+    if (e < n)
+        for (int sl = sp; sl < q.nslices; sl += SP) s += (double)q.ws[(size_t)sl * n + e];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    if (sp != 0 || e >= n) return;
+    for (int j = 1; j < SP; ++j) s += sm[j * OUT + o];
     const int co = (int)(e % q.Cg);
     const size_t r = e / q.Cg;
     const int ci = (int)(r % q.Cx);
     const int sb = (int)(r / q.Cx);
-    const size_t o = ((size_t)q.mslab[sb] * q.Ctot + q.c_off + ci) * q.Cg + co;
+    const size_t dsti = ((size_t)q.mslab[sb] * q.Ctot + q.c_off + ci) * q.Cg + co;
     float v = (float)s;
-    if (q.g2) q.g2[o] = v;
-    if (q.w && q.reg_kind) v += reg_grad(q.w[o], q.reg_kind, q.reg_c);
-    q.g[o] = v;
+    if (q.g2) q.g2[dsti] = v;
+    if (q.w && q.reg_kind) v += reg_grad(q.w[dsti], q.reg_kind, q.reg_c);
+    q.g[dsti] = v;
 }
 
 hipError_t launch_wgrad_reduce(const WgradParams& p, int Ctot, int c_off, float* g, const float* w, int reg_kind,
@@ -738,7 +867,26 @@ hipError_t launch_wgrad_reduce(const WgradParams& p, int Ctot, int c_off, float*
     q.g = g; q.w = w; q.reg_kind = reg_kind; q.reg_c = reg_c; q.g2 = g2;
     for (int s = 0; s < kWgMaxSlabs; ++s) q.mslab[s] = s < p.nslab ? p.mslab[s] : 0;
     const size_t n = (size_t)p.nslab * p.Cx * p.Cg;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, q);
+    int SP = 1;
+    while (SP < 64 && SP * 8 < p.nslices) SP *= 2;
+    const int OUT = 256 / SP;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + OUT - 1) / OUT)), dim3(256), 0, stream, q, SP);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) split_reduce_kernel(const float* __restrict__ part, int nsplit, size_t stride,
+                                                           size_t n, int act, float* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = part[i];
+    for (int k = 1; k < nsplit; ++k) s += part[(size_t)k * stride + i];
+    dst[i] = act_of(s, act);
+}
+
+hipError_t launch_split_reduce(const float* part, int nsplit, size_t stride, size_t n, int act, float* dst,
+                               hipStream_t stream) {
+    hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part, nsplit, stride, n,
+                       act, dst);
     return hipGetLastError();
 }
 
