@@ -292,16 +292,14 @@ def cpu_baseline_train(hp, blob, data, labels, weights, budget_s):
     """The training oracle (torch autograd on the host cores, float32) on the first images of the same batch."""
     import torch
     from oracle import train_oracle as to
-    n = 1
     o = to.duo_options()
+    t = time.perf_counter()
+    to.loss_and_grads(hp, blob, data[:1], labels[:1], weights[:1], o, 0, dtype=torch.float32)   # untimed: thread pool, caches
+    warm = time.perf_counter() - t
+    n = int(max(1, min(data.shape[0], budget_s / max(warm, 1e-3) / 2)))
     t = time.perf_counter()
     to.loss_and_grads(hp, blob, data[:n], labels[:n], weights[:n], o, 0, dtype=torch.float32)
     dt = time.perf_counter() - t
-    if dt < budget_s / 3 and data.shape[0] >= 2:
-        n = int(min(data.shape[0], max(2, budget_s / dt / 2)))
-        t = time.perf_counter()
-        to.loss_and_grads(hp, blob, data[:n], labels[:n], weights[:n], o, 0, dtype=torch.float32)
-        dt = time.perf_counter() - t
     return {"value": round(n / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "forward+backward of %d image(s) of the same batch (oracle/train_oracle.py, torch CPU float32, no "
                       "optimiser update), %.1f s" % (n, dt)}

@@ -220,7 +220,11 @@ int setup_conv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int C
         int min_chunks = 1 << 30;
         for (int g = 0; g < ngroups; ++g) min_chunks = std::min(min_chunks, (round_up(gs[g].C, 4) + kCC - 1) / kCC);
         int S = 1;
-        if (wgs < 384 && !getenv("UMX_TRAIN_NO_KSPLIT")) S = (int)std::max<long>(1, std::min<long>(std::min<long>(8, 768 / wgs), min_chunks / 4));
+        const char* e1 = getenv("UMX_TRAIN_KSPLIT_WGS");
+        const char* e2 = getenv("UMX_TRAIN_KSPLIT_MAX");
+        const long target = e1 ? atol(e1) : 1536, smax = e2 ? atol(e2) : 8;
+        if (wgs < target / 2 && !getenv("UMX_TRAIN_NO_KSPLIT"))
+            S = (int)std::max<long>(1, std::min<long>(std::min<long>(smax, target / wgs), min_chunks / 4));
         p.ksplit = S;
         p.split_stride = (size_t)tr->B * p.outH * p.outW * Cout;
         if (S > 1) tr->split_floats = std::max(tr->split_floats, (size_t)S * p.split_stride);
