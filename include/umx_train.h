@@ -70,6 +70,10 @@ UMX_API int umx_trainer_read(umx_trainer* tr, int which, float* out, size_t n_fl
 /* softmax output of the last step's forward pass [B,P,P,nClasses] (the reference evaluates its pixel errors on it,
  * UnMicst1-5.py:386-397) */
 UMX_API int umx_trainer_probs(umx_trainer* tr, float* probs_host);
+/* Session.run(UNet2D.nn / errors, feed_dict={tfData: batchData, tfTraining: 0}) with the trainer's current variables
+ * (the validation and test passes of UNet2D.train, UnMicst1-5.py:501-502,564-565): moving statistics, no dropout.
+ * data [B,P,P,nChannels] and probs [B,P,P,nClasses] are HOST buffers; synchronous. */
+UMX_API int umx_trainer_eval(umx_trainer* tr, const float* data, float* probs_host);
 UMX_API int64_t umx_trainer_step_count(const umx_trainer* tr);
 UMX_API int umx_trainer_batch(const umx_trainer* tr);
 /* algorithmic FLOPs of one step per image: forward + input gradients + weight gradients of every convolution */

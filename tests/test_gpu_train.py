@@ -14,6 +14,8 @@ The top of the graph (lt.*, lu0.bn.*, lu0.w2) must always be TIGHT; the small gr
 least one of three batches.  BN moving statistics 1e-5; optimiser slots like the gradients; the update itself is
 checked exactly against the kernel's own gradient (Adam divides by sqrt(v): where |g| is at rounding level the
 *direction* of a step is not determined by the maths, so parameters after Adam steps are compared with nsteps * lr)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -210,3 +212,41 @@ def test_errors():
     with pytest.raises(ValueError):
         tr.step(np.zeros((3, 32, 32, 2)), np.zeros((3, 32, 32, 3)), np.zeros((3, 32, 32, 3)))
     tr.close()
+
+
+def test_eval_is_the_inference_mode_forward():
+    """umx_trainer_eval == Session.run(UNet2D.nn, {tfTraining: 0}) with the current variables (moving statistics)."""
+    from oracle import oracle
+    hp = helpers.small_hps()["v2_duo_like"]
+    blob = model.random_blob(hp, seed=31)
+    tr = trainer.Trainer(hp, blob, trainer.duo_options(), batch=4)
+    data, labels, weights = _batch(hp, 4, 2)
+    assert np.abs(tr.eval(data) - oracle.forward(hp, blob, data)).max() <= 1e-5
+    for s in range(2):
+        tr.step(*_batch(hp, 4, 50 + s))
+    now = tr.blob()
+    assert not np.array_equal(now, blob)
+    assert np.abs(tr.eval(data) - oracle.forward(hp, now, data)).max() <= 1e-5
+    tr.close()
+
+
+def test_train_loop_end_to_end(tmp_path):
+    """UNet2D.train on the GPU: the reference's file convention in, model directory + PNGs out, error goes down, and the
+    saved model serves the inference engine."""
+    from test_train_loop_cpu import HP, write_dataset
+    from unmicst_amd.unet2d import UNet2D
+    hp = dict(HP, nOut0=8, batchSize=4)
+    for name, n in (("train", 12), ("valid", 8), ("test", 2)):
+        write_dataset(str(tmp_path / name), n, 32, 1, 12, seed=len(name))
+    np.random.seed(1)
+    UNet2D.setupWithHP(hp)
+    UNet2D.train_regime = "solo"
+    hist = UNet2D.train(str(tmp_path / "train"), str(tmp_path / "valid"), str(tmp_path / "test"), str(tmp_path / "log"),
+                        str(tmp_path / "model"), str(tmp_path / "pm"), 12, 8, 2, False, 60, 0, 2)
+    losses = [l for l, _ in hist]
+    assert np.mean(losses[-10:]) < np.mean(losses[:10])
+    assert len(os.listdir(tmp_path / "pm")) == 2 * 12 * 2
+    art = model.load_model_dir(str(tmp_path / "model"))
+    with umx.Engine(art.hp, art.blob, max_batch=2) as eng:
+        p = eng.forward_tiles(np.zeros((1, 32, 32, 1), np.float32))
+    assert np.allclose(p.sum(-1), 1.0, atol=1e-5)

@@ -173,6 +173,12 @@ hipError_t launch_chan_stats(const float* x, size_t N, int C, double* part, int 
 hipError_t launch_bn_finalize(const double* part, int nblk, size_t N, int C, const float* gamma, const float* beta,
                               float* mov_mean, float* mov_var, float momentum, float* stat, hipStream_t stream);
 
+// inference-mode statistics: stat from the moving averages (tf.layers.batch_normalization(training=False))
+hipError_t launch_bn_stat_from_moving(int C, const float* gamma, const float* beta, const float* mov_mean,
+                                      const float* mov_var, float* stat, hipStream_t stream);
+// probs = softmax(t0*scale + shift)
+hipError_t launch_softmax_only(const float* t0, const float* stat, size_t N, int K, float* probs, hipStream_t stream);
+
 struct ActParams {          // y = dropout(act(z*scale + shift)) [-> 2x2 max-pool]
     const float* z;         // [B,H,W,C] pre-BN conv output
     const float* stat;      // [4][C]

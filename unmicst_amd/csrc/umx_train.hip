@@ -340,7 +340,12 @@ int bn_alloc(umx_trainer* tr, BnSite& s, int C, int H, size_t off_gamma) {
 }
 
 // z -> statistics -> stat (and the moving averages when updating)
-int bn_forward_stats(umx_trainer* tr, BnSite& s, bool update) {
+int bn_forward_stats(umx_trainer* tr, BnSite& s, bool update, bool training = true) {
+    if (!training) {
+        T_HIP(tr, launch_bn_stat_from_moving(s.C, tr->d_w + s.gamma, tr->d_w + s.beta, tr->d_w + s.mean, tr->d_w + s.var,
+                                             s.stat, tr->stream));
+        return UMX_OK;
+    }
     const size_t N = (size_t)tr->B * s.H * s.W;
     const int nblk = chan_blocks(N, s.C);
     T_HIP(tr, launch_chan_stats(s.z, N, s.C, tr->d_part, nblk, tr->stream));
@@ -386,6 +391,38 @@ float down_rate(const umx_trainer* tr, int i) { return tr->o.drop_down_step * i;
 
 enum { LAYER_DOWN = 0, LAYER_BOTTOM = 16, LAYER_UP = 32 };   // dropout stream ids (oracle/train_oracle.py)
 
+// forward of the graph up to the top layer's pre-BN output (UnMicst1-5.py:83-222).  training: batch statistics + dropout;
+// otherwise the moving statistics, no dropout (tfTraining: 0)
+int forward_pass(umx_trainer* tr, const float* data, bool training, bool update) {
+    const int L = tr->L;
+    hipStream_t st = tr->stream;
+    const umx_train_options& o = tr->o;
+    auto rate = [&](float r) { return training ? r : 0.f; };
+    tr->ds[0] = const_cast<float*>(data);
+    for (int i = 0; i < L; ++i) {
+        BnSite& s = tr->bn_d[i];
+        T_TRY(run_conv(tr, tr->c_fwd_d[i], tr->ds[i], nullptr, s.z));
+        T_TRY(bn_forward_stats(tr, s, update, training));
+        T_HIP(tr, launch_act_fwd(act_params(tr, s, 1, ACT_LEAKY, rate(down_rate(tr, i)), LAYER_DOWN + i), tr->ds[i + 1], st));
+    }
+    T_TRY(run_conv(tr, tr->c_fwd_b, tr->ds[L], nullptr, tr->bn_b.z));
+    T_TRY(bn_forward_stats(tr, tr->bn_b, update, training));
+    T_HIP(tr, launch_act_fwd(act_params(tr, tr->bn_b, 0, ACT_LEAKY, rate(o.drop_bottom), LAYER_BOTTOM), tr->act_b, st));
+    const float* cur = tr->act_b;
+    for (int idx = L - 1; idx >= 0; --idx) {
+        BnSite& s = tr->bn_u[idx];
+        T_TRY(run_conv(tr, tr->c_T[idx], cur, nullptr, tr->us[idx]));
+        T_TRY(run_conv(tr, tr->c_fwd_u[idx], tr->ds[idx], tr->us[idx], s.z));
+        T_TRY(bn_forward_stats(tr, s, update, training));
+        T_HIP(tr, launch_act_fwd(act_params(tr, s, 0, ACT_LEAKY, rate(up_rate(tr, idx)), LAYER_UP + idx), tr->cv[idx], st));
+        cur = tr->cv[idx];
+    }
+    BnSite& t = tr->bn_t;
+    T_HIP(tr, launch_head_fwd(tr->cv[0], (size_t)tr->B * tr->P * tr->P, tr->n[1], tr->K, tr->d_w + tr->o_lt, t.z, st));
+    T_TRY(bn_forward_stats(tr, t, update, training));
+    return UMX_OK;
+}
+
 int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const float* weights, bool update) {
     const int L = tr->L, K = tr->K, B = tr->B, P = tr->P;
     hipStream_t st = tr->stream;
@@ -395,29 +432,8 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
     T_HIP(tr, hipMemsetAsync(tr->d_loss, 0, 2 * sizeof(double), st));
     T_HIP(tr, launch_pack_weights(tr->d_packs, (int)tr->packs.size(), tr->max_pack, st));
 
-    // ------------------------------------------------------------------ forward (UnMicst1-5.py:83-237)
-    tr->ds[0] = const_cast<float*>(data);
-    for (int i = 0; i < L; ++i) {
-        BnSite& s = tr->bn_d[i];
-        T_TRY(run_conv(tr, tr->c_fwd_d[i], tr->ds[i], nullptr, s.z));
-        T_TRY(bn_forward_stats(tr, s, update));
-        T_HIP(tr, launch_act_fwd(act_params(tr, s, 1, ACT_LEAKY, down_rate(tr, i), LAYER_DOWN + i), tr->ds[i + 1], st));
-    }
-    T_TRY(run_conv(tr, tr->c_fwd_b, tr->ds[L], nullptr, tr->bn_b.z));
-    T_TRY(bn_forward_stats(tr, tr->bn_b, update));
-    T_HIP(tr, launch_act_fwd(act_params(tr, tr->bn_b, 0, ACT_LEAKY, o.drop_bottom, LAYER_BOTTOM), tr->act_b, st));
-    const float* cur = tr->act_b;
-    for (int idx = L - 1; idx >= 0; --idx) {
-        BnSite& s = tr->bn_u[idx];
-        T_TRY(run_conv(tr, tr->c_T[idx], cur, nullptr, tr->us[idx]));
-        T_TRY(run_conv(tr, tr->c_fwd_u[idx], tr->ds[idx], tr->us[idx], s.z));
-        T_TRY(bn_forward_stats(tr, s, update));
-        T_HIP(tr, launch_act_fwd(act_params(tr, s, 0, ACT_LEAKY, up_rate(tr, idx), LAYER_UP + idx), tr->cv[idx], st));
-        cur = tr->cv[idx];
-    }
+    T_TRY(forward_pass(tr, data, true, update));
     BnSite& t = tr->bn_t;
-    T_HIP(tr, launch_head_fwd(tr->cv[0], Npix, tr->n[1], K, tr->d_w + tr->o_lt, t.z, st));
-    T_TRY(bn_forward_stats(tr, t, update));
     {
         const int nblk = loss_blocks(Npix);
         T_HIP(tr, launch_softmax_loss(t.z, t.stat, labels, weights, Npix, K, o.clip_eps, tr->d_probs, tr->d_dt, tr->d_part,
@@ -839,6 +855,23 @@ int umx_train_step(umx_trainer* tr, const float* data, const float* labels, cons
     double l[3];
     T_TRY(umx_trainer_loss(tr, l));
     if (loss3) { loss3[0] = l[0]; loss3[1] = l[1]; loss3[2] = l[2]; }
+    return UMX_OK;
+}
+
+int umx_trainer_eval(umx_trainer* tr, const float* data, float* probs_host) {
+    if (!tr || !data || !probs_host) return tfail(tr, UMX_ERR_INVALID, "null argument");
+    T_HIP(tr, hipSetDevice(tr->device));
+    T_TRY(fold_profile(tr));
+    const size_t npx = (size_t)tr->B * tr->P * tr->P;
+    float* own = tr->ds[0];
+    T_HIP(tr, hipMemcpyAsync(own, data, npx * tr->n[0] * sizeof(float), hipMemcpyHostToDevice, tr->stream));
+    T_HIP(tr, launch_pack_weights(tr->d_packs, (int)tr->packs.size(), tr->max_pack, tr->stream));
+    const int rc = forward_pass(tr, own, false, false);
+    tr->ds[0] = own;
+    T_TRY(rc);
+    T_HIP(tr, launch_softmax_only(tr->bn_t.z, tr->bn_t.stat, npx, tr->K, tr->d_probs, tr->stream));
+    T_HIP(tr, hipMemcpyAsync(probs_host, tr->d_probs, npx * tr->K * sizeof(float), hipMemcpyDeviceToHost, tr->stream));
+    T_HIP(tr, hipStreamSynchronize(tr->stream));
     return UMX_OK;
 }
 

@@ -149,6 +149,28 @@ hipError_t launch_bn_finalize(const double* part, int nblk, size_t N, int C, con
     return hipGetLastError();
 }
 
+__global__ void __launch_bounds__(256) bn_stat_from_moving_kernel(int C, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta,
+                                                                  const float* __restrict__ mov_mean,
+                                                                  const float* __restrict__ mov_var,
+                                                                  float* __restrict__ stat) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double rstd = 1.0 / sqrt((double)mov_var[c] + 1e-3);
+    const double scale = (double)gamma[c] * rstd;
+    stat[c] = mov_mean[c];
+    stat[C + c] = (float)rstd;
+    stat[2 * C + c] = (float)scale;
+    stat[3 * C + c] = (float)((double)beta[c] - (double)mov_mean[c] * scale);
+}
+
+hipError_t launch_bn_stat_from_moving(int C, const float* gamma, const float* beta, const float* mov_mean,
+                                      const float* mov_var, float* stat, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_stat_from_moving_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, C, gamma, beta,
+                       mov_mean, mov_var, stat);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ dropout stream
 // == oracle/train_oracle.py dropout_mask: u = top 24 bits of mix(key ^ flat NHWC index); keep iff u >= rate
 __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
@@ -432,6 +454,29 @@ hipError_t launch_softmax_loss(const float* t0, const float* stat, const float* 
     if (K > kMaxK) return hipErrorInvalidValue;
     hipLaunchKernelGGL(softmax_loss_kernel, dim3((unsigned)nblk), dim3(256), 0, stream, t0, stat, labels, weights, N, K,
                        clip_eps, probs, dt, part);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) softmax_only_kernel(const float* __restrict__ t0, const float* __restrict__ stat,
+                                                           size_t N, int K, float* __restrict__ probs) {
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= N) return;
+    float t[kMaxK];
+    float mx = -3.0e38f, den = 0.f;
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k)
+        if (k < K) { t[k] = t0[p * K + k] * stat[2 * K + k] + stat[3 * K + k]; mx = fmaxf(mx, t[k]); }
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k)
+        if (k < K) { t[k] = expf(t[k] - mx); den += t[k]; }
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k)
+        if (k < K) probs[p * K + k] = t[k] / den;
+}
+
+hipError_t launch_softmax_only(const float* t0, const float* stat, size_t N, int K, float* probs, hipStream_t stream) {
+    if (K > kMaxK) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(softmax_only_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, t0, stat, N, K, probs);
     return hipGetLastError();
 }
 

@@ -26,7 +26,7 @@ TV_PARAMS, TV_GRADS, TV_SLOT_M, TV_SLOT_V = 0, 1, 2, 3
 EXPORTS = [
     "umx_train_options_solo", "umx_train_options_duo", "umx_trainer_create", "umx_trainer_destroy",
     "umx_trainer_last_error", "umx_train_step", "umx_train_step_dev", "umx_trainer_loss", "umx_trainer_read",
-    "umx_trainer_probs", "umx_trainer_step_count", "umx_trainer_batch", "umx_trainer_flops_per_image",
+    "umx_trainer_probs", "umx_trainer_eval", "umx_trainer_step_count", "umx_trainer_batch", "umx_trainer_flops_per_image",
     "umx_trainer_profile",
 ]
 
@@ -106,6 +106,8 @@ def _bind(L):
     L.umx_trainer_read.argtypes = [c_void_p, c_int, c_void_p, ctypes.c_size_t]
     L.umx_trainer_probs.restype = c_int
     L.umx_trainer_probs.argtypes = [c_void_p, c_void_p]
+    L.umx_trainer_eval.restype = c_int
+    L.umx_trainer_eval.argtypes = [c_void_p, c_void_p, c_void_p]
     L.umx_trainer_step_count.restype = ctypes.c_int64
     L.umx_trainer_step_count.argtypes = [c_void_p]
     L.umx_trainer_batch.restype = c_int
@@ -213,6 +215,16 @@ class Trainer:
         hp = self.hp
         out = np.empty((self.batch, hp.imSize, hp.imSize, hp.nClasses), np.float32)
         self._check(self._lib.umx_trainer_probs(self._h, out.ctypes.data))
+        return out
+
+    def eval(self, data) -> np.ndarray:
+        """Inference-mode forward of one batch with the current variables (``tfTraining: 0``) -> probabilities."""
+        hp = self.hp
+        d = np.ascontiguousarray(data, dtype=np.float32)
+        if d.shape != (self.batch, hp.imSize, hp.imSize, hp.nChannels):
+            raise ValueError("data must be %r, got %r" % ((self.batch, hp.imSize, hp.imSize, hp.nChannels), d.shape))
+        out = np.empty((self.batch, hp.imSize, hp.imSize, hp.nClasses), np.float32)
+        self._check(self._lib.umx_trainer_eval(self._h, d.ctypes.data, out.ctypes.data))
         return out
 
     @property
