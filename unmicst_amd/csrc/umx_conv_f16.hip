@@ -164,18 +164,33 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
 #pragma unroll
             for (int j = 0; j < kStageK; ++j) {
                 if (j < cur.nk) {
-                    const unsigned char* const ap = smem + kbs[j];
                     const unsigned char* const bp = wl + 64 + j * (NT * 2048) + lane * 16;
+                    const unsigned char* const ap = smem + kbs[j];
                     h8 ah[KMT], al[KMT];
 #pragma unroll
                     for (int m = 0; m < KMT; ++m) {
                         ah[m] = *reinterpret_cast<const h8*>(ap + abase[m]);
                         al[m] = *reinterpret_cast<const h8*>(ap + abase[m] + lo_off);
                     }
+                    // B (weight) fragments are streamed with a prefetch distance of two N-tiles (three (hi, lo) pairs live),
+                    // and the scheduler is asked for its DS-read / MFMA interleaving pipeline (iglp_opt 0): left to itself it
+                    // puts a full lgkmcnt(0) wait between a fragment read and the MFMA block of the previous tile
+                    // (+4 % on the whole bench; explicit sched_group_barrier patterns were slower).
+                    constexpr int kBPre = 2;
+                    h8 bhq[kBPre + 1], blq[kBPre + 1];
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) {   // B fragments are streamed: two live at a time
-                        const h8 bh = *reinterpret_cast<const h8*>(bp + n * 2048);
-                        const h8 bl = *reinterpret_cast<const h8*>(bp + n * 2048 + 1024);
+                    for (int n = 0; n < kBPre && n < NT; ++n) {
+                        bhq[n] = *reinterpret_cast<const h8*>(bp + n * 2048);
+                        blq[n] = *reinterpret_cast<const h8*>(bp + n * 2048 + 1024);
+                    }
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        __builtin_amdgcn_iglp_opt(0);
+                        if (n + kBPre < NT) {
+                            bhq[(n + kBPre) % (kBPre + 1)] = *reinterpret_cast<const h8*>(bp + (n + kBPre) * 2048);
+                            blq[(n + kBPre) % (kBPre + 1)] = *reinterpret_cast<const h8*>(bp + (n + kBPre) * 2048 + 1024);
+                        }
+                        const h8 bh = bhq[n % (kBPre + 1)], bl = blq[n % (kBPre + 1)];
 #pragma unroll
                         for (int m = 0; m < KMT; ++m) {
                             // weights are the A operand (rows = output channels), activations the B operand (columns =

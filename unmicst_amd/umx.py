@@ -90,7 +90,7 @@ def load(path: Optional[str] = None):
     global _lib
     if _lib is not None:
         return _lib
-    path = path or _build.lib_path()
+    path = path or os.environ.get("UMX_LIB") or _build.lib_path()   # UMX_LIB: an alternative build (kernel experiments)
     if not os.path.exists(path):
         raise FileNotFoundError("%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                 "(libumx has no CPU fallback)" % path)
