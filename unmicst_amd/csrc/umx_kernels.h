@@ -238,7 +238,18 @@ struct WgradParams {
     int mi;                       // input-channel tiles (of 16) per workgroup: 1..3
     int vecx, vecg;               // 16-byte loads allowed
     float* ws;                    // [slice][slab][Cx][Cg]
+    // split-precision variant (wgrad_f16x3): 48 x 48 channel tiles, operands staged as (hi, lo) binary16 planes
+    int f16;                      // 1: use it (W >= 8, Cx > 4, <= 9 slabs per group); 0: fp32 MFMA kernel
+    int hp, xs, gs;               // halo row pitch, X / G channel strides in LDS (halves)
+    const unsigned* xmax;         // device word holding max|X| as float bits (gradient operand), or NULL: activation
+    const unsigned* gmax;         // same for G
+    int* overflow;                // set when a scaled operand leaves the binary16 range
 };
+// max |v| of a gradient tensor is tracked by its producer (bit pattern of a non-negative float, atomicMax on uint)
+hipError_t launch_bn_bwd_apply_max(float* g, const float* z, const float* stat, const float* m12, size_t N, int C,
+                                   unsigned* gmax, hipStream_t stream);
+hipError_t launch_leaky_bwd_s2d_max(const float* d_us, const float* us, int B, int S, int C, float* gS, unsigned* gmax,
+                                    hipStream_t stream);
 bool wgrad_setup(WgradParams* p, std::string* why);   // fills geometry, slab groups and slices from B,H,W,Cx,Cg,nslab,dy,dx,coff
 size_t wgrad_ws_floats(const WgradParams& p);
 hipError_t launch_wgrad(const WgradParams& p, hipStream_t stream);

@@ -47,6 +47,7 @@ struct BnSite {            // one batch-normalised tensor
     float* z = nullptr;    // [B,H,W,C] pre-BN
     float* stat = nullptr; // [4][C]
     float* m12 = nullptr;  // [2][C]
+    unsigned* gmax = nullptr;   // max |dz| of the current step (float bits), for the split-precision weight gradient
 };
 
 struct Seg { std::string name; size_t off, n; float reg; };
@@ -80,6 +81,8 @@ struct umx_trainer {
     float *DA = nullptr, *DB = nullptr, *DZ = nullptr, *GS = nullptr;
     double* d_part = nullptr;  size_t part_doubles = 0;
     double* d_loss = nullptr;           // [0] data term, [1] regularisation
+    unsigned* d_maxw = nullptr;  int n_maxw = 0;   // per-tensor max |gradient| words, then the binary16 range flag
+    std::vector<unsigned*> smax;        // max |gS| per up layer
     float* d_ws = nullptr;  size_t ws_floats = 0;
     float* d_split = nullptr;  size_t split_floats = 0;   // partial outputs of K-split convolutions
     // launches
@@ -371,15 +374,18 @@ int bn_backward(umx_trainer* tr, BnSite& s, const ActParams& a, const float* dy0
     const int nblk = chan_blocks(rows, s.C);
     T_HIP(tr, launch_act_bwd(a, dy0, dy1, dz, tr->d_part, nblk, tr->stream));
     T_HIP(tr, launch_bn_bwd_finalize(tr->d_part, nblk, N, s.C, tr->d_g + s.gamma, tr->d_g + s.beta, s.m12, tr->stream));
-    T_HIP(tr, launch_bn_bwd_apply(dz, s.z, s.stat, s.m12, N, s.C, tr->stream));
+    T_HIP(tr, launch_bn_bwd_apply_max(dz, s.z, s.stat, s.m12, N, s.C, s.gmax, tr->stream));
     return UMX_OK;
 }
 
 int run_wgrad(umx_trainer* tr, WgradParams& w, const float* X, const float* G, int Ctot, int c_off, size_t w_off,
-              float reg, size_t pair_off /* SIZE_MAX: none */) {
+              float reg, size_t pair_off /* SIZE_MAX: none */, const unsigned* xmax, const unsigned* gmax) {
     w.X = X;
     w.G = G;
     w.ws = tr->d_ws;
+    w.xmax = xmax;
+    w.gmax = gmax;
+    w.overflow = reinterpret_cast<int*>(tr->d_maxw + tr->n_maxw);
     T_HIP(tr, launch_wgrad(w, tr->stream));
     T_HIP(tr, launch_wgrad_reduce(w, Ctot, c_off, tr->d_g + w_off, tr->d_w + w_off, reg > 0.f ? tr->o.reg_kind : 0, reg,
                                   pair_off == SIZE_MAX ? nullptr : tr->d_g + pair_off, tr->stream));
@@ -430,6 +436,7 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
     const size_t Npix = (size_t)B * P * P;
     if (tr->prof) T_HIP(tr, hipEventRecord(tr->ev[0], st));
     T_HIP(tr, hipMemsetAsync(tr->d_loss, 0, 2 * sizeof(double), st));
+    T_HIP(tr, hipMemsetAsync(tr->d_maxw, 0, (tr->n_maxw + 1) * sizeof(unsigned), st));
     T_HIP(tr, launch_pack_weights(tr->d_packs, (int)tr->packs.size(), tr->max_pack, st));
 
     T_TRY(forward_pass(tr, data, true, update));
@@ -460,19 +467,19 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         const float* layer_in = idx == L - 1 ? tr->act_b : tr->cv[idx + 1];
         ActParams a = act_params(tr, s, 0, ACT_LEAKY, up_rate(tr, idx), LAYER_UP + idx);
         T_TRY(bn_backward(tr, s, a, tr->DA, nullptr, tr->DZ));
-        T_TRY(run_wgrad(tr, tr->wg_u0[idx], tr->ds[idx], tr->DZ, Cskip + Cup, 0, tr->o_w2[idx], o.reg_up, SIZE_MAX));
-        T_TRY(run_wgrad(tr, tr->wg_u1[idx], tr->us[idx], tr->DZ, Cskip + Cup, Cskip, tr->o_w2[idx], o.reg_up, SIZE_MAX));
+        T_TRY(run_wgrad(tr, tr->wg_u0[idx], tr->ds[idx], tr->DZ, Cskip + Cup, 0, tr->o_w2[idx], o.reg_up, SIZE_MAX, nullptr, s.gmax));
+        T_TRY(run_wgrad(tr, tr->wg_u1[idx], tr->us[idx], tr->DZ, Cskip + Cup, Cskip, tr->o_w2[idx], o.reg_up, SIZE_MAX, nullptr, s.gmax));
         T_TRY(run_conv(tr, tr->c_dg_us[idx], tr->DZ, nullptr, tr->DB));
         if (idx >= 1) T_TRY(run_conv(tr, tr->c_dg_skip[idx], tr->DZ, nullptr, tr->dskip[idx]));
-        T_HIP(tr, launch_leaky_bwd_s2d(tr->DB, tr->us[idx], B, S / 2, Cup, tr->GS, st));
-        T_TRY(run_wgrad(tr, tr->wg_T[idx], tr->GS, layer_in, Cup, 0, tr->o_wt[idx], o.reg_up, SIZE_MAX));
+        T_HIP(tr, launch_leaky_bwd_s2d_max(tr->DB, tr->us[idx], B, S / 2, Cup, tr->GS, tr->smax[idx], st));
+        T_TRY(run_wgrad(tr, tr->wg_T[idx], tr->GS, layer_in, Cup, 0, tr->o_wt[idx], o.reg_up, SIZE_MAX, tr->smax[idx], nullptr));
         T_TRY(run_conv(tr, tr->c_dg_T[idx], tr->GS, nullptr, tr->DA));
         S /= 2;
     }
     {   // bottom layer
         ActParams a = act_params(tr, tr->bn_b, 0, ACT_LEAKY, o.drop_bottom, LAYER_BOTTOM);
         T_TRY(bn_backward(tr, tr->bn_b, a, tr->DA, nullptr, tr->DZ));
-        T_TRY(run_wgrad(tr, tr->wg_b, tr->ds[L], tr->DZ, tr->n[L], 0, tr->o_lb, o.reg_bottom, SIZE_MAX));
+        T_TRY(run_wgrad(tr, tr->wg_b, tr->ds[L], tr->DZ, tr->n[L], 0, tr->o_lb, o.reg_bottom, SIZE_MAX, nullptr, tr->bn_b.gmax));
         T_TRY(run_conv(tr, tr->c_dg_b, tr->DZ, nullptr, tr->DB));
     }
     for (int i = L - 1; i >= 0; --i) {     // down layers
@@ -481,7 +488,7 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         const float* dy1 = (i + 1 <= L - 1) ? tr->dskip[i + 1] : nullptr;
         T_TRY(bn_backward(tr, s, a, tr->DB, dy1, tr->DZ));
         // c00 + shortcut = conv(x, W1 + Wshort): both filters receive the same data gradient (UnMicst1-5.py:102-114)
-        T_TRY(run_wgrad(tr, tr->wg_d[i], tr->ds[i], tr->DZ, tr->n[i], 0, tr->o_ws[i], o.reg_down, tr->o_w1[i]));
+        T_TRY(run_wgrad(tr, tr->wg_d[i], tr->ds[i], tr->DZ, tr->n[i], 0, tr->o_ws[i], o.reg_down, tr->o_w1[i], nullptr, s.gmax));
         if (i >= 1) T_TRY(run_conv(tr, tr->c_dg_d[i], tr->DZ, nullptr, tr->DB));
     }
     if (tr->prof) T_HIP(tr, hipEventRecord(tr->ev[2], st));
@@ -607,6 +614,17 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
     tr->part_doubles = std::max<size_t>((size_t)1024 * 2 * maxC, (size_t)1024 * n[1] * K) + 1024;
     T_TRY(talloc(tr, &tr->d_part, tr->part_doubles));
     T_TRY(tzero(tr, &tr->d_loss, 2));
+    {   // max-|gradient| words: one per batch-normalised tensor and per up layer, + the range flag
+        tr->n_maxw = 3 * L + 2;
+        T_TRY(tzero(tr, &tr->d_maxw, (size_t)tr->n_maxw + 1));
+        int k = 0;
+        for (int i = 0; i < L; ++i) tr->bn_d[i].gmax = tr->d_maxw + k++;
+        for (int i = 0; i < L; ++i) tr->bn_u[i].gmax = tr->d_maxw + k++;
+        tr->bn_b.gmax = tr->d_maxw + k++;
+        tr->bn_t.gmax = tr->d_maxw + k++;
+        tr->smax.assign(L, nullptr);
+        for (int i = 0; i < L; ++i) tr->smax[i] = tr->d_maxw + k++;
+    }
 
     // ---- conv launches
     tr->c_fwd_d.resize(L); tr->c_dg_d.resize(L); tr->c_T.resize(L); tr->c_fwd_u.resize(L);
@@ -835,8 +853,13 @@ int umx_trainer_loss(umx_trainer* tr, double* loss3) {
     if (!tr || !loss3) return tfail(tr, UMX_ERR_INVALID, "null argument");
     T_HIP(tr, hipSetDevice(tr->device));
     double h[2] = {0, 0};
+    unsigned flag = 0;
     T_HIP(tr, hipMemcpyAsync(h, tr->d_loss, sizeof h, hipMemcpyDeviceToHost, tr->stream));
+    T_HIP(tr, hipMemcpyAsync(&flag, tr->d_maxw + tr->n_maxw, sizeof flag, hipMemcpyDeviceToHost, tr->stream));
     T_HIP(tr, hipStreamSynchronize(tr->stream));
+    if (flag)
+        return tfail(tr, UMX_ERR_RANGE, "an operand of the split-precision weight gradient left the binary16 range "
+                                        "(|v| >= 6e4 after scaling or not finite); set UMX_TRAIN_WGRAD_F32=1");
     loss3[0] = h[0] + h[1];
     loss3[1] = h[0];
     loss3[2] = h[1];

@@ -9,6 +9,7 @@
 #include "umx_kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -328,41 +329,74 @@ hipError_t launch_bn_bwd_finalize(const double* part, int nblk, size_t N, int C,
     return hipGetLastError();
 }
 
+// max |v| over a block -> one atomicMax on the tensor's word (uint order == float order for non-negative floats;
+// integer max is associative: the result does not depend on the order of the blocks)
+__device__ __forceinline__ void block_absmax_to(unsigned* dst, float v) {
+    __shared__ unsigned smax[4];
+    unsigned u = __float_as_uint(fabsf(v));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, off));
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = u;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(dst, max(max(smax[0], smax[1]), max(smax[2], smax[3])));
+}
+
+// (grid-stride over at most 1024 blocks: one atomic per block on the tensor's max word)
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ z,
                                                            const float* __restrict__ stat, const float* __restrict__ m12,
-                                                           size_t n, int C) {
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
-    const int c = (int)(e % C);
-    const float xh = (z[e] - stat[c]) * stat[C + c];
-    g[e] = stat[2 * C + c] * (g[e] - m12[c] - xh * m12[C + c]);
+                                                           size_t n, int C, unsigned* gmax) {
+    float mx = 0.f;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const float xh = (z[e] - stat[c]) * stat[C + c];
+        const float v = stat[2 * C + c] * (g[e] - m12[c] - xh * m12[C + c]);
+        g[e] = v;
+        mx = fmaxf(mx, fabsf(v));
+    }
+    if (gmax) block_absmax_to(gmax, mx);
+}
+
+hipError_t launch_bn_bwd_apply_max(float* g, const float* z, const float* stat, const float* m12, size_t N, int C,
+                                   unsigned* gmax, hipStream_t stream) {
+    const size_t n = N * C;
+    const unsigned blocks = (unsigned)std::min<size_t>(1024, (n + 255) / 256);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, g, z, stat, m12, n, C, gmax);
+    return hipGetLastError();
 }
 
 hipError_t launch_bn_bwd_apply(float* g, const float* z, const float* stat, const float* m12, size_t N, int C,
                                hipStream_t stream) {
-    const size_t n = N * C;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, g, z, stat, m12, n, C);
-    return hipGetLastError();
+    return launch_bn_bwd_apply_max(g, z, stat, m12, N, C, nullptr, stream);
 }
 
 __global__ void __launch_bounds__(256) leaky_bwd_s2d_kernel(const float* __restrict__ d_us, const float* __restrict__ us,
-                                                            int S, int C, float* __restrict__ gS, size_t n) {
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
-    const int c = (int)(e % C);
-    size_t r = e / C;
-    const int q = (int)(r & 3); r >>= 2;
-    const int j = (int)(r % S); r /= S;
-    const int i = (int)(r % S);
-    const size_t b = r / S;
-    const size_t src = ((b * (2 * S) + 2 * i + (q >> 1)) * (size_t)(2 * S) + 2 * j + (q & 1)) * C + c;
-    gS[e] = d_us[src] * (us[src] > 0.f ? 1.f : 0.2f);
+                                                            int S, int C, float* __restrict__ gS, size_t n, unsigned* gmax) {
+    float mx = 0.f;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        size_t r = e / C;
+        const int q = (int)(r & 3); r >>= 2;
+        const int j = (int)(r % S); r /= S;
+        const int i = (int)(r % S);
+        const size_t b = r / S;
+        const size_t src = ((b * (2 * S) + 2 * i + (q >> 1)) * (size_t)(2 * S) + 2 * j + (q & 1)) * C + c;
+        const float v = d_us[src] * (us[src] > 0.f ? 1.f : 0.2f);
+        gS[e] = v;
+        mx = fmaxf(mx, fabsf(v));
+    }
+    if (gmax) block_absmax_to(gmax, mx);
+}
+
+hipError_t launch_leaky_bwd_s2d_max(const float* d_us, const float* us, int B, int S, int C, float* gS, unsigned* gmax,
+                                    hipStream_t stream) {
+    const size_t n = (size_t)B * S * S * 4 * C;
+    const unsigned blocks = (unsigned)std::min<size_t>(1024, (n + 255) / 256);
+    hipLaunchKernelGGL(leaky_bwd_s2d_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, d_us, us, S, C, gS, n, gmax);
+    return hipGetLastError();
 }
 
 hipError_t launch_leaky_bwd_s2d(const float* d_us, const float* us, int B, int S, int C, float* gS, hipStream_t stream) {
-    const size_t n = (size_t)B * S * S * 4 * C;
-    hipLaunchKernelGGL(leaky_bwd_s2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_us, us, S, C, gS, n);
-    return hipGetLastError();
+    return launch_leaky_bwd_s2d_max(d_us, us, B, S, C, gS, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ top layer
@@ -781,6 +815,257 @@ __global__ void __launch_bounds__(256, 2) wgrad_mfma_f32(const WgradParams p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ weight gradient, f16x3
+// The same GEMM on the binary16 matrix cores with fp32-equivalent products: x*g = xh*gh + xh*gl + xl*gh, (hi, lo) exact
+// binary16 pairs, fp32 accumulation (the scheme of conv_f16x3).  One v_mfma_f32_16x16x32_f16 covers
+// 32 pixels of K where the fp32 MFMA covers 4: 3 x 16 cycles instead of 8 x 32.
+//   * Operands are converted while they are staged: fp32 NHWC from HBM -> scaled -> (hi, lo) -> channel-planar LDS
+//     [plane][channel][pixel] (a fragment = 8 consecutive pixels of one channel = one ds_read_b128).  Gradient operands
+//     are scaled by a power of two that brings their tracked max |v| to [2^11, 2^12) (binary16 would flush them
+//     otherwise), activations by 16 (keeps the lo parts normal); the reduce kernel divides the product of the scales out.
+//   * A tap shifts the X window by dx pixels = dx halves: the fragment is read as an aligned b128 + b32 and funnel-
+//     shifted (v_alignbit) -- no per-tap copies of the halo.
+//   * 48 x 48 channel tiles (the 36*2^k and 80*2^k widths of the shipped models pad to multiples of 48 with <= 1.33x):
+//     the 9 taps x 3 channel tiles = 27 (tap, tile) pairs are dealt 7/7/7/6 to the four waves, each wave against all
+//     three output-channel tiles, so every X fragment is read once per workgroup and every wave is busy.
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+constexpr int kHwC = 48, kHwPW = 7, kHwXT = 5, kHwGT = 3;
+
+__device__ __forceinline__ float wg_scale(const unsigned* mx) {
+    if (!mx) return 16.f;
+    const int e = (int)((*mx >> 23) & 0xff);          // biased exponent of max |v|
+    if (e == 0 || e == 255) return 1.f;
+    const int se = min(max(127 + 11 - (e - 127), 1), 254);
+    return __uint_as_float((unsigned)se << 23);        // max * scale in [2^11, 2^12)
+}
+
+__device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+__global__ void __launch_bounds__(256, 2) wgrad_f16x3(const WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    _Float16* const Xh = reinterpret_cast<_Float16*>(smem_b);   // [2][48][xs]
+    _Float16* const Gh = Xh + 2 * kHwC * p.xs;                  // [2][48][gs]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = lane >> 4, li = lane & 15;
+    const int TW = 1 << p.tw_log2, TH = 1 << p.th_log2;
+    const int imgplaneP = p.hh * p.hp;
+
+    const int slice = blockIdx.x;
+    const int nco = (p.Cg + kHwC - 1) / kHwC;
+    const int ci0 = (blockIdx.y / nco) * kHwC, co0 = (blockIdx.y % nco) * kHwC;
+    const int slab0 = p.gstart[blockIdx.z], ns = p.gcount[blockIdx.z];
+    const int coff = p.coff[slab0];
+    const float sx = wg_scale(p.xmax), sg = wg_scale(p.gmax);
+
+    // this wave's (slab, channel tile) pairs
+    const int npairs = ns * 3, pair0 = wave * kHwPW;
+    int aoff[kHwPW], dxs[kHwPW], sbi[kHwPW], t2i[kHwPW];
+#pragma unroll
+    for (int i = 0; i < kHwPW; ++i) {
+        const int id = min(pair0 + i, npairs - 1);
+        const int sb = id / 3, t2 = id - sb * 3;
+        sbi[i] = __builtin_amdgcn_readfirstlane(sb);
+        t2i[i] = __builtin_amdgcn_readfirstlane(t2);
+        aoff[i] = __builtin_amdgcn_readfirstlane(t2 * 16 * p.xs + (p.dy[slab0 + sb] - p.ymin) * p.hp);
+        dxs[i] = __builtin_amdgcn_readfirstlane(p.dx[slab0 + sb] - p.xmin);
+    }
+    f32x4 acc[kHwPW][3];
+#pragma unroll
+    for (int i = 0; i < kHwPW; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int prow = (p.hw + 1) >> 1;                       // pixel pairs per halo row
+    const int nxt = p.imgs * p.hh * prow * (kHwC / 4);      // X staging tasks: (halo row, pixel pair, channel quad)
+    float4 xr[kHwXT][2], gr[kHwGT][2];
+    auto load_tile = [&](int t) {
+        const int tx = t % p.tiles_x;
+        const int ty = (t / p.tiles_x) % p.tiles_y;
+        const int img0 = (t / (p.tiles_x * p.tiles_y)) * p.imgs;
+        const int y0 = ty * TH, x0 = tx * TW;
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+#pragma unroll
+        for (int i = 0; i < kHwXT; ++i) {
+            const int e = tid_o + i * 256;
+            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+            if (e < nxt) {
+                const int pr = e % prow;                      // pixel pair fastest: conflict-free LDS stores
+                int r = e / prow;
+                const int q = r % (kHwC / 4); r /= (kHwC / 4);
+                const int il = r / p.hh, hy = r - il * p.hh;
+                const int gy = y0 + p.ymin + hy, gx = x0 + p.xmin + 2 * pr, img = img0 + il;
+                const int c = ci0 + 4 * q;
+                if (img < p.B && gy >= 0 && gy < p.H && c < p.Cx) {
+                    const float* row = p.X + ((size_t)(img * p.H + gy) * p.W) * p.Cxt + coff + c;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int gxx = gx + h;
+                        if (gxx >= 0 && gxx < p.W && 2 * pr + h < p.hw) {
+                            const float* src = row + (size_t)gxx * p.Cxt;
+                            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (p.vecx && c + 3 < p.Cx) v = *reinterpret_cast<const float4*>(src);
+                            else {
+                                v.x = src[0];
+                                if (c + 1 < p.Cx) v.y = src[1];
+                                if (c + 2 < p.Cx) v.z = src[2];
+                                if (c + 3 < p.Cx) v.w = src[3];
+                            }
+                            if (h == 0) v0 = v; else v1 = v;
+                        }
+                    }
+                }
+            }
+            xr[i][0] = v0;
+            xr[i][1] = v1;
+        }
+#pragma unroll
+        for (int i = 0; i < kHwGT; ++i) {
+            const int e = tid_o + i * 256;              // 64 pixel pairs x 12 channel quads = 768 tasks
+            const int pp = e & 63, q = e >> 6;
+            const int px = 2 * pp;
+            const int il = px >> (p.th_log2 + p.tw_log2);
+            const int y = (px >> p.tw_log2) & (TH - 1), x = px & (TW - 1);
+            const int img = img0 + il;
+            const int co = co0 + 4 * q;
+            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+            if (img < p.B && co < p.Cg) {
+                const float* src = p.G + ((size_t)(img * p.H + y0 + y) * p.W + x0 + x) * p.Cg + co;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float* s2 = src + (size_t)h * p.Cg;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.vecg && co + 3 < p.Cg) v = *reinterpret_cast<const float4*>(s2);
+                    else {
+                        v.x = s2[0];
+                        if (co + 1 < p.Cg) v.y = s2[1];
+                        if (co + 2 < p.Cg) v.z = s2[2];
+                        if (co + 3 < p.Cg) v.w = s2[3];
+                    }
+                    if (h == 0) v0 = v; else v1 = v;
+                }
+            }
+            gr[i][0] = v0;
+            gr[i][1] = v1;
+        }
+    };
+    auto split_store = [&](_Float16* base, int plane_stride, int chan_stride, int pos, float4 a, float4 b, float sc) {
+        const float va[4] = {a.x * sc, a.y * sc, a.z * sc, a.w * sc};
+        const float vb[4] = {b.x * sc, b.y * sc, b.z * sc, b.w * sc};
+        float big = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) big = fmaxf(big, fmaxf(fabsf(va[k]), fabsf(vb[k])));
+        if (!(big < 6.0e4f)) atomicOr(p.overflow, 1);   // also catches NaN
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const _Float16 ha = (_Float16)va[k], hb = (_Float16)vb[k];
+            const _Float16 la = (_Float16)(va[k] - (float)ha), lb = (_Float16)(vb[k] - (float)hb);
+            *reinterpret_cast<unsigned*>(base + k * chan_stride + pos) = pack_h2(ha, hb);
+            *reinterpret_cast<unsigned*>(base + plane_stride + k * chan_stride + pos) = pack_h2(la, lb);
+        }
+    };
+    auto store_tile = [&]() {
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
+#pragma unroll
+        for (int i = 0; i < kHwXT; ++i) {
+            const int e = tid_o + i * 256;
+            if (e < nxt) {
+                const int pr = e % prow;
+                int r = e / prow;
+                const int q = r % (kHwC / 4); r /= (kHwC / 4);   // r = il * hh + hy
+                split_store(Xh + (4 * q) * p.xs, kHwC * p.xs, p.xs, r * p.hp + 2 * pr, xr[i][0], xr[i][1], sx);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kHwGT; ++i) {
+            const int e = tid_o + i * 256;
+            const int pp = e & 63, q = e >> 6;
+            split_store(Gh + (4 * q) * p.gs, kHwC * p.gs, p.gs, 2 * pp, gr[i][0], gr[i][1], sg);
+        }
+    };
+
+    const bool live1 = co0 + 16 < p.Cg, live2 = co0 + 32 < p.Cg;
+    const int t_begin = slice * p.tiles_per_slice;
+    const int t_end = min(p.ntiles, (slice + 1) * p.tiles_per_slice);
+    if (t_begin < t_end) load_tile(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (t + 1 < t_end) load_tile(t + 1);
+        for (int ks = 0; ks < kWgPix / 32; ++ks) {
+            const int p0 = 32 * ks + 8 * kq;
+            const int il = p0 >> (p.th_log2 + p.tw_log2);
+            const int y = (p0 >> p.tw_log2) & (TH - 1), x = p0 & (TW - 1);
+            const _Float16* const gp = Gh + li * p.gs + p0;
+            h8v gh[3], gl[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                gh[j] = *reinterpret_cast<const h8v*>(gp + j * 16 * p.gs);
+                gl[j] = *reinterpret_cast<const h8v*>(gp + (kHwC + j * 16) * p.gs);
+            }
+            const _Float16* const xp = Xh + li * p.xs + il * imgplaneP + y * p.hp + x;
+#pragma unroll
+            for (int i = 0; i < kHwPW; ++i) {
+                if (pair0 + i < npairs) {
+                    h8v xf[2];
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+                        const _Float16* a = xp + aoff[i] + pl * kHwC * p.xs;
+                        const uint4 d = *reinterpret_cast<const uint4*>(a);
+                        const unsigned d4 = *reinterpret_cast<const unsigned*>(a + 8);
+                        uint4 f;
+                        if (dxs[i] == 0) f = d;
+                        else if (dxs[i] == 1) {
+                            f.x = __builtin_amdgcn_alignbit(d.y, d.x, 16);
+                            f.y = __builtin_amdgcn_alignbit(d.z, d.y, 16);
+                            f.z = __builtin_amdgcn_alignbit(d.w, d.z, 16);
+                            f.w = __builtin_amdgcn_alignbit(d4, d.w, 16);
+                        } else f = make_uint4(d.y, d.z, d.w, d4);
+                        xf[pl] = __builtin_bit_cast(h8v, f);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        if (j == 0 || (j == 1 && live1) || (j == 2 && live2)) {
+                            f32x4 c = acc[i][j];
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[0], gl[j], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[1], gh[j], c, 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[0], gh[j], c, 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    const size_t slab_sz = (size_t)p.Cx * p.Cg;
+#pragma unroll
+    for (int i = 0; i < kHwPW; ++i) {
+        if (pair0 + i < npairs) {
+            float* dst = p.ws + ((size_t)slice * p.nslab + slab0 + sbi[i]) * slab_sz;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int co = co0 + j * 16 + li;
+                if (co < p.Cg) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ci = ci0 + t2i[i] * 16 + 4 * kq + r;
+                        if (ci < p.Cx) dst[(size_t)ci * p.Cg + co] = acc[i][j][r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+static size_t wgrad_f16_lds(const WgradParams& p) { return sizeof(_Float16) * 2 * kHwC * ((size_t)p.xs + p.gs); }
+
 bool wgrad_setup(WgradParams* p, std::string* why) {
     auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
     if (p->nslab < 1 || p->nslab > kWgMaxSlabs) { *why = "wgrad: too many filter taps"; return false; }
@@ -820,6 +1105,23 @@ bool wgrad_setup(WgradParams* p, std::string* why) {
         ++p->ngroups;
         s += n;
     }
+    p->f16 = 0;
+    if (TW >= 8 && p->Cx > 4 && !getenv("UMX_TRAIN_WGRAD_F32")) {
+        auto stride_halves = [](int halves) { int dw = (halves + 1) / 2; while (dw % 16 != 8) ++dw; return 2 * dw; };
+        p->hp = (p->hw + 7) / 8 * 8;
+        p->xs = stride_halves(p->imgs * p->hh * p->hp);
+        p->gs = stride_halves(kWgPix);
+        const int tasks = p->imgs * p->hh * ((p->hw + 1) / 2) * (kHwC / 4);
+        if (tasks <= kHwXT * 256 && wgrad_f16_lds(*p) <= 160 * 1024) {
+            p->f16 = 1;
+            p->mi = 3;
+            const int chunks = ((p->Cx + kHwC - 1) / kHwC) * ((p->Cg + kHwC - 1) / kHwC) * p->ngroups;
+            int nslices = std::max(1, std::min(p->ntiles, 1024 / std::max(1, chunks)));
+            p->tiles_per_slice = (p->ntiles + nslices - 1) / nslices;
+            p->nslices = (p->ntiles + p->tiles_per_slice - 1) / p->tiles_per_slice;
+            return true;
+        }
+    }
     // input-channel tiles per workgroup: fewest padded tiles, each chunk charged one tile for its G traffic
     if (p->nhalo > kWgHaloBig) { *why = "wgrad: halo too large"; return false; }
     const int mi_max = p->nhalo > kWgHalo ? 2 : 3;
@@ -858,6 +1160,19 @@ static hipError_t launch_wgrad_mi(const WgradParams& p, hipStream_t stream) {
 }
 
 hipError_t launch_wgrad(const WgradParams& p, hipStream_t stream) {
+    if (p.f16) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16x3),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        const unsigned chunks = (unsigned)(((p.Cx + kHwC - 1) / kHwC) * ((p.Cg + kHwC - 1) / kHwC));
+        hipLaunchKernelGGL(wgrad_f16x3, dim3((unsigned)p.nslices, chunks, (unsigned)p.ngroups), dim3(256), wgrad_f16_lds(p),
+                           stream, p);
+        return hipGetLastError();
+    }
     const bool big = p.nhalo > kWgHalo;
     if (p.nhalo > kWgHaloBig || (big && p.mi > 2)) return hipErrorInvalidValue;
     switch (p.mi) {
@@ -876,6 +1191,9 @@ struct WgReduce {
     int reg_kind;
     float reg_c;
     float* g2;
+    const unsigned* xmax;     // split-precision launches: the operand scales are divided out here
+    const unsigned* gmax;
+    int f16;
     short mslab[kWgMaxSlabs];
 };
 
@@ -899,6 +1217,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WgReduce q, int
     const int ci = (int)(r % q.Cx);
     const int sb = (int)(r / q.Cx);
     const size_t dsti = ((size_t)q.mslab[sb] * q.Ctot + q.c_off + ci) * q.Cg + co;
+    if (q.f16) s /= (double)wg_scale(q.xmax) * (double)wg_scale(q.gmax);
     float v = (float)s;
     if (q.g2) q.g2[dsti] = v;
     if (q.w && q.reg_kind) v += reg_grad(q.w[dsti], q.reg_kind, q.reg_c);
@@ -910,6 +1229,7 @@ hipError_t launch_wgrad_reduce(const WgradParams& p, int Ctot, int c_off, float*
     WgReduce q;
     q.ws = p.ws; q.nslices = p.nslices; q.nslab = p.nslab; q.Cx = p.Cx; q.Cg = p.Cg; q.Ctot = Ctot; q.c_off = c_off;
     q.g = g; q.w = w; q.reg_kind = reg_kind; q.reg_c = reg_c; q.g2 = g2;
+    q.xmax = p.xmax; q.gmax = p.gmax; q.f16 = p.f16;
     for (int s = 0; s < kWgMaxSlabs; ++s) q.mslab[s] = s < p.nslab ? p.mslab[s] : 0;
     const size_t n = (size_t)p.nslab * p.Cx * p.Cg;
     int SP = 1;
