@@ -79,12 +79,18 @@ struct umx_trainer {
     float *d_labels = nullptr, *d_weights = nullptr, *d_probs = nullptr, *d_dt = nullptr;
     std::vector<float*> dskip;          // gradient w.r.t. ds[idx] from the up path (idx >= 1)
     float *DA = nullptr, *DB = nullptr, *DZ = nullptr, *GS = nullptr;
+    float* DZ2[2] = {nullptr, nullptr};   // gradient w.r.t. a conv output, double-buffered: the weight gradients of layer l
+    float* GS2[2] = {nullptr, nullptr};   // run on the side stream while the main stream moves on to layer l+1
+    hipStream_t side = nullptr;
+    hipEvent_t ev_dz[2] = {nullptr, nullptr}, ev_gs[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr}, ev_join = nullptr;
+    bool overlap = true;
     double* d_part = nullptr;  size_t part_doubles = 0;
     double* d_loss = nullptr;           // [0] data term, [1] regularisation
     unsigned* d_maxw = nullptr;  int n_maxw = 0;   // per-tensor max |gradient| words, then the binary16 range flag
     std::vector<unsigned*> smax;        // max |gS| per up layer
     float* d_ws = nullptr;  size_t ws_floats = 0;
     float* d_split = nullptr;  size_t split_floats = 0;   // partial outputs of K-split convolutions
+    float* d_split2 = nullptr;                            // ... of those enqueued on the side stream
     // launches
     std::vector<TConv> c_fwd_d, c_dg_d, c_T, c_fwd_u, c_dg_us, c_dg_skip, c_dg_T;
     TConv c_fwd_b, c_dg_b;
@@ -277,20 +283,22 @@ int setup_conv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int C
     return UMX_OK;
 }
 
-int run_conv(umx_trainer* tr, TConv& tc, const float* src0, const float* src1, float* dst) {
+int run_conv(umx_trainer* tr, TConv& tc, const float* src0, const float* src1, float* dst, bool on_side = false) {
     ConvParams p = tc.cp;
     p.src[0] = src0;
     p.src[1] = src1;
     p.dst = dst;
     p.B = tr->B;
+    hipStream_t st = on_side ? tr->side : tr->stream;
+    float* split = on_side ? tr->d_split2 : tr->d_split;     // each stream has its own K-split scratch
     if (p.ksplit > 1) {
-        p.dst = tr->d_split;
+        p.dst = split;
         p.act = ACT_NONE;
-        T_HIP(tr, launch_conv(p, tc.nt, tc.hpix, tr->stream));
-        T_HIP(tr, launch_split_reduce(tr->d_split, p.ksplit, p.split_stride, p.split_stride, tc.cp.act, dst, tr->stream));
+        T_HIP(tr, launch_conv(p, tc.nt, tc.hpix, st));
+        T_HIP(tr, launch_split_reduce(split, p.ksplit, p.split_stride, p.split_stride, tc.cp.act, dst, st));
         return UMX_OK;
     }
-    T_HIP(tr, launch_conv(p, tc.nt, tc.hpix, tr->stream));
+    T_HIP(tr, launch_conv(p, tc.nt, tc.hpix, st));
     return UMX_OK;
 }
 
@@ -379,16 +387,17 @@ int bn_backward(umx_trainer* tr, BnSite& s, const ActParams& a, const float* dy0
 }
 
 int run_wgrad(umx_trainer* tr, WgradParams& w, const float* X, const float* G, int Ctot, int c_off, size_t w_off,
-              float reg, size_t pair_off /* SIZE_MAX: none */, const unsigned* xmax, const unsigned* gmax) {
+              float reg, size_t pair_off /* SIZE_MAX: none */, const unsigned* xmax, const unsigned* gmax,
+              hipStream_t stream) {
     w.X = X;
     w.G = G;
     w.ws = tr->d_ws;
     w.xmax = xmax;
     w.gmax = gmax;
     w.overflow = reinterpret_cast<int*>(tr->d_maxw + tr->n_maxw);
-    T_HIP(tr, launch_wgrad(w, tr->stream));
+    T_HIP(tr, launch_wgrad(w, stream));
     T_HIP(tr, launch_wgrad_reduce(w, Ctot, c_off, tr->d_g + w_off, tr->d_w + w_off, reg > 0.f ? tr->o.reg_kind : 0, reg,
-                                  pair_off == SIZE_MAX ? nullptr : tr->d_g + pair_off, tr->stream));
+                                  pair_off == SIZE_MAX ? nullptr : tr->d_g + pair_off, stream));
     return UMX_OK;
 }
 
@@ -460,36 +469,82 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         T_HIP(tr, launch_reduce_partials(tr->d_part, nblk, tr->n[1] * K, 1.0, tr->d_g + tr->o_lt, tr->d_w + tr->o_lt,
                                          o.reg_top > 0.f ? o.reg_kind : 0, o.reg_top, st));
     }
+    // The weight gradients hang off the critical path (gradient w.r.t. conv output -> input gradient -> next layer):
+    // they run on a side stream against double-buffered dz / gS while the main stream continues.  Ordering is by events
+    // only; every kernel still has a fixed summation order, so the step stays bit-reproducible.
+    hipStream_t ws = tr->overlap ? tr->side : st;
+    int slot = 0;
+    bool used[2] = {false, false};
+    auto dz_begin = [&](int sl) -> int {      // main: the slot's previous consumers on the side stream are done
+        if (tr->overlap && used[sl]) T_HIP(tr, hipStreamWaitEvent(st, tr->ev_side[sl], 0));
+        return UMX_OK;
+    };
+    auto dz_ready = [&](int sl) -> int {      // main has written DZ2[sl]; the side stream may read it
+        if (tr->overlap) {
+            T_HIP(tr, hipEventRecord(tr->ev_dz[sl], st));
+            T_HIP(tr, hipStreamWaitEvent(ws, tr->ev_dz[sl], 0));
+        }
+        return UMX_OK;
+    };
+    auto side_done = [&](int sl) -> int {
+        if (tr->overlap) T_HIP(tr, hipEventRecord(tr->ev_side[sl], ws));
+        used[sl] = true;
+        return UMX_OK;
+    };
     int S = P;
     for (int idx = 0; idx < L; ++idx) {    // up layers, output side first
         BnSite& s = tr->bn_u[idx];
         const int Cskip = tr->n[idx], Cup = tr->n[idx + 1];
         const float* layer_in = idx == L - 1 ? tr->act_b : tr->cv[idx + 1];
+        float* dz = tr->DZ2[slot];
+        float* gs = tr->GS2[slot];
         ActParams a = act_params(tr, s, 0, ACT_LEAKY, up_rate(tr, idx), LAYER_UP + idx);
-        T_TRY(bn_backward(tr, s, a, tr->DA, nullptr, tr->DZ));
-        T_TRY(run_wgrad(tr, tr->wg_u0[idx], tr->ds[idx], tr->DZ, Cskip + Cup, 0, tr->o_w2[idx], o.reg_up, SIZE_MAX, nullptr, s.gmax));
-        T_TRY(run_wgrad(tr, tr->wg_u1[idx], tr->us[idx], tr->DZ, Cskip + Cup, Cskip, tr->o_w2[idx], o.reg_up, SIZE_MAX, nullptr, s.gmax));
-        T_TRY(run_conv(tr, tr->c_dg_us[idx], tr->DZ, nullptr, tr->DB));
-        if (idx >= 1) T_TRY(run_conv(tr, tr->c_dg_skip[idx], tr->DZ, nullptr, tr->dskip[idx]));
-        T_HIP(tr, launch_leaky_bwd_s2d_max(tr->DB, tr->us[idx], B, S / 2, Cup, tr->GS, tr->smax[idx], st));
-        T_TRY(run_wgrad(tr, tr->wg_T[idx], tr->GS, layer_in, Cup, 0, tr->o_wt[idx], o.reg_up, SIZE_MAX, tr->smax[idx], nullptr));
-        T_TRY(run_conv(tr, tr->c_dg_T[idx], tr->GS, nullptr, tr->DA));
+        T_TRY(dz_begin(slot));
+        T_TRY(bn_backward(tr, s, a, tr->DA, nullptr, dz));
+        T_TRY(dz_ready(slot));
+        T_TRY(run_wgrad(tr, tr->wg_u0[idx], tr->ds[idx], dz, Cskip + Cup, 0, tr->o_w2[idx], o.reg_up, SIZE_MAX, nullptr, s.gmax, ws));
+        T_TRY(run_wgrad(tr, tr->wg_u1[idx], tr->us[idx], dz, Cskip + Cup, Cskip, tr->o_w2[idx], o.reg_up, SIZE_MAX, nullptr, s.gmax, ws));
+        T_TRY(run_conv(tr, tr->c_dg_us[idx], dz, nullptr, tr->DB));
+        if (idx >= 1) T_TRY(run_conv(tr, tr->c_dg_skip[idx], dz, nullptr, tr->dskip[idx]));   // (side stream: 2 % slower)
+        T_HIP(tr, launch_leaky_bwd_s2d_max(tr->DB, tr->us[idx], B, S / 2, Cup, gs, tr->smax[idx], st));
+        if (tr->overlap) {
+            T_HIP(tr, hipEventRecord(tr->ev_gs[slot], st));
+            T_HIP(tr, hipStreamWaitEvent(ws, tr->ev_gs[slot], 0));
+        }
+        T_TRY(run_wgrad(tr, tr->wg_T[idx], gs, layer_in, Cup, 0, tr->o_wt[idx], o.reg_up, SIZE_MAX, tr->smax[idx], nullptr, ws));
+        T_TRY(side_done(slot));
+        T_TRY(run_conv(tr, tr->c_dg_T[idx], gs, nullptr, tr->DA));
+        slot ^= 1;
         S /= 2;
     }
     {   // bottom layer
+        float* dz = tr->DZ2[slot];
         ActParams a = act_params(tr, tr->bn_b, 0, ACT_LEAKY, o.drop_bottom, LAYER_BOTTOM);
-        T_TRY(bn_backward(tr, tr->bn_b, a, tr->DA, nullptr, tr->DZ));
-        T_TRY(run_wgrad(tr, tr->wg_b, tr->ds[L], tr->DZ, tr->n[L], 0, tr->o_lb, o.reg_bottom, SIZE_MAX, nullptr, tr->bn_b.gmax));
-        T_TRY(run_conv(tr, tr->c_dg_b, tr->DZ, nullptr, tr->DB));
+        T_TRY(dz_begin(slot));
+        T_TRY(bn_backward(tr, tr->bn_b, a, tr->DA, nullptr, dz));
+        T_TRY(dz_ready(slot));
+        T_TRY(run_wgrad(tr, tr->wg_b, tr->ds[L], dz, tr->n[L], 0, tr->o_lb, o.reg_bottom, SIZE_MAX, nullptr, tr->bn_b.gmax, ws));
+        T_TRY(side_done(slot));
+        T_TRY(run_conv(tr, tr->c_dg_b, dz, nullptr, tr->DB));
+        slot ^= 1;
     }
     for (int i = L - 1; i >= 0; --i) {     // down layers
         BnSite& s = tr->bn_d[i];
+        float* dz = tr->DZ2[slot];
         ActParams a = act_params(tr, s, 1, ACT_LEAKY, down_rate(tr, i), LAYER_DOWN + i);
         const float* dy1 = (i + 1 <= L - 1) ? tr->dskip[i + 1] : nullptr;
-        T_TRY(bn_backward(tr, s, a, tr->DB, dy1, tr->DZ));
+        T_TRY(dz_begin(slot));
+        T_TRY(bn_backward(tr, s, a, tr->DB, dy1, dz));
+        T_TRY(dz_ready(slot));
         // c00 + shortcut = conv(x, W1 + Wshort): both filters receive the same data gradient (UnMicst1-5.py:102-114)
-        T_TRY(run_wgrad(tr, tr->wg_d[i], tr->ds[i], tr->DZ, tr->n[i], 0, tr->o_ws[i], o.reg_down, tr->o_w1[i], nullptr, s.gmax));
-        if (i >= 1) T_TRY(run_conv(tr, tr->c_dg_d[i], tr->DZ, nullptr, tr->DB));
+        T_TRY(run_wgrad(tr, tr->wg_d[i], tr->ds[i], dz, tr->n[i], 0, tr->o_ws[i], o.reg_down, tr->o_w1[i], nullptr, s.gmax, ws));
+        T_TRY(side_done(slot));
+        if (i >= 1) T_TRY(run_conv(tr, tr->c_dg_d[i], dz, nullptr, tr->DB));
+        slot ^= 1;
+    }
+    if (tr->overlap) {   // join: the optimiser (and the caller) see every gradient
+        T_HIP(tr, hipEventRecord(tr->ev_join, ws));
+        T_HIP(tr, hipStreamWaitEvent(st, tr->ev_join, 0));
     }
     if (tr->prof) T_HIP(tr, hipEventRecord(tr->ev[2], st));
 
@@ -609,6 +664,9 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
     T_TRY(talloc(tr, &tr->DB, max_act));
     T_TRY(talloc(tr, &tr->DZ, max_act));
     T_TRY(talloc(tr, &tr->GS, max_act));
+    tr->DZ2[0] = tr->DZ; tr->GS2[0] = tr->GS;
+    T_TRY(talloc(tr, &tr->DZ2[1], max_act));
+    T_TRY(talloc(tr, &tr->GS2[1], max_act));
     int maxC = K;
     for (int v : n) maxC = std::max(maxC, v);
     tr->part_doubles = std::max<size_t>((size_t)1024 * 2 * maxC, (size_t)1024 * n[1] * K) + 1024;
@@ -745,6 +803,7 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
     tr->flops_per_image = 2.0 * mac_total;
     T_TRY(talloc(tr, &tr->d_ws, tr->ws_floats));
     T_TRY(talloc(tr, &tr->d_split, tr->split_floats));
+    T_TRY(talloc(tr, &tr->d_split2, tr->split_floats));
     {
         std::vector<RegSeg> rs;
         for (const Seg& sg : tr->segs)
@@ -818,6 +877,14 @@ int umx_trainer_create(const umx_hparams* hp, const float* weight_blob, size_t b
     if (rc == UMX_OK)
         for (int i = 0; i < 4; ++i)
             if (hipEventCreate(&tr->ev[i]) != hipSuccess) rc = tfail(tr, UMX_ERR_HIP, "hipEventCreate failed");
+    if (rc == UMX_OK) {
+        tr->overlap = !getenv("UMX_TRAIN_NO_OVERLAP");
+        if (hipStreamCreateWithFlags(&tr->side, hipStreamNonBlocking) != hipSuccess) rc = tfail(tr, UMX_ERR_HIP, "hipStreamCreate failed");
+        hipEvent_t* evs[] = {&tr->ev_dz[0], &tr->ev_dz[1], &tr->ev_gs[0], &tr->ev_gs[1], &tr->ev_side[0], &tr->ev_side[1], &tr->ev_join};
+        for (hipEvent_t* e : evs)
+            if (rc == UMX_OK && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess)
+                rc = tfail(tr, UMX_ERR_HIP, "hipEventCreate failed");
+    }
     if (rc != UMX_OK) {
         g_terr = tr->err;
         umx_trainer_destroy(tr);
@@ -834,6 +901,9 @@ void umx_trainer_destroy(umx_trainer* tr) {
     for (void* p : tr->allocs) (void)hipFree(p);
     for (int i = 0; i < 4; ++i)
         if (tr->ev[i]) (void)hipEventDestroy(tr->ev[i]);
+    if (tr->side) { (void)hipStreamSynchronize(tr->side); (void)hipStreamDestroy(tr->side); }
+    for (hipEvent_t e : {tr->ev_dz[0], tr->ev_dz[1], tr->ev_gs[0], tr->ev_gs[1], tr->ev_side[0], tr->ev_side[1], tr->ev_join})
+        if (e) (void)hipEventDestroy(e);
     if (tr->stream) (void)hipStreamDestroy(tr->stream);
     delete tr;
 }
