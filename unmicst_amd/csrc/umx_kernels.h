@@ -194,11 +194,8 @@ hipError_t launch_act_bwd(const ActParams& a, const float* dy0, const float* dy1
 // sums -> m12[2][C] = (mean g, mean g*xhat); dgamma = sum g*xhat, dbeta = sum g
 hipError_t launch_bn_bwd_finalize(const double* part, int nblk, size_t N, int C, float* dgamma, float* dbeta, float* m12,
                                   hipStream_t stream);
-// g <- scale * (g - m1 - xhat*m2)   (in place: gradient w.r.t. the conv output z)
-hipError_t launch_bn_bwd_apply(float* g, const float* z, const float* stat, const float* m12, size_t N, int C,
-                               hipStream_t stream);
-// gS[b,i,j,(pa*2+pb)*C + c] = d_us[b,2i+pa,2j+pb,c] * (us > 0 ? 1 : 0.2)
-hipError_t launch_leaky_bwd_s2d(const float* d_us, const float* us, int B, int S, int C, float* gS, hipStream_t stream);
+// (bn_bwd_apply: g <- scale * (g - m1 - xhat*m2) in place, and leaky_bwd_s2d: gS[b,i,j,(pa*2+pb)*C + c] =
+//  d_us[b,2i+pa,2j+pb,c] * (us > 0 ? 1 : 0.2), are declared with the weight-gradient kernels below: they track max |v|)
 
 // top layer: t0 = x W (1x1 conv, K <= 8 classes)
 hipError_t launch_head_fwd(const float* x, size_t N, int C, int K, const float* w, float* t0, hipStream_t stream);
@@ -245,7 +242,9 @@ struct WgradParams {
     const unsigned* gmax;         // same for G
     int* overflow;                // set when a scaled operand leaves the binary16 range
 };
-// max |v| of a gradient tensor is tracked by its producer (bit pattern of a non-negative float, atomicMax on uint)
+// BN input gradient g <- scale * (g - m1 - xhat*m2) (in place) and LeakyReLU backward + space-to-depth of the transposed
+// conv's output gradient; both track max |v| of what they write (bit pattern of a non-negative float, atomicMax on uint;
+// gmax may be NULL)
 hipError_t launch_bn_bwd_apply_max(float* g, const float* z, const float* stat, const float* m12, size_t N, int C,
                                    unsigned* gmax, hipStream_t stream);
 hipError_t launch_leaky_bwd_s2d_max(const float* d_us, const float* us, int B, int S, int C, float* gS, unsigned* gmax,

@@ -33,7 +33,6 @@ struct TConv {                       // one launch of conv_mfma_f32 with device-
     int nt = 1, hpix = 2;
     float* packed[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     double mac = 0.0;                // algorithmic multiply-accumulates per image
-    bool used = false;
 };
 
 struct TapSet {
@@ -279,7 +278,6 @@ int setup_conv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int C
             tr->max_pack = std::max(tr->max_pack, elems);
             tc.mac += (double)H * W * nt * gs[g].C * Cout;
         }
-    tc.used = true;
     return UMX_OK;
 }
 

@@ -364,11 +364,6 @@ hipError_t launch_bn_bwd_apply_max(float* g, const float* z, const float* stat, 
     return hipGetLastError();
 }
 
-hipError_t launch_bn_bwd_apply(float* g, const float* z, const float* stat, const float* m12, size_t N, int C,
-                               hipStream_t stream) {
-    return launch_bn_bwd_apply_max(g, z, stat, m12, N, C, nullptr, stream);
-}
-
 __global__ void __launch_bounds__(256) leaky_bwd_s2d_kernel(const float* __restrict__ d_us, const float* __restrict__ us,
                                                             int S, int C, float* __restrict__ gS, size_t n, unsigned* gmax) {
     float mx = 0.f;
@@ -393,10 +388,6 @@ hipError_t launch_leaky_bwd_s2d_max(const float* d_us, const float* us, int B, i
     const unsigned blocks = (unsigned)std::min<size_t>(1024, (n + 255) / 256);
     hipLaunchKernelGGL(leaky_bwd_s2d_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, d_us, us, S, C, gS, n, gmax);
     return hipGetLastError();
-}
-
-hipError_t launch_leaky_bwd_s2d(const float* d_us, const float* us, int B, int S, int C, float* gS, hipStream_t stream) {
-    return launch_leaky_bwd_s2d_max(d_us, us, B, S, C, gS, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ top layer
