@@ -15,8 +15,11 @@ from test_gpu_train import CASES, _batch, _oracle_opts  # noqa: E402
 
 
 def main():
-    for name, B, regime in CASES:
-        hp = helpers.small_hps()[name]
+    cases = list(CASES)
+    if "--full" in sys.argv:           # BASELINE.json configs[4] at full size (about a minute of CPU for the two oracle runs)
+        cases.append(("synthetic-256", 8, "duo"))
+    for name, B, regime in cases:
+        hp = model.KNOWN_HP[name] if name in model.KNOWN_HP else helpers.small_hps()[name]
         opts = trainer.solo_options() if regime == "solo" else trainer.duo_options()
         blob = model.random_blob(hp, seed=21)
         data, labels, weights = _batch(hp, B, 3)
