@@ -187,7 +187,9 @@ struct ActParams {          // y = dropout(act(z*scale + shift)) [-> 2x2 max-poo
     float drop_rate;
     unsigned long long drop_key;
 };
-hipError_t launch_act_fwd(const ActParams& a, float* out, hipStream_t stream);
+hipError_t launch_act_fwd(const ActParams& a, float* out, unsigned* omax /* max |out| word or NULL */, hipStream_t stream);
+// omax = max(omax, max |x|)  (float bits; integer atomicMax)
+hipError_t launch_absmax(const float* x, size_t n, unsigned* omax, hipStream_t stream);
 // backward of the same: g = d(loss)/d(BN output) written full-res [B,H,W,C]; part[blk][2][C] = (sum g, sum g*xhat)
 hipError_t launch_act_bwd(const ActParams& a, const float* dy0, const float* dy1, float* g, double* part, int nblk,
                           hipStream_t stream);
@@ -238,7 +240,7 @@ struct WgradParams {
     // split-precision variant (wgrad_f16x3): 48 x 48 channel tiles, operands staged as (hi, lo) binary16 planes
     int f16;                      // 1: use it (W >= 8, Cx > 4, <= 9 slabs per group); 0: fp32 MFMA kernel
     int hp, xs, gs;               // halo row pitch, X / G channel strides in LDS (halves)
-    const unsigned* xmax;         // device word holding max|X| as float bits (gradient operand), or NULL: activation
+    const unsigned* xmax;         // device word holding max|X| as float bits, written by the tensor's producer
     const unsigned* gmax;         // same for G
     int* overflow;                // set when a scaled operand leaves the binary16 range
 };

@@ -87,6 +87,8 @@ struct umx_trainer {
     double* d_loss = nullptr;           // [0] data term, [1] regularisation
     unsigned* d_maxw = nullptr;  int n_maxw = 0;   // per-tensor max |gradient| words, then the binary16 range flag
     std::vector<unsigned*> smax;        // max |gS| per up layer
+    std::vector<unsigned*> dsmax, usmax, cvmax;   // max |activation| of ds[i], us[idx], cv[idx]
+    unsigned* bmax = nullptr;           // ... of the bottom layer's output
     float* d_ws = nullptr;  size_t ws_floats = 0;
     float* d_split = nullptr;  size_t split_floats = 0;   // partial outputs of K-split convolutions
     float* d_split2 = nullptr;                            // ... of those enqueued on the side stream
@@ -411,23 +413,33 @@ int forward_pass(umx_trainer* tr, const float* data, bool training, bool update)
     hipStream_t st = tr->stream;
     const umx_train_options& o = tr->o;
     auto rate = [&](float r) { return training ? r : 0.f; };
+    // (training: every activation that the backward pass feeds to the split-precision weight gradient gets its max |v|
+    // tracked by the kernel that writes it -- the input batch and the transposed-conv outputs by a pass of their own)
     tr->ds[0] = const_cast<float*>(data);
+    if (training) T_HIP(tr, launch_absmax(data, (size_t)tr->B * tr->P * tr->P * tr->n[0], tr->dsmax[0], st));
+    int S = tr->P;
     for (int i = 0; i < L; ++i) {
         BnSite& s = tr->bn_d[i];
         T_TRY(run_conv(tr, tr->c_fwd_d[i], tr->ds[i], nullptr, s.z));
         T_TRY(bn_forward_stats(tr, s, update, training));
-        T_HIP(tr, launch_act_fwd(act_params(tr, s, 1, ACT_LEAKY, rate(down_rate(tr, i)), LAYER_DOWN + i), tr->ds[i + 1], st));
+        T_HIP(tr, launch_act_fwd(act_params(tr, s, 1, ACT_LEAKY, rate(down_rate(tr, i)), LAYER_DOWN + i), tr->ds[i + 1],
+                                 training ? tr->dsmax[i + 1] : nullptr, st));
+        S /= 2;
     }
     T_TRY(run_conv(tr, tr->c_fwd_b, tr->ds[L], nullptr, tr->bn_b.z));
     T_TRY(bn_forward_stats(tr, tr->bn_b, update, training));
-    T_HIP(tr, launch_act_fwd(act_params(tr, tr->bn_b, 0, ACT_LEAKY, rate(o.drop_bottom), LAYER_BOTTOM), tr->act_b, st));
+    T_HIP(tr, launch_act_fwd(act_params(tr, tr->bn_b, 0, ACT_LEAKY, rate(o.drop_bottom), LAYER_BOTTOM), tr->act_b,
+                             training ? tr->bmax : nullptr, st));
     const float* cur = tr->act_b;
     for (int idx = L - 1; idx >= 0; --idx) {
         BnSite& s = tr->bn_u[idx];
+        S *= 2;
         T_TRY(run_conv(tr, tr->c_T[idx], cur, nullptr, tr->us[idx]));
+        if (training) T_HIP(tr, launch_absmax(tr->us[idx], (size_t)tr->B * S * S * tr->n[idx + 1], tr->usmax[idx], st));
         T_TRY(run_conv(tr, tr->c_fwd_u[idx], tr->ds[idx], tr->us[idx], s.z));
         T_TRY(bn_forward_stats(tr, s, update, training));
-        T_HIP(tr, launch_act_fwd(act_params(tr, s, 0, ACT_LEAKY, rate(up_rate(tr, idx)), LAYER_UP + idx), tr->cv[idx], st));
+        T_HIP(tr, launch_act_fwd(act_params(tr, s, 0, ACT_LEAKY, rate(up_rate(tr, idx)), LAYER_UP + idx), tr->cv[idx],
+                                 training ? tr->cvmax[idx] : nullptr, st));
         cur = tr->cv[idx];
     }
     BnSite& t = tr->bn_t;
@@ -500,8 +512,8 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         T_TRY(dz_begin(slot));
         T_TRY(bn_backward(tr, s, a, tr->DA, nullptr, dz));
         T_TRY(dz_ready(slot));
-        T_TRY(run_wgrad(tr, tr->wg_u0[idx], tr->ds[idx], dz, Cskip + Cup, 0, tr->o_w2[idx], o.reg_up, SIZE_MAX, nullptr, s.gmax, ws));
-        T_TRY(run_wgrad(tr, tr->wg_u1[idx], tr->us[idx], dz, Cskip + Cup, Cskip, tr->o_w2[idx], o.reg_up, SIZE_MAX, nullptr, s.gmax, ws));
+        T_TRY(run_wgrad(tr, tr->wg_u0[idx], tr->ds[idx], dz, Cskip + Cup, 0, tr->o_w2[idx], o.reg_up, SIZE_MAX, tr->dsmax[idx], s.gmax, ws));
+        T_TRY(run_wgrad(tr, tr->wg_u1[idx], tr->us[idx], dz, Cskip + Cup, Cskip, tr->o_w2[idx], o.reg_up, SIZE_MAX, tr->usmax[idx], s.gmax, ws));
         T_TRY(run_conv(tr, tr->c_dg_us[idx], dz, nullptr, tr->DB));
         if (idx >= 1) T_TRY(run_conv(tr, tr->c_dg_skip[idx], dz, nullptr, tr->dskip[idx]));   // (side stream: 2 % slower)
         T_HIP(tr, launch_leaky_bwd_s2d_max(tr->DB, tr->us[idx], B, S / 2, Cup, gs, tr->smax[idx], st));
@@ -509,7 +521,8 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
             T_HIP(tr, hipEventRecord(tr->ev_gs[slot], st));
             T_HIP(tr, hipStreamWaitEvent(ws, tr->ev_gs[slot], 0));
         }
-        T_TRY(run_wgrad(tr, tr->wg_T[idx], gs, layer_in, Cup, 0, tr->o_wt[idx], o.reg_up, SIZE_MAX, tr->smax[idx], nullptr, ws));
+        T_TRY(run_wgrad(tr, tr->wg_T[idx], gs, layer_in, Cup, 0, tr->o_wt[idx], o.reg_up, SIZE_MAX, tr->smax[idx],
+                        idx == L - 1 ? tr->bmax : tr->cvmax[idx + 1], ws));
         T_TRY(side_done(slot));
         T_TRY(run_conv(tr, tr->c_dg_T[idx], gs, nullptr, tr->DA));
         slot ^= 1;
@@ -521,7 +534,7 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         T_TRY(dz_begin(slot));
         T_TRY(bn_backward(tr, tr->bn_b, a, tr->DA, nullptr, dz));
         T_TRY(dz_ready(slot));
-        T_TRY(run_wgrad(tr, tr->wg_b, tr->ds[L], dz, tr->n[L], 0, tr->o_lb, o.reg_bottom, SIZE_MAX, nullptr, tr->bn_b.gmax, ws));
+        T_TRY(run_wgrad(tr, tr->wg_b, tr->ds[L], dz, tr->n[L], 0, tr->o_lb, o.reg_bottom, SIZE_MAX, tr->dsmax[L], tr->bn_b.gmax, ws));
         T_TRY(side_done(slot));
         T_TRY(run_conv(tr, tr->c_dg_b, dz, nullptr, tr->DB));
         slot ^= 1;
@@ -535,7 +548,7 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         T_TRY(bn_backward(tr, s, a, tr->DB, dy1, dz));
         T_TRY(dz_ready(slot));
         // c00 + shortcut = conv(x, W1 + Wshort): both filters receive the same data gradient (UnMicst1-5.py:102-114)
-        T_TRY(run_wgrad(tr, tr->wg_d[i], tr->ds[i], dz, tr->n[i], 0, tr->o_ws[i], o.reg_down, tr->o_w1[i], nullptr, s.gmax, ws));
+        T_TRY(run_wgrad(tr, tr->wg_d[i], tr->ds[i], dz, tr->n[i], 0, tr->o_ws[i], o.reg_down, tr->o_w1[i], tr->dsmax[i], s.gmax, ws));
         T_TRY(side_done(slot));
         if (i >= 1) T_TRY(run_conv(tr, tr->c_dg_d[i], dz, nullptr, tr->DB));
         slot ^= 1;
@@ -671,7 +684,7 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
     T_TRY(talloc(tr, &tr->d_part, tr->part_doubles));
     T_TRY(tzero(tr, &tr->d_loss, 2));
     {   // max-|gradient| words: one per batch-normalised tensor and per up layer, + the range flag
-        tr->n_maxw = 3 * L + 2;
+        tr->n_maxw = 6 * L + 4;
         T_TRY(tzero(tr, &tr->d_maxw, (size_t)tr->n_maxw + 1));
         int k = 0;
         for (int i = 0; i < L; ++i) tr->bn_d[i].gmax = tr->d_maxw + k++;
@@ -680,6 +693,11 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
         tr->bn_t.gmax = tr->d_maxw + k++;
         tr->smax.assign(L, nullptr);
         for (int i = 0; i < L; ++i) tr->smax[i] = tr->d_maxw + k++;
+        tr->dsmax.assign(L + 1, nullptr); tr->usmax.assign(L, nullptr); tr->cvmax.assign(L, nullptr);
+        for (int i = 0; i <= L; ++i) tr->dsmax[i] = tr->d_maxw + k++;
+        for (int i = 0; i < L; ++i) tr->usmax[i] = tr->d_maxw + k++;
+        for (int i = 0; i < L; ++i) tr->cvmax[i] = tr->d_maxw + k++;
+        tr->bmax = tr->d_maxw + k++;
     }
 
     // ---- conv launches

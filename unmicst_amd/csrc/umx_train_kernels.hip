@@ -196,37 +196,73 @@ __device__ __forceinline__ float dact_of(float v, int act) {
     return 1.f;
 }
 
-__global__ void __launch_bounds__(256) act_fwd_kernel(const ActParams a, float* __restrict__ out, size_t nout) {
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= nout) return;
-    const int C = a.C;
-    const int c = (int)(e % C);
-    const float sc = a.stat[2 * C + c], sh = a.stat[3 * C + c];
-    const float ks = 1.0f / (1.0f - a.drop_rate);
-    if (!a.pool) {
-        const float v = a.z[e] * sc + sh;
-        out[e] = act_of(v, a.act) * drop_mul(a.drop_key, e, a.drop_rate, ks);
-        return;
-    }
-    size_t r = e / C;
-    const int OW = a.W >> 1, OH = a.H >> 1;
-    const int ox = (int)(r % OW); r /= OW;
-    const int oy = (int)(r % OH);
-    const int b = (int)(r / OH);
-    float best = 0.f;
+// max |v| over a block -> one atomicMax on the tensor's word (uint order == float order for non-negative floats;
+// integer max is associative: the result does not depend on the order of the blocks)
+__device__ __forceinline__ void block_absmax_to(unsigned* dst, float v) {
+    __shared__ unsigned smax[4];
+    unsigned u = __float_as_uint(fabsf(v));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const size_t idx = (((size_t)b * a.H + 2 * oy + (j >> 1)) * a.W + 2 * ox + (j & 1)) * C + c;
-        const float v = a.z[idx] * sc + sh;
-        const float y = act_of(v, a.act) * drop_mul(a.drop_key, idx, a.drop_rate, ks);
-        if (j == 0 || y > best) best = y;
+    for (int off = 32; off > 0; off >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, off));
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned m = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
+        // most blocks cannot raise the maximum once a few have reported: a plain (possibly stale, never too large) read
+        // keeps them off the atomic unit; the atomic itself stays the arbiter
+        if (m > *reinterpret_cast<volatile unsigned*>(dst)) atomicMax(dst, m);
     }
-    out[e] = best;
 }
 
-hipError_t launch_act_fwd(const ActParams& a, float* out, hipStream_t stream) {
+// (grid-stride; the block's max |output| goes to the tensor's max word with at most one atomic)
+__global__ void __launch_bounds__(256) act_fwd_kernel(const ActParams a, float* __restrict__ out, size_t nout,
+                                                      unsigned* omax) {
+    const int C = a.C;
+    const float ks = 1.0f / (1.0f - a.drop_rate);
+    const int OW = a.W >> 1, OH = a.H >> 1;
+    float mx = 0.f;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nout; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const float sc = a.stat[2 * C + c], sh = a.stat[3 * C + c];
+        float y;
+        if (!a.pool) {
+            const float v = a.z[e] * sc + sh;
+            y = act_of(v, a.act) * drop_mul(a.drop_key, e, a.drop_rate, ks);
+        } else {
+            size_t r = e / C;
+            const int ox = (int)(r % OW); r /= OW;
+            const int oy = (int)(r % OH);
+            const int b = (int)(r / OH);
+            y = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const size_t idx = (((size_t)b * a.H + 2 * oy + (j >> 1)) * a.W + 2 * ox + (j & 1)) * C + c;
+                const float v = a.z[idx] * sc + sh;
+                const float yj = act_of(v, a.act) * drop_mul(a.drop_key, idx, a.drop_rate, ks);
+                if (j == 0 || yj > y) y = yj;
+            }
+        }
+        out[e] = y;
+        mx = fmaxf(mx, fabsf(y));
+    }
+    if (omax) block_absmax_to(omax, mx);
+}
+
+hipError_t launch_act_fwd(const ActParams& a, float* out, unsigned* omax, hipStream_t stream) {
     const size_t nout = (size_t)a.B * (a.pool ? a.H / 2 : a.H) * (a.pool ? a.W / 2 : a.W) * a.C;
-    hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, stream, a, out, nout);
+    const unsigned blocks = (unsigned)std::min<size_t>(2048, (nout + 255) / 256);
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, a, out, nout, omax);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, size_t n, unsigned* omax) {
+    float mx = 0.f;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) mx = fmaxf(mx, fabsf(x[e]));
+    block_absmax_to(omax, mx);
+}
+
+hipError_t launch_absmax(const float* x, size_t n, unsigned* omax, hipStream_t stream) {
+    const unsigned blocks = (unsigned)std::min<size_t>(4096, (n + 255) / 256);
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, x, n, omax);
     return hipGetLastError();
 }
 
@@ -329,19 +365,7 @@ hipError_t launch_bn_bwd_finalize(const double* part, int nblk, size_t N, int C,
     return hipGetLastError();
 }
 
-// max |v| over a block -> one atomicMax on the tensor's word (uint order == float order for non-negative floats;
-// integer max is associative: the result does not depend on the order of the blocks)
-__device__ __forceinline__ void block_absmax_to(unsigned* dst, float v) {
-    __shared__ unsigned smax[4];
-    unsigned u = __float_as_uint(fabsf(v));
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) u = max(u, (unsigned)__shfl_xor((int)u, off));
-    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = u;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicMax(dst, max(max(smax[0], smax[1]), max(smax[2], smax[3])));
-}
-
-// (grid-stride over at most 1024 blocks: one atomic per block on the tensor's max word)
+// (grid-stride; at most one atomic per block on the tensor's max word)
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(float* __restrict__ g, const float* __restrict__ z,
                                                            const float* __restrict__ stat, const float* __restrict__ m12,
                                                            size_t n, int C, unsigned* gmax) {
@@ -812,9 +836,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_mfma_f32(const WgradParams p) {
 // binary16 pairs, fp32 accumulation (the scheme of conv_f16x3).  One v_mfma_f32_16x16x32_f16 covers
 // 32 pixels of K where the fp32 MFMA covers 4: 3 x 16 cycles instead of 8 x 32.
 //   * Operands are converted while they are staged: fp32 NHWC from HBM -> scaled -> (hi, lo) -> channel-planar LDS
-//     [plane][channel][pixel] (a fragment = 8 consecutive pixels of one channel = one ds_read_b128).  Gradient operands
-//     are scaled by a power of two that brings their tracked max |v| to [2^11, 2^12) (binary16 would flush them
-//     otherwise), activations by 16 (keeps the lo parts normal); the reduce kernel divides the product of the scales out.
+//     [plane][channel][pixel] (a fragment = 8 consecutive pixels of one channel = one ds_read_b128).  Every operand is
+//     scaled by the power of two that brings its tracked max |v| (written by its producer) to [2^11, 2^12): gradients
+//     would flush to zero in binary16 otherwise, and activations keep their lo parts normal; the reduce kernel divides
+//     the product of the two scales out.
 //   * A tap shifts the X window by dx pixels = dx halves: the fragment is read as an aligned b128 + b32 and funnel-
 //     shifted (v_alignbit) -- no per-tap copies of the halo.
 //   * 48 x 48 channel tiles (the 36*2^k and 80*2^k widths of the shipped models pad to multiples of 48 with <= 1.33x):
@@ -824,8 +849,7 @@ typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 constexpr int kHwC = 48, kHwPW = 7, kHwXT = 5, kHwGT = 3;
 
 __device__ __forceinline__ float wg_scale(const unsigned* mx) {
-    if (!mx) return 16.f;
-    const int e = (int)((*mx >> 23) & 0xff);          // biased exponent of max |v|
+    const int e = (int)((*mx >> 23) & 0xff);          // biased exponent of the tensor's tracked max |v|
     if (e == 0 || e == 255) return 1.f;
     const int se = min(max(127 + 11 - (e - 127), 1), 254);
     return __uint_as_float((unsigned)se << 23);        // max * scale in [2^11, 2^12)
