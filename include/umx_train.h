@@ -6,7 +6,8 @@
  * graph with batch-statistics BN and dropout (UnMicst1-5.py:83-237), weighted cross-entropy + regularisation loss
  * (:367-373), gradients of every trainable variable, the optimiser update (:378-380) and the BN moving-average update
  * (UPDATE_OPS, :375,379).  Parameters live in the same flat blob layout umx_create takes, so a trained blob loads into
- * the inference engine unchanged.  Covered: UMX_GRAPH_V2 with nExtraConvs == 0 (every v2 model the reference ships).
+ * the inference engine unchanged.  Covered: UMX_GRAPH_V2 with nExtraConvs == 0 and 3x3 or 5x5 filters (every v2 model the
+ * reference ships is 3x3).
  * Conventions as in umx.h: 0 = ok, umx_trainer_last_error() gives the message, the caller owns host buffers, one
  * trainer per host thread.  There is no CPU fallback.
  */

@@ -61,13 +61,22 @@ def _per_tensor(hp, got, want, what, rel=LOOSE, top=TIGHT):
 
 
 CASES = [("v2_solo_like", 4, "solo"), ("v2_duo_like", 4, "duo"), ("v2_deep", 3, "duo"), ("v2_wide", 2, "solo"),
-         ("v2_wide", 2, "duo")]
+         ("v2_wide", 2, "duo"), ("v2_k5", 3, "duo")]
+
+
+def _hp(name):
+    extra = {
+        # 5x5 filters: 25 weight-gradient slabs in groups of 9/9/7, transposed conv with pad_before 1 (space-to-depth taps
+        # -1..1, parity groups 9/6/6/4)
+        "v2_k5": model.HParams(model.GRAPH_V2, 32, 2, 3, 8, 2, 5, 0),
+    }
+    return extra[name] if name in extra else helpers.small_hps()[name]
 
 
 @pytest.mark.parametrize("name,B,regime", CASES)
 def test_loss_gradients_and_probabilities_match_oracle(name, B, regime):
     from oracle import train_oracle as to
-    hp = helpers.small_hps()[name]
+    hp = _hp(name)
     opts = trainer.solo_options() if regime == "solo" else trainer.duo_options()
     blob = model.random_blob(hp, seed=21)
     data, labels, weights = _batch(hp, B, 3)

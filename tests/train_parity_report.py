@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import helpers  # noqa: E402
 from oracle import train_oracle as to  # noqa: E402
 from unmicst_amd import model, trainer  # noqa: E402
-from test_gpu_train import CASES, _batch, _oracle_opts  # noqa: E402
+from test_gpu_train import CASES, _batch, _hp, _oracle_opts  # noqa: E402
 
 
 def main():
@@ -19,7 +19,7 @@ def main():
     if "--full" in sys.argv:           # BASELINE.json configs[4] at full size (about a minute of CPU for the two oracle runs)
         cases.append(("synthetic-256", 8, "duo"))
     for name, B, regime in cases:
-        hp = model.KNOWN_HP[name] if name in model.KNOWN_HP else helpers.small_hps()[name]
+        hp = model.KNOWN_HP[name] if name in model.KNOWN_HP else _hp(name)
         opts = trainer.solo_options() if regime == "solo" else trainer.duo_options()
         blob = model.random_blob(hp, seed=21)
         data, labels, weights = _batch(hp, B, 3)

@@ -866,7 +866,7 @@ int umx_trainer_create(const umx_hparams* hp, const float* weight_blob, size_t b
     if (hp->graph != UMX_GRAPH_V2 || hp->nExtraConvs != 0)
         return tfail(nullptr, UMX_ERR_INVALID, "the training step covers the v2 graph with nExtraConvs == 0");
     if (hp->nClasses < 1 || hp->nClasses > 8) return tfail(nullptr, UMX_ERR_INVALID, "nClasses must be 1..8");
-    if (hp->nLayers < 1 || hp->nLayers > 8 || hp->ks % 2 != 1 || hp->ks < 1 || hp->ks > 5 || hp->featMapsFact < 1 ||
+    if (hp->nLayers < 1 || hp->nLayers > 8 || (hp->ks != 3 && hp->ks != 5) || hp->featMapsFact < 1 ||
         hp->nChannels < 1 || hp->nOut0 < 1)
         return tfail(nullptr, UMX_ERR_INVALID, "unsupported hyper-parameters");
     if ((hp->imSize & (hp->imSize - 1)) || (hp->imSize >> hp->nLayers) < 1)
