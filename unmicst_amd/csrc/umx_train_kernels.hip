@@ -417,23 +417,33 @@ hipError_t launch_leaky_bwd_s2d_max(const float* d_us, const float* us, int B, i
 // ------------------------------------------------------------------------------------------------ top layer
 constexpr int kMaxK = 8;
 
+// 256 pixels per block: the [256][C] slab is loaded with consecutive threads on consecutive addresses and parked in LDS
+// (pixel pitch C+1: a thread walking its own pixel then touches a new bank every step), each thread reduces one pixel
 __global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__ x, size_t N, int C, int K,
                                                        const float* __restrict__ w, float* __restrict__ t0) {
-    extern __shared__ float wl[];   // [C][K]
+    extern __shared__ float hl[];    // [C][K] weights, then [256][C+1] pixels
+    float* const wl = hl;
+    float* const xl = hl + C * K;
+    const size_t p0 = (size_t)blockIdx.x * 256;
+    const int npx = (int)min((size_t)256, N - p0);
     for (int i = threadIdx.x; i < C * K; i += 256) wl[i] = w[i];
+    for (int i = threadIdx.x; i < npx * C; i += 256) {
+        const int px = i / C, c = i - px * C;
+        xl[px * (C + 1) + c] = x[p0 * C + i];
+    }
     __syncthreads();
-    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= N) return;
+    if ((int)threadIdx.x >= npx) return;
     float acc[kMaxK];
 #pragma unroll
     for (int k = 0; k < kMaxK; ++k) acc[k] = 0.f;
-    const float* xp = x + p * C;
+    const float* xp = xl + threadIdx.x * (C + 1);
     for (int c = 0; c < C; ++c) {
         const float v = xp[c];
 #pragma unroll
         for (int k = 0; k < kMaxK; ++k)
             if (k < K) acc[k] = fmaf(v, wl[c * K + k], acc[k]);
     }
+    const size_t p = p0 + threadIdx.x;
 #pragma unroll
     for (int k = 0; k < kMaxK; ++k)
         if (k < K) t0[p * K + k] = acc[k];
@@ -441,8 +451,9 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__
 
 hipError_t launch_head_fwd(const float* x, size_t N, int C, int K, const float* w, float* t0, hipStream_t stream) {
     if (K > kMaxK) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), sizeof(float) * C * K, stream, x, N, C,
-                       K, w, t0);
+    const size_t lds = sizeof(float) * ((size_t)C * K + 256 * (size_t)(C + 1));
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), lds, stream, x, N, C, K, w, t0);
     return hipGetLastError();
 }
 
