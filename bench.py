@@ -46,25 +46,29 @@ def synth_rows(torch, C, row0, rows, W, device):
     return torch.clamp(base + 0.12 * h, 0.0, 0.983).contiguous()
 
 
-def pmc_traffic(layer, precision, batch):
-    """HBM bytes per launch of `layer` from the committed rocprofv3 counter passes of this same command
-    (profiles/r01/final_<precision>_by_layer_pmc.csv, written by tools/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE collected in
-    separate --pmc passes, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  None when no profile of
+def pmc_traffic(kernel, precision, batch):
+    """HBM bytes per launch of `kernel` (a template instantiation as rocprofv3 names it, e.g. "conv_f16x3<9, 4, 1>"),
+    averaged over its launches, from the committed rocprofv3 counter passes of this same command
+    (profiles/r01/final_<precision>_b<batch>_by_layer_pmc.csv, written by tools/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE collected
+    in separate --pmc passes, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  None when no profile of
     this configuration is committed."""
     import csv
     path = os.path.join(ROOT, "profiles", "r01", "final_%s_b%d_by_layer_pmc.csv" % (precision, batch))
     if not os.path.exists(path):
         return None
-    best = None
+    calls = rd = wr = us = 0.0
     with open(path, newline="") as f:
         for r in csv.DictReader(f):
-            if r["pos"] == layer and r.get("hbm_read_MB_corrected") and r.get("hbm_write_MB"):
-                if best is None or int(r["calls"]) > int(best["calls"]):   # full batches, not the tail batch
-                    best = r
-    if best is None:
+            if kernel in r["kernel"] and r.get("hbm_read_MB_corrected") and r.get("hbm_write_MB"):
+                n = float(r["calls"])
+                calls += n
+                rd += n * float(r["hbm_read_MB_corrected"]) * 1e6
+                wr += n * float(r["hbm_write_MB"]) * 1e6
+                us += n * float(r["avg_us"])
+    if calls == 0:
         return None
-    rd, wr = float(best["hbm_read_MB_corrected"]) * 1e6, float(best["hbm_write_MB"]) * 1e6
-    return {"bytes_per_launch": rd + wr, "read": rd, "write": wr, "avg_launch_us_profiled": float(best["avg_us"]),
+    return {"bytes_per_launch": round((rd + wr) / calls), "read": round(rd / calls), "write": round(wr / calls),
+            "avg_launch_us_profiled": round(us / calls, 2), "launches_profiled": int(calls),
             "source": os.path.relpath(path, ROOT)}
 
 
@@ -166,26 +170,39 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = tiles_total * args.steps / elapsed
-        # ---- roofline of the dominant kernel (largest share of the timed region), from the in-library HIP events
+        # ---- roofline of the dominant kernel = the template instantiation with the largest share of the timed region (what
+        # `rocprofv3 --stats` ranks first: profiles/r01/final_*_kernel_stats.csv), from the in-library HIP events; one kernel
+        # serves several layers, so the figures are launch-weighted averages over its sites
         convs = [p for p in prof if p["kernel"].startswith("conv_")]
-        dom = max(convs, key=lambda p: p["total_ms"])
-        dom_tflops = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
+        by_kernel = {}
+        for p in convs:
+            k = by_kernel.setdefault(p["kernel"], {"ms": 0.0, "flops": 0.0, "exec": 0.0, "bytes": 0.0, "launches": 0, "layers": []})
+            k["ms"] += p["total_ms"]; k["flops"] += p["flops"]; k["exec"] += p["exec_flops"]; k["bytes"] += p["bytes"]
+            k["launches"] += p["launches"]; k["layers"].append(p["name"])
+        dom_name = max(by_kernel, key=lambda n: by_kernel[n]["ms"])
+        dom = by_kernel[dom_name]
+        dom_tflops = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        slow = max(convs, key=lambda p: p["total_ms"])          # the single most expensive layer, for the record
         all_flops = sum(p["flops"] for p in convs)
         all_exec = sum(p["exec_flops"] for p in convs)
         all_ms = sum(p["total_ms"] for p in convs)
         peak = PEAK_F16_MFMA_TFLOPS if eng.precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
         roofline = {
-            # achieved = ALGORITHMIC fp32 FLOPs of the layer / HIP-event time of its launches; peak = dense MFMA peak of
-            # the dtype the matrix cores run (f16x3 issues 3 binary16 MFMA FLOPs per algorithmic FLOP: "mfma_issued")
+            # achieved = ALGORITHMIC fp32 FLOPs of the kernel's launches / HIP-event time of those launches; peak = dense MFMA
+            # peak of the dtype the matrix cores run (f16x3 issues 3 binary16 MFMA FLOPs per algorithmic FLOP: "mfma_issued")
             "bound": "mfma", "achieved": round(dom_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(dom_tflops / peak, 4), "traffic": pmc_traffic(dom["name"], eng.precision, args.batch),
-            "kernel": dom["kernel"], "layer": dom["name"],
-            "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
+            "frac": round(dom_tflops / peak, 4), "traffic": pmc_traffic(dom_name, eng.precision, args.batch),
+            "kernel": dom_name, "layers": dom["layers"], "share_of_step": round(dom["ms"] / (1e3 * elapsed), 4),
+            "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
             "flop_per_launch": dom["flops"] / dom["launches"],
-            "mfma_issued": {"tflops": round(dom["exec_flops"] / (dom["total_ms"] * 1e-3) / 1e12, 2),
-                            "frac": round(dom["exec_flops"] / (dom["total_ms"] * 1e-3) / 1e12 / peak, 4)},
-            "compulsory_hbm": {"GBps": round(dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9, 1),
-                               "frac_of_8TBps": round(dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
+            "mfma_issued": {"tflops": round(dom["exec"] / (dom["ms"] * 1e-3) / 1e12, 2),
+                            "frac": round(dom["exec"] / (dom["ms"] * 1e-3) / 1e12 / peak, 4)},
+            "compulsory_hbm": {"GBps": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
+                               "frac_of_8TBps": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
+            "slowest_layer": {"layer": slow["name"], "kernel": slow["kernel"],
+                              "achieved": round(slow["flops"] / (slow["total_ms"] * 1e-3) / 1e12, 2),
+                              "frac": round(slow["flops"] / (slow["total_ms"] * 1e-3) / 1e12 / peak, 4),
+                              "avg_launch_us": round(1e3 * slow["total_ms"] / slow["launches"], 2)},
             "all_conv_launches": {"achieved": round(all_flops / (all_ms * 1e-3) / 1e12, 2),
                                   "frac": round(all_flops / (all_ms * 1e-3) / 1e12 / peak, 4),
                                   "mfma_issued_frac": round(all_exec / (all_ms * 1e-3) / 1e12 / peak, 4),

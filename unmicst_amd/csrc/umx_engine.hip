@@ -932,7 +932,8 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
     else if (db.as_f32) p.dst_f32 = db.d + (size_t)k0 * db.floats_per_tile;
     else { p.dst_hi = hi_at(db); p.dst_lo = lo_at(db); }
     char kn[48];
-    snprintf(kn, sizeof kn, "conv_f16x3<NT=%d>", L.nt16);
+    // the instantiation as rocprofv3 names it (<NT, KMT, NPH>): bench.py groups the timed sites by kernel
+    snprintf(kn, sizeof kn, "conv_f16x3<%d, %d, %d>", L.nt16, p.fused_phases ? 2 : kMT, p.fused_phases ? 4 : 1);
     {
         // diagnostic: UMX_DEBUG_STAMPS=<layer name> prints the mean s_memtime segments of that layer's workgroups
         static const char* dbg_layer = getenv("UMX_DEBUG_STAMPS");
@@ -1000,7 +1001,7 @@ int run_unet(umx_ctx* ctx, const float* tiles, int n, float* probs) {
         if (L.ngroups > 1) p.src[1] = L.g[1].src == 0 ? tiles : ctx->bufs[L.g[1].src].d;
         p.dst = ctx->bufs[L.dst].d;
         char kn[48];
-        snprintf(kn, sizeof kn, "conv_mfma_f32<NT=%d,HPIX=%d>", L.nt, L.hpix);
+        snprintf(kn, sizeof kn, "conv_mfma_f32<%d, %d>", L.nt, L.hpix <= 2 ? 2 : 4);
         ProfScope ps(ctx, site_of(ctx, L.name, kn), L.flops * n, L.bytes * n, L.exec_flops * n);
         HIP_TRY(ctx, launch_conv(p, L.nt, L.hpix, ctx->stream));
     }
