@@ -286,3 +286,29 @@ def test_baseline_config_256x256x2_batch8_against_the_oracle():
     for name in ("lt.w", "lt.bn.gamma", "lt.bn.beta"):
         assert np.abs(G[name] - W[name]).max() <= TIGHT * np.abs(W[name]).max(), name
     print("worst relative gradient error %.2e" % worst)
+
+
+@pytest.mark.parametrize("hp_args,B", [
+    ((16, 1, 2, 4, 1, 3, 0), 1),      # one level, one image, two classes, 8x8 bottom
+    ((16, 3, 4, 5, 2, 3, 0), 5),      # three input channels, four classes, odd widths and batch, 4x4 bottom
+    ((64, 2, 3, 6, 5, 3, 0), 2),      # five levels down to a 2x2 bottom
+    ((16, 1, 3, 8, 2, 5, 0), 3),      # 5x5 filters on 4x4 layers (fp32 weight-gradient path, big halos)
+    ((128, 1, 3, 4, 2, 3, 0), 1),     # one large image
+])
+def test_odd_shapes_match_oracle(hp_args, B):
+    """Shapes off the beaten path: every launch geometry (image groups, partial channel tiles, tiny layers) must still be
+    right -- loss 1e-5, gradients within the discontinuity bound, nothing out of range."""
+    from oracle import train_oracle as to
+    hp = model.HParams(model.GRAPH_V2, *hp_args)
+    opts = trainer.duo_options()
+    blob = model.random_blob(hp, seed=17)
+    data, labels, weights = _batch(hp, B, 23)
+    want = to.loss_and_grads(hp, blob, data, labels, weights, _oracle_opts(opts), step=0)
+    tr = trainer.Trainer(hp, blob, opts, batch=B)
+    loss = tr.step(data, labels, weights, apply_update=False)[0]
+    assert loss == pytest.approx(want[0], rel=1e-5)
+    _per_tensor(hp, tr.grads(), want[3], "odd shape grads", rel=0.1, top=0.1)
+    assert np.abs(tr.probs() - want[4]).max() <= 2e-5
+    l2 = tr.step(data, labels, weights)[0]
+    assert l2 == pytest.approx(want[0], rel=1e-5) and tr.step_count == 1
+    tr.close()

@@ -753,7 +753,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_mfma_f32(const WgradParams p) {
             const int img = img0 + il;
             const int co = co0 + 4 * q;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (img < p.B && co < p.Cg) {
+            if (il < p.imgs && img < p.B && co < p.Cg) {   // (tiny layers: fewer images than pixel slots -> zero rows of G)
                 const float* src = p.G + ((size_t)(img * p.H + y0 + y) * p.W + x0 + x) * p.Cg + co;
                 if (p.vecg && co + 3 < p.Cg) v = *reinterpret_cast<const float4*>(src);
                 else {
@@ -801,7 +801,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_mfma_f32(const WgradParams p) {
         if (wave_live) {
             for (int ks = 0; ks < kWgPix / 4; ++ks) {
                 const int px = 4 * ks + kq;
-                const int il = px >> (p.th_log2 + p.tw_log2);
+                const int il = min(px >> (p.th_log2 + p.tw_log2), p.imgs - 1);   // unused slots: any finite X (their G is 0)
                 const int y = (px >> p.tw_log2) & (TH - 1), x = px & (TW - 1);
                 const float* ap = Xl + (il * p.imgplane + y * p.hw + x) * PX + li;
                 const float b = Gl[px * kWgPG + wave * 16 + li];
@@ -1117,6 +1117,9 @@ bool wgrad_setup(WgradParams* p, std::string* why) {
     p->hh = TH + ymax - ymin;
     p->hw = TW + xmax - xmin;
     p->imgplane = p->hh * p->hw;
+    // tiny layers (2x2, 4x4): 128 pixel slots would span dozens of images and their halos; use as many images as the
+    // staging budget holds and leave the other slots empty (their rows of G are staged as zeros)
+    p->imgs = std::max(1, std::min(p->imgs, kWgHaloBig / p->imgplane));
     p->nhalo = p->imgs * p->imgplane;
     p->tiles_y = p->H / TH;
     p->tiles_x = p->W / TW;
