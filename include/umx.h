@@ -42,7 +42,9 @@ enum umx_status {
  *   UMX_PREC_F32    exact fp32 products on v_mfma_f32_16x16x4_f32 (bit-for-bit an fp32 fma chain).
  *   UMX_PREC_F16X3  every fp32 product as three binary16 MFMA products of a (hi, lo) split of both operands with fp32
  *                   accumulation (~2^-21 relative error per product; 16/3 of the fp32 matrix rate).  Default.
- *   UMX_PREC_DEFAULT  = UMX_PREC_F16X3 unless the environment says UMX_PRECISION=f32. */
+ *   UMX_PREC_DEFAULT  = UMX_PREC_F16X3 where its planner covers every layer of the graph, else UMX_PREC_F32 (layers of 2x2 /
+ *                     4x4 pixels under 5x5 / 7x7 filters exceed the split kernel's LDS image); UMX_PRECISION=f32|f16x3 in the
+ *                     environment pins it.  umx_precision_of() tells which one a ctx runs. */
 enum umx_precision { UMX_PREC_DEFAULT = 0, UMX_PREC_F32 = 1, UMX_PREC_F16X3 = 2 };
 
 typedef struct umx_options {

@@ -226,3 +226,47 @@ def test_infer_image_edge_sizes(shape):
     for k in range(hp.nClasses):
         ref = oracle.single_image_inference(hp, blob, img, 0.3, 0.2, "accumulate", k, duplicate_plane=False)
         assert np.abs(got[k].astype(np.float32) - ref.astype(np.float32)).max() <= 1e-3
+
+
+def _random_hps(n, seed):
+    """Seeded hyper-parameter sets across both graphs: filter sizes 3/5/7, 1-3 input channels, 2-4 classes, 1-5 levels
+    (bottoms down to 2x2), 0-2 extra convs, widths that are not multiples of 8 or 16."""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        graph = int(rng.integers(0, 2))
+        L = int(rng.integers(1, 6))
+        ks = int(rng.choice([3, 3, 5, 7]))
+        P = int(rng.choice([16, 32, 64, 128]))
+        if P >> L < 2 or (ks == 7 and P >> L < 4):
+            continue
+        hp = model.HParams(graph, P, int(rng.integers(1, 4)), int(rng.integers(2, 5)), int(rng.integers(3, 25)), L, ks,
+                           int(rng.integers(0, 3)) if graph == model.GRAPH_LEGACY else int(rng.integers(0, 2)))
+        if hp.flops_per_tile() > 3e9:
+            continue
+        out.append(hp)
+    return out
+
+
+@pytest.mark.parametrize("prec", PRECS + ["default"])
+def test_forward_tiles_random_hyper_parameters(prec):
+    """Fuzz of the planner: 14 seeded configurations, each either runs within tolerance or is refused at create time with
+    UMX_ERR_INVALID (a geometry the kernels do not cover) -- never a wrong answer, never a fault.  The split-precision
+    planner covers fewer tiny-layer geometries than the fp32 kernels; "default" picks whichever covers the graph."""
+    from oracle import oracle
+    ran = 0
+    need = {"f32": 10, "default": 10, "f16x3": 4}[prec]
+    for i, hp in enumerate(_random_hps(14, 2026)):
+        blob = model.random_blob(hp, seed=100 + i)
+        x = np.random.default_rng(i).normal(size=(3, hp.imSize, hp.imSize, hp.nChannels)).astype(np.float32)
+        try:
+            eng = umx.Engine(hp, blob, max_batch=2, precision=prec)
+        except umx.UmxError as e:
+            assert e.code == 1, (hp, e)
+            continue
+        with eng:
+            got = eng.forward_tiles(x)
+        ref = oracle.forward(hp, blob, x)
+        assert np.abs(got - ref).max() <= TILE_TOL, (hp, np.abs(got - ref).max())
+        ran += 1
+    assert ran >= need

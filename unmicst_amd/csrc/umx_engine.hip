@@ -1087,6 +1087,19 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
     if (!out) return fail(nullptr, UMX_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (!opts) return fail(nullptr, UMX_ERR_INVALID, "opts is NULL");
+    if (opts->precision == UMX_PREC_DEFAULT && !getenv("UMX_PRECISION")) {
+        // default = split precision where its planner covers every layer, else the exact-fp32 MFMA kernels (tiny layers
+        // under big filters exceed the LDS image of conv_f16x3).  Both are HIP paths; there is no CPU fallback.
+        umx_options o2 = *opts;
+        o2.precision = UMX_PREC_F16X3;
+        int rc = umx_create_opts(hp, weight_blob, blob_floats, &o2, out);
+        if (rc != UMX_ERR_INVALID) return rc;
+        const std::string first = g_err;
+        o2.precision = UMX_PREC_F32;
+        rc = umx_create_opts(hp, weight_blob, blob_floats, &o2, out);
+        if (rc) g_err = first + "; fp32 kernels: " + g_err;
+        return rc;
+    }
     const int device_ordinal = opts->device_ordinal, max_batch = opts->max_batch;
     int precision = opts->precision;
     if (precision == UMX_PREC_DEFAULT) {
