@@ -312,3 +312,13 @@ def test_odd_shapes_match_oracle(hp_args, B):
     l2 = tr.step(data, labels, weights)[0]
     assert l2 == pytest.approx(want[0], rel=1e-5) and tr.step_count == 1
     tr.close()
+
+
+def test_deploy_on_the_gpu(tmp_path):
+    from test_train_loop_cpu import HP, write_dataset
+    from unmicst_amd.unet2d import UNet2D
+    hp = model.hparams_from_dict(dict(HP, nOut0=8), model.GRAPH_V2)
+    model.save_converted(model.ModelArtefacts(hp, model.random_blob(hp, seed=3), 0.3, 0.2), str(tmp_path / "model"))
+    write_dataset(str(tmp_path / "imgs"), 3, 32, 1, 0, seed=1)
+    UNet2D.deploy(str(tmp_path / "imgs"), 3, str(tmp_path / "model"), str(tmp_path / "pm"), 0, 2)
+    assert sorted(os.listdir(tmp_path / "pm")) == ["I%05d_%s.png" % (i, t) for i in range(1, 4) for t in ("Im", "PM")]

@@ -137,3 +137,27 @@ def test_unet2d_facade_records_hyper_parameters():
     assert UNet2D.hp["nOut0"] == 80 and UNet2D.hp["stdDev0"] == 0.03 and UNet2D.hparams.nLayers == 4
     UNet2D.setupWithHP(dict(HP))
     assert UNet2D.hparams.imSize == 32 and trainer.solo_options().drop_bottom == 0.35
+
+
+def test_deploy_writes_the_reference_files(tmp_path):
+    """UNet2D.deploy host logic with an oracle-backed engine stand-in (the GPU run is test_gpu_train.py::test_deploy_on_the_gpu)."""
+    from oracle import oracle
+
+    class OracleEngine:
+        def __init__(self, hp, blob, device, max_batch):
+            self.hp, self.blob = hp, blob
+
+        def forward_tiles(self, x):
+            return oracle.forward(self.hp, self.blob, x)
+
+        def close(self):
+            pass
+
+    hp = model.hparams_from_dict(dict(HP, nChannels=2), model.GRAPH_V2)
+    model.save_converted(model.ModelArtefacts(hp, model.random_blob(hp, seed=3), 0.3, 0.2), str(tmp_path / "model"))
+    write_dataset(str(tmp_path / "imgs"), 5, 32, 2, 0, seed=1)
+    train_loop.deploy(str(tmp_path / "imgs"), 5, str(tmp_path / "model"), str(tmp_path / "pm"), 0, 2, engine_factory=OracleEngine)
+    names = sorted(os.listdir(tmp_path / "pm"))
+    assert names == ["I%05d_%s.png" % (i, t) for i in range(1, 6) for t in ("Im", "PM")]
+    png = open(tmp_path / "pm" / "I00003_PM.png", "rb").read()
+    assert png[:8] == b"\x89PNG\r\n\x1a\n" and png[16:24] == (32).to_bytes(4, "big") * 2

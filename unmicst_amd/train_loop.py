@@ -295,3 +295,37 @@ def train(hp_dict: dict, imPath, validPath, testPath, logPath, modelPath, pmPath
         finally:
             te.close()
     return history
+
+
+def deploy(imPath, nImages, modelPath, pmPath, gpuIndex, pmIndex, engine_factory: Optional[Callable] = None):
+    """The reference's ``UNet2D.deploy`` (UnMicst1-5.py:583-654): images ``I%05d_Img.tif`` of the model's tile size, one
+    page per channel, normalised with the model's mean / st.dev, pushed through the network in batches; writes
+    ``I%05d_Im.png`` (sqrt of the min-max normalised first channel) and ``I%05d_PM.png`` (class ``pmIndex``).
+    ``engine_factory(hp, blob, device, max_batch)`` defaults to the HIP inference engine."""
+    from . import umx as _umx
+    art = model.load_model_dir(modelPath)
+    hp = art.hp
+    B, P, C = hp.batchSize, hp.imSize, hp.nChannels
+    make = engine_factory or (lambda hp_, blob_, device_, mb_: _umx.Engine(hp_, blob_, device=device_, max_batch=mb_))
+    Data = np.zeros((nImages, P, P, C))
+    for i in range(nImages):
+        path = "%s/I%05d_Img.tif" % (imPath, i)
+        for c in range(C):
+            Data[i, :, :, c] = (imtools.im2double(tiffio.imread(path, key=c)) - art.mean) / art.std
+    eng = make(hp, art.blob, max(int(gpuIndex), 0), B)
+    print("Model restored.")
+    os.makedirs(pmPath, exist_ok=True)
+    batchData = np.zeros((B, P, P, C))
+    try:
+        for i in range(nImages):
+            print(i, nImages)
+            j = i % B
+            batchData[j] = Data[i]
+            if j == B - 1 or i == nImages - 1:
+                output = eng.forward_tiles(batchData[:j + 1].astype(np.float32))
+                for k in range(j + 1):
+                    im = np.sqrt(normalize(batchData[k, :, :, 0]))
+                    png_write("%s/I%05d_Im.png" % (pmPath, i - j + k + 1), np.uint8(255 * im))
+                    png_write("%s/I%05d_PM.png" % (pmPath, i - j + k + 1), np.uint8(255 * output[k, :, :, pmIndex]))
+    finally:
+        eng.close()

@@ -70,6 +70,12 @@ class UNet2D:
         return train_loop.train(UNet2D.hp, imPath, validPath, testPath, logPath, modelPath, pmPath, nTrain, nValid, nTest,
                                 restoreVariables, nSteps, gpuIndex, testPMIndex, regime=UNet2D.train_regime)
 
+    @staticmethod
+    def deploy(imPath, nImages, modelPath, pmPath, gpuIndex, pmIndex):
+        """== reference UnMicst1-5.py:583-654 (tile-sized images in, ``I%05d_Im.png`` / ``I%05d_PM.png`` out)."""
+        from . import train_loop
+        return train_loop.deploy(imPath, nImages, modelPath, pmPath, gpuIndex, pmIndex)
+
     # ---------------------------------------------------------------- setup / cleanup
     @staticmethod
     def singleImageInferenceSetup(modelPath, gpuIndex, mean, std, graph=None):
