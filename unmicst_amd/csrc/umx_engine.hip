@@ -95,6 +95,14 @@ struct umx_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::vector<Launch> plan;
     std::vector<Buffer> bufs;   // bufs[0] = input tiles
+    // Second "lane": the tile batches of one band alternate between two activation-buffer sets on two streams, so that
+    // the kernels of batch i+1 fill the CUs the tail of batch i's current layer leaves idle and MFMA-bound layers of one
+    // batch share a CU with the load-bound full-resolution layers of the other.
+    std::vector<Buffer> bufs2;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    float* d_tiles32_2 = nullptr;
+    int nlanes = 1, lane = 0;
     std::vector<void*> allocs;
     std::string err;
     // whole-image scratch (grown on demand)
@@ -120,6 +128,9 @@ struct umx_ctx {
 };
 
 namespace {
+
+inline std::vector<Buffer>& cur_bufs(umx_ctx* ctx) { return ctx->lane ? ctx->bufs2 : ctx->bufs; }
+inline hipStream_t run_stream(umx_ctx* ctx) { return ctx->lane ? ctx->stream2 : ctx->stream; }
 
 int fail(umx_ctx* ctx, int code, const char* fmt, ...) {
     char buf[512];
@@ -853,6 +864,7 @@ int site_of(umx_ctx* ctx, const std::string& name, const std::string& kernel) {
 int prof_fold(umx_ctx* ctx) {
     if (ctx->pending.empty()) return UMX_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->stream2) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream2));
     for (auto& pe : ctx->pending) {
         float ms = 0.f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, pe.a, pe.b));
@@ -882,11 +894,11 @@ struct ProfScope {
         ctx->sites[site].flops += flops;
         ctx->sites[site].bytes += bytes;
         ctx->sites[site].exec += exec;
-        hipEventRecord(a, ctx->stream);
+        hipEventRecord(a, run_stream(ctx));
     }
     ~ProfScope() {
         if (!on) return;
-        hipEventRecord(b, ctx->stream);
+        hipEventRecord(b, run_stream(ctx));
         ctx->pending.push_back({site, a, b});
     }
 };
@@ -903,31 +915,31 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
     auto lo_at = [&](const Buffer& b) { return lo_of(b, n) + (size_t)k0 * b.S * b.S * b.Cs; };
     if (L.name == "input.split") {   // fp32 tiles -> (hi, lo) input planes (2 -> 8 channels, scaled by 2^act_shift)
         if (!tiles) return UMX_OK;   // the gather kernel already wrote the (hi, lo) planes
-        const Buffer& b0 = ctx->bufs[0];
+        const Buffer& b0 = cur_bufs(ctx)[0];
         if (ctx->site_split < 0) ctx->site_split = site_of(ctx, "input.split", "split_f32");
         ProfScope ps(ctx, ctx->site_split, 0.0, (double)ns * b0.S * b0.S * (4.0 * b0.C + 4.0 * b0.Cs));
         HIP_TRY(ctx, launch_split_f32(tiles + (size_t)k0 * b0.floats_per_tile, (size_t)ns * b0.S * b0.S, b0.C, b0.Cs,
-                                      std::ldexp(1.f, ctx->act_shift), hi_at(b0), lo_at(b0), ctx->stream));
+                                      std::ldexp(1.f, ctx->act_shift), hi_at(b0), lo_at(b0), run_stream(ctx)));
         return UMX_OK;
     }
     if (L.head) {
         if (ctx->head_fused) return UMX_OK;   // computed in the epilogue of the last convolution
-        const Buffer& sb = ctx->bufs[L.g[0].src];
+        const Buffer& sb = cur_bufs(ctx)[L.g[0].src];
         const size_t npix = (size_t)ns * L.H * L.W;
         ProfScope ps(ctx, site_of(ctx, L.name, "head_softmax"), L.flops * ns, L.bytes * ns);
         HIP_TRY(ctx, launch_head_softmax(sb.d + (size_t)k0 * sb.floats_per_tile, npix, L.head_C, L.head_K, L.d_head_w,
-                                         L.d_pre_s, L.d_pre_b, probs + (size_t)k0 * L.H * L.W * L.head_K, ctx->stream));
+                                         L.d_pre_s, L.d_pre_b, probs + (size_t)k0 * L.H * L.W * L.head_K, run_stream(ctx)));
         return UMX_OK;
     }
     HConvParams p = L.hcp;
     p.B = ns;
     for (int gi = 0; gi < L.ngroups; ++gi) {
-        const Buffer& sb = ctx->bufs[L.g[gi].src];
+        const Buffer& sb = cur_bufs(ctx)[L.g[gi].src];
         p.src_hi[gi] = hi_at(sb);
         p.src_lo[gi] = lo_at(sb);
         p.Cs[gi] = sb.Cs;
     }
-    const Buffer& db = ctx->bufs[L.dst];
+    const Buffer& db = cur_bufs(ctx)[L.dst];
     if (p.head_K > 0) p.probs = probs + (size_t)k0 * L.H * L.W * p.head_K;   // fused softmax head
     else if (db.as_f32) p.dst_f32 = db.d + (size_t)k0 * db.floats_per_tile;
     else { p.dst_hi = hi_at(db); p.dst_lo = lo_at(db); }
@@ -942,8 +954,8 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
             long long* d = nullptr;
             HIP_TRY(ctx, hipMalloc((void**)&d, nwg * 7 * sizeof(long long)));
             p.dbg = d;
-            HIP_TRY(ctx, launch_conv_f16(p, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            HIP_TRY(ctx, launch_conv_f16(p, run_stream(ctx)));
+            HIP_TRY(ctx, hipStreamSynchronize(run_stream(ctx)));
             std::vector<long long> hst(nwg * 7);
             HIP_TRY(ctx, hipMemcpy(hst.data(), d, hst.size() * sizeof(long long), hipMemcpyDeviceToHost));
             hipFree(d);
@@ -957,7 +969,7 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
         }
     }
     ProfScope ps(ctx, site_of(ctx, L.name, kn), L.flops * ns, L.bytes * ns, L.exec_flops * ns);
-    HIP_TRY(ctx, launch_conv_f16(p, ctx->stream));
+    HIP_TRY(ctx, launch_conv_f16(p, run_stream(ctx)));
     return UMX_OK;
 }
 
@@ -987,28 +999,63 @@ int run_unet(umx_ctx* ctx, const float* tiles, int n, float* probs) {
     if (ctx->precision == UMX_PREC_F16X3) return run_unet_f16(ctx, tiles, n, probs);
     const umx_hparams& hp = ctx->hp;
     for (auto& L : ctx->plan) {
-        const float* src0 = L.g[0].src == 0 ? tiles : ctx->bufs[L.g[0].src].d;
+        const float* src0 = L.g[0].src == 0 ? tiles : cur_bufs(ctx)[L.g[0].src].d;
         if (L.head) {
             const size_t npix = (size_t)n * L.H * L.W;
             ProfScope ps(ctx, site_of(ctx, L.name, "head_softmax"), L.flops * n, L.bytes * n);
             HIP_TRY(ctx, launch_head_softmax(src0, npix, L.head_C, L.head_K, L.d_head_w, L.d_pre_s, L.d_pre_b, probs,
-                                             ctx->stream));
+                                             run_stream(ctx)));
             continue;
         }
         ConvParams p = L.cp;
         p.B = n;
         p.src[0] = src0;
-        if (L.ngroups > 1) p.src[1] = L.g[1].src == 0 ? tiles : ctx->bufs[L.g[1].src].d;
-        p.dst = ctx->bufs[L.dst].d;
+        if (L.ngroups > 1) p.src[1] = L.g[1].src == 0 ? tiles : cur_bufs(ctx)[L.g[1].src].d;
+        p.dst = cur_bufs(ctx)[L.dst].d;
         char kn[48];
         snprintf(kn, sizeof kn, "conv_mfma_f32<%d, %d>", L.nt, L.hpix <= 2 ? 2 : 4);
         ProfScope ps(ctx, site_of(ctx, L.name, kn), L.flops * n, L.bytes * n, L.exec_flops * n);
-        HIP_TRY(ctx, launch_conv(p, L.nt, L.hpix, ctx->stream));
+        HIP_TRY(ctx, launch_conv(p, L.nt, L.hpix, run_stream(ctx)));
     }
     if (ctx->prof && ctx->pending.size() > 4096) return prof_fold(ctx);
     (void)hp;
     return UMX_OK;
 }
+
+// Batching of `total` tiles over the lanes of a context: equal batches (<= max_batch), as many as a multiple of the lane
+// count when there is more than one batch, consecutive batches on alternating lanes.  The second lane's stream is forked
+// from the context's stream by an event at the first use and joined back in join(); with one lane (or one batch) every
+// launch stays on the context's stream.
+struct LaneLoop {
+    umx_ctx* ctx;
+    int batch, k = 0;
+    bool forked = false;
+    LaneLoop(umx_ctx* c, int total) : ctx(c) {
+        int nbatch = (total + c->max_batch - 1) / c->max_batch;
+        if (c->nlanes > 1 && nbatch > 1) nbatch = (nbatch + c->nlanes - 1) / c->nlanes * c->nlanes;
+        batch = nbatch > 0 ? (total + nbatch - 1) / nbatch : 1;
+        ctx->lane = 0;
+    }
+    int next(int left) {
+        ctx->lane = ctx->nlanes > 1 ? k % ctx->nlanes : 0;
+        if (ctx->lane == 1 && !forked) {
+            forked = true;
+            if (hipEventRecord(ctx->ev_fork, ctx->stream) != hipSuccess ||
+                hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0) != hipSuccess) ctx->lane = 0;   // degrade to one lane
+        }
+        ++k;
+        return std::min(batch, left);
+    }
+    int join() {
+        ctx->lane = 0;
+        if (!forked) return UMX_OK;
+        forked = false;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        return UMX_OK;
+    }
+    ~LaneLoop() { join(); }   // error paths: the side stream is still joined into the context's stream
+};
 
 TileGeom geom_of(const umx_hparams& hp, int H, int W) {
     TileGeom g;
@@ -1166,10 +1213,37 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
         if ((rc = dev_alloc(c, &d, bytes_per_tile * (size_t)max_batch))) return bail(rc);
         B.d = (float*)d;
     }
+    {
+        int lanes = opts->lanes;
+        if (const char* e = getenv("UMX_LANES")) lanes = atoi(e);
+        if (lanes == 0) lanes = 2;
+        if (lanes < 1 || lanes > 2) { c->err = "lanes must be 1 or 2"; return bail(UMX_ERR_INVALID); }
+        c->nlanes = lanes;
+    }
+    if (c->nlanes == 2) {
+        if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+            c->err = "creating the second lane's stream/events failed";
+            return bail(UMX_ERR_HIP);
+        }
+        c->bufs2 = c->bufs;
+        for (size_t i = 0; i < c->bufs2.size(); ++i) {
+            Buffer& B = c->bufs2[i];
+            const size_t bytes_per_tile = B.as_f32 ? B.floats_per_tile * sizeof(float) : (size_t)B.S * B.S * B.Cs * 4;
+            void* d = nullptr;
+            if ((rc = dev_alloc(c, &d, bytes_per_tile * (size_t)max_batch))) return bail(rc);
+            B.d = (float*)d;
+        }
+    }
     if (f16) {
         void* d = nullptr;
         if ((rc = dev_alloc(c, &d, c->bufs[0].floats_per_tile * sizeof(float) * (size_t)max_batch))) return bail(rc);
         c->d_tiles32 = (float*)d;
+        if (c->nlanes == 2) {
+            if ((rc = dev_alloc(c, &d, c->bufs[0].floats_per_tile * sizeof(float) * (size_t)max_batch))) return bail(rc);
+            c->d_tiles32_2 = (float*)d;
+        }
         if ((rc = dev_alloc(c, &d, 256))) return bail(rc);
         c->d_zeros = (uint4*)d;
         if ((rc = dev_alloc(c, &d, 256))) return bail(rc);
@@ -1233,6 +1307,9 @@ void umx_destroy(umx_ctx* ctx) {
     if (ctx->d_out) hipFree(ctx->d_out);
     if (ctx->d_io_tiles) hipFree(ctx->d_io_tiles);
     if (ctx->d_io_probs) hipFree(ctx->d_io_probs);
+    if (ctx->stream2) { hipStreamSynchronize(ctx->stream2); hipStreamDestroy(ctx->stream2); }
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -1256,12 +1333,13 @@ int umx_forward_tiles_dev(umx_ctx* ctx, const float* tiles_dev, int n, float* pr
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t P = ctx->hp.imSize;
     const size_t tile_f = P * P * ctx->hp.nChannels, prob_f = P * P * ctx->hp.nClasses;
-    for (int i = 0; i < n; i += ctx->max_batch) {
-        const int nb = std::min(ctx->max_batch, n - i);
+    LaneLoop ll(ctx, n);
+    for (int i = 0, nb; i < n; i += nb) {
+        nb = ll.next(n - i);
         int rc = run_unet(ctx, tiles_dev + (size_t)i * tile_f, nb, probs_dev + (size_t)i * prob_f);
         if (rc) return rc;
     }
-    return UMX_OK;
+    return ll.join();
 }
 
 int umx_forward_tiles(umx_ctx* ctx, const float* tiles_host, int n, float* probs_host) {
@@ -1311,26 +1389,28 @@ int umx_band_tiles_dev(umx_ctx* ctx, const double* image_dev, int C_img, int H, 
     const int t0 = pr0 * g.npc, t1 = pr1 * g.npc;
     const size_t prob_f = (size_t)g.P * g.P * ctx->hp.nClasses;
     if (ctx->site_gather < 0) ctx->site_gather = site_of(ctx, "pi2d.gather_normalise", "gather_normalise");
-    float* const tiles32 = ctx->precision == UMX_PREC_F16X3 ? ctx->d_tiles32 : ctx->bufs[0].d;
     const bool direct16 = ctx->precision == UMX_PREC_F16X3 && ctx->hp.nChannels <= 8 && ctx->bufs[0].Cs == 8;
-    for (int t = t0; t < t1; t += ctx->max_batch) {
-        const int nb = std::min(ctx->max_batch, t1 - t);
+    LaneLoop ll(ctx, t1 - t0);
+    for (int t = t0, nb; t < t1; t += nb) {
+        nb = ll.next(t1 - t);
+        float* const tiles32 = ctx->precision == UMX_PREC_F16X3 ? (ctx->lane ? ctx->d_tiles32_2 : ctx->d_tiles32)
+                                                                : cur_bufs(ctx)[0].d;
         {
             ProfScope ps(ctx, ctx->site_gather, 0.0,
                          (double)nb * g.P * g.P * (8.0 + (direct16 ? 32.0 : 4.0 * ctx->hp.nChannels)));
             if (direct16) {   // gather + normalise + (hi, lo) split in one pass
-                const Buffer& b0 = ctx->bufs[0];
+                const Buffer& b0 = cur_bufs(ctx)[0];
                 HIP_TRY(ctx, launch_gather_split(image_dev, C_img, band_row0, band_rows, g, ctx->hp.nChannels, mean, stdv, t, nb,
-                                                 std::ldexp(1.f, ctx->act_shift), hi_of(b0), lo_of(b0, nb), ctx->stream));
+                                                 std::ldexp(1.f, ctx->act_shift), hi_of(b0), lo_of(b0, nb), run_stream(ctx)));
             } else {
                 HIP_TRY(ctx, launch_gather_normalise(image_dev, C_img, band_row0, band_rows, g, ctx->hp.nChannels, mean, stdv, t,
-                                                     nb, tiles32, ctx->stream));
+                                                     nb, tiles32, run_stream(ctx)));
             }
         }
         int rc = run_unet(ctx, direct16 ? nullptr : tiles32, nb, probs_dev + (size_t)(t - t0) * prob_f);
         if (rc) return rc;
     }
-    return UMX_OK;
+    return ll.join();
 }
 
 int umx_stitch_dev(umx_ctx* ctx, const float* probs_dev, int tpr0, int tpr1, int H, int W, int mode, int stitch, int y0,

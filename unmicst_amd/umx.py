@@ -43,7 +43,7 @@ class _HP(ctypes.Structure):
 
 class _Options(ctypes.Structure):
     _fields_ = [("device_ordinal", ctypes.c_int32), ("max_batch", ctypes.c_int32), ("precision", ctypes.c_int32),
-                ("act_shift", ctypes.c_int32), ("reserved", ctypes.c_int32 * 12)]
+                ("act_shift", ctypes.c_int32), ("lanes", ctypes.c_int32), ("reserved", ctypes.c_int32 * 11)]
 
 
 class ProfEntry(ctypes.Structure):
@@ -185,15 +185,16 @@ class Engine:
     """One umx_ctx: a model resident on one MI355X."""
 
     def __init__(self, hp: HParams, blob: np.ndarray, device: int = 0, max_batch: int = 32,
-                 precision="default", act_shift: int = -1):
+                 precision="default", act_shift: int = -1, lanes: int = 0):
         """precision: "default" (f16x3 unless UMX_PRECISION=f32), "f32" (exact fp32 MFMA) or "f16x3" (three binary16
-        MFMA products per fp32 product, fp32 accumulation) -- both hold the 1e-4 tolerance."""
+        MFMA products per fp32 product, fp32 accumulation) -- both hold the 1e-4 tolerance.
+        lanes: 0 = library default, 1 or 2 activation-buffer sets / streams the tile batches alternate between."""
         self._L = load()
         self.hp = hp
         self._ctx = ctypes.c_void_p()
         blob = np.ascontiguousarray(blob, dtype="<f4")
         h = _hp_struct(hp)
-        o = _Options(int(device), int(max_batch), PRECISIONS.get(precision, precision), int(act_shift))
+        o = _Options(int(device), int(max_batch), PRECISIONS.get(precision, precision), int(act_shift), int(lanes))
         rc = self._L.umx_create_opts(ctypes.byref(h), blob.ctypes.data, blob.size, ctypes.byref(o),
                                      ctypes.byref(self._ctx))
         if rc:
