@@ -52,7 +52,7 @@ typedef struct umx_options {
     int32_t max_batch;       /* tiles per UNet launch group */
     int32_t precision;       /* enum umx_precision */
     int32_t act_shift;       /* F16X3: activations stored times 2^act_shift (0..8); -1 = default (0) */
-    int32_t lanes;           /* 0 = default (2), 1 or 2: activation-buffer sets / streams the tile batches of one call
+    int32_t lanes;           /* 0 = default (1), 1 or 2: activation-buffer sets / streams the tile batches of one call
                                 alternate between (2: the kernels of consecutive batches overlap; twice the arena) */
     int32_t reserved[11];    /* must be zero */
 } umx_options;

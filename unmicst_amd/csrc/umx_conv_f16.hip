@@ -78,49 +78,94 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     unsigned char* const Bl = smem + p.b_off;
     const uint4* const wbase = ph.w + (size_t)nblk * ph.wblk_stride;
 
-    // Two-deep software pipeline: the LDS-DMA loads of stage s+1 (next weight block into the other weight buffer, and,
-    // at a chunk boundary, the next halo chunk into the other halo slot) are in flight while stage s runs its MFMAs.
-    // One barrier per stage: it orders "everyone's loads of stage s have landed" (each wave waits for its own first)
-    // and "everyone is done computing stage s-1" (so the buffers stage s+1 loads into are free).
-    auto issue = [&](const HStage& st, int buf) {
-        if (st.group >= 0) {
-            // Halo chunk: octets [oct0, oct0+noct) of operand group `group` into halo slot `plane0` (0/1).  The LDS image is
-            // pixel-major -- [halo pixel][OC octets], 16-byte slots -- so consecutive lanes of a wave-instruction fetch
-            // consecutive octets of one pixel and then the next pixel: whole channel vectors (64..144 contiguous bytes,
-            // contiguous across the pixels of a halo row when the chunk is the whole tensor) instead of 64 scattered
-            // 16-byte pieces.  An odd OC keeps the fragment reads of 16 consecutive pixels conflict-free.
-            const int g = st.group;
-            const _Float16* const shi = p.src_hi[g];
-            const _Float16* const slo = p.src_lo[g];
-            const int Cs = p.Cs[g];
-            const int nslots = p.nhalo * p.OC;                       // 16-byte slots of one plane (hi or lo) of a chunk
-            const int ninst = (nslots + 63) >> 6;
-            unsigned char* const slot = smem + st.plane0 * p.slot_bytes;
-            for (int t = wave; t < 2 * ninst; t += kWaves) {        // (instruction, hi|lo) pairs, wave-uniform
-                const int half = t & 1, idx = t >> 1;
-                const int sl = idx * 64 + lane;
-                const int px = (int)(((float)sl + 0.5f) * p.inv_OC);   // sl < 9216: exact after truncation
-                const int k = sl - px * p.OC;
-                if (sl < nslots && k < st.noct) {
-                    const int il = (int)(((float)px + 0.5f) * p.inv_imgplane);
-                    const int r = px - il * p.imgplane;
-                    const int hy = (int)(((float)r + 0.5f) * p.inv_hw);
-                    const int hx = r - hy * p.hw;
-                    const int gy = y0 + p.ymin + hy, gx = x0 + p.xmin + hx, img = img0 + il;
-                    const bool inside = img < p.B && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-                    const _Float16* const sb = half ? slo : shi;
-                    const void* src = inside ? (const void*)(sb + ((size_t)(img * p.H + gy) * p.W + gx) * Cs + (st.oct0 + k) * 8)
-                                             : (const void*)p.zeros;
-                    UMX_GLDS16(src, slot + (half ? lo_off : 0) + idx * 1024);
+    // ---- load path.  Everything is LDS-DMA (no staging VGPRs) through buffer descriptors: `buffer_load_dwordx4 .. offen lds`
+    // takes a wave-uniform descriptor + scalar offset and a 32-bit per-lane offset, and lanes whose offset is outside the
+    // descriptor write ZEROS to LDS (probed on MI355X, tools/probes/lds_dma_oob.hip) -- which is exactly the zero padding
+    // of the convolution, so no address arithmetic and no zero source survive in the stage loop:
+    //   halo    piece i of a chunk = PP = 64/OC consecutive halo pixels x OC octets (lanes >= PP*OC masked); wave w owns the
+    //           pieces w, w+4, ..; the NHWC pixel index each lane fetches for its j-th piece depends on the tile only, so
+    //           it is computed ONCE per workgroup (pix[j]); per chunk a piece costs one multiply-add + one select.
+    //   weights a linear copy: per-lane offset lane*16, the piece's position in the scalar offset: no VALU at all.
+    constexpr int MAXP = NT >= 6 ? 4 : 12;   // halo pieces per wave and chunk (the planner keeps ceil(ninst/4) <= MAXP)
+    const int pl = (lane * p.inv_oc_q16) >> 16;   // lane / OC   (exact for lane < 64, OC <= 9)
+    const int kq = lane - pl * p.OC;              // lane % OC: octet inside the chunk
+    int pix[MAXP];   // >= 0: pixel index relative to image img0; -2: zero padding; -1: this lane writes nothing
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+        const int px = (wave + kWaves * j) * p.PP + pl;
+        int v = -1;
+        if (lane < p.nact && px < p.nhalo) {
+            const int il = (int)(((float)px + 0.5f) * p.inv_imgplane);   // px < 1024: exact after truncation
+            const int r = px - il * p.imgplane;
+            const int hy = (int)(((float)r + 0.5f) * p.inv_hw);
+            const int hx = r - hy * p.hw;
+            const int gy = y0 + p.ymin + hy, gx = x0 + p.xmin + hx;
+            const bool inside = img0 + il < p.B && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            v = inside ? (il * p.H + gy) * p.W + gx : -2;
+        }
+        pix[j] = v;
+    }
+    // descriptors: activation planes from this workgroup's first image on (offsets stay far below 2^31), the weight slab of
+    // this (phase, N-block), the epilogue constants of this N-block
+    const size_t img_elems = (size_t)p.H * p.W;
+    auto act_rsrc = [&](const _Float16* base, int Cs) {
+        const size_t left = (size_t)(p.B - img0) * img_elems * Cs * 2;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)img0 * img_elems * Cs), 0,
+                                                 (int)(left < 0x7fffffffu ? left : 0x7fffffffu), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t r0h = act_rsrc(p.src_hi[0], p.Cs[0]), r0l = act_rsrc(p.src_lo[0], p.Cs[0]);
+    const __amdgpu_buffer_rsrc_t r1h = act_rsrc(p.src_hi[1] ? p.src_hi[1] : p.src_hi[0], p.Cs[1]),
+                                 r1l = act_rsrc(p.src_lo[1] ? p.src_lo[1] : p.src_lo[0], p.Cs[1]);
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, ph.wblk_stride * 16, 0x00020000);
+    const int lane16 = lane * 16;
+#define UMX_BLDS16(rsrc, lptr, voff, soff) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lptr), 16, voff, soff, 0, 0)
+
+    // all pieces of one halo chunk: octets [oct0, oct0+noct) of operand group `group` into halo slot `plane0`
+    auto issue_halo = [&](const HStage& st) {
+        const bool g1 = st.group > 0;
+        const int Cs2 = p.Cs[g1 ? 1 : 0] * 2;               // bytes per pixel of one plane
+        const __amdgpu_buffer_rsrc_t rh = g1 ? r1h : r0h, rl = g1 ? r1l : r0l;
+        unsigned char* const slot = smem + st.plane0 * p.slot_bytes;
+        const int soff = st.oct0 * 16;
+        const bool kok = kq < st.noct;
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) {
+            const int i = wave + kWaves * j;
+            if (i < p.ninst) {                   // wave-uniform
+                if (pix[j] != -1 && kok) {       // lanes of this piece
+                    const int voff = pix[j] >= 0 ? (int)__umul24(pix[j], Cs2) + kq * 16 : 0x7fffffff;
+                    UMX_BLDS16(rh, slot + i * p.piece_bytes, voff, soff);
+                    UMX_BLDS16(rl, slot + lo_off + i * p.piece_bytes, voff, soff);
                 }
             }
         }
-        // weight block: [64 B header: k-map of its k-steps][nk x NT x (hi, lo) images], a linear copy
+    };
+    // weight block of a stage: [64 B header: k-map of its k-steps][nk x NT x (hi, lo) images].  The header goes out at once
+    // (one 64-byte piece by the last wave); the 1-KiB pieces are handed out one per N-tile iteration of the MFMA loop below
+    // (wq_* state), so that a wave never queues a burst of vector-memory instructions in front of its matrix work.
+    int wq_pc = 0, wq_np = 0, wq_soff = 0;
+    unsigned char* wq_dst = Bl;
+    auto wq_begin = [&](const HStage& st, int buf) {
         unsigned char* const wl = Bl + buf * p.wbuf_bytes;
-        const uint4* const wsrc = wbase + st.woff;
-        if (wave == 0 && lane < 4) UMX_GLDS16(wsrc + lane, wl);
-        const int npieces = st.nk * NT * 2;
-        for (int pc = wave; pc < npieces; pc += kWaves) UMX_GLDS16(wsrc + 4 + pc * 64 + lane, wl + 64 + pc * 1024);
+        if (wave == kWaves - 1 && lane < 4) UMX_BLDS16(rw, wl, lane16, st.woff * 16);
+        wq_pc = wave;
+        wq_np = st.nk * NT * 2;
+        wq_soff = st.woff * 16 + 64;
+        wq_dst = wl + 64;
+    };
+    auto wq_one = [&]() {
+        if (wq_pc < wq_np) {
+            UMX_BLDS16(rw, wq_dst + wq_pc * 1024, lane16, wq_soff + wq_pc * 1024);
+            wq_pc += kWaves;
+        }
+    };
+    auto wq_drain = [&]() {
+        while (wq_pc < wq_np) {
+            UMX_BLDS16(rw, wq_dst + wq_pc * 1024, lane16, wq_soff + wq_pc * 1024);
+            wq_pc += kWaves;
+        }
     };
 
     // epilogue constants of this N-block ([pre_s | pre_b | post_s | post_b] x NT*16 floats, defaults and 2^shift factors
@@ -138,17 +183,30 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     const float* const ec = reinterpret_cast<const float*>(Bl + (ph.nstages & 1) * p.wbuf_bytes);
     if (ph.nstages == 0) issue_econst(0);
     HStage cur = p.stages[ph.stage0];
-    if (ph.nstages > 0) issue(cur, 0);
+    if (ph.nstages > 0) {
+        if (cur.group >= 0) issue_halo(cur);
+        wq_begin(cur, 0);
+        wq_drain();
+    }
     long long t_pro = 0;
     if (p.dbg) { t_pro = __builtin_amdgcn_s_memtime(); t_a = t_pro; }
+    // Two-deep software pipeline: the loads of stage s+1 (next weight block into the other weight buffer, and, at a chunk
+    // boundary, the next halo chunk into the other halo slot) are in flight while stage s runs its MFMAs.  One barrier
+    // per stage: it orders "everyone's loads of stage s have landed" (each wave waits for its own first) and "everyone is
+    // done computing stage s-1" (so the buffers stage s+1 loads into are free).
     for (int s = 0; s < ph.nstages; ++s) {
         const HStage nxt = p.stages[ph.stage0 + (s + 1 < ph.nstages ? s + 1 : s)];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (p.dbg) { const long long t_v = __builtin_amdgcn_s_memtime(); t_vm += t_v - t_a; }
         __syncthreads();
         if (p.dbg) { t_b = __builtin_amdgcn_s_memtime(); t_wait += t_b - t_a; }
-        if (s + 1 < ph.nstages) issue(nxt, (s + 1) & 1);
-        else issue_econst((s + 1) & 1);
+        if (s + 1 < ph.nstages) {
+            if (nxt.group >= 0) issue_halo(nxt);
+            wq_begin(nxt, (s + 1) & 1);
+            if (!(p.flags & 1)) wq_drain();   // A/B switch: all weight pieces up front (the round-1 schedule)
+        } else {
+            issue_econst((s + 1) & 1);
+        }
         if (p.dbg) t_iss += (long long)__builtin_amdgcn_s_memtime() - t_b;
 
         const unsigned char* const wl = Bl + (s & 1) * p.wbuf_bytes;
@@ -185,6 +243,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
                     }
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
+                        wq_one();   // next stage's weight pieces, one per N-tile: spread under the MFMAs
                         __builtin_amdgcn_iglp_opt(0);
                         if (n + kBPre < NT) {
                             bhq[(n + kBPre) % (kBPre + 1)] = *reinterpret_cast<const h8*>(bp + (n + kBPre) * 2048);
@@ -204,6 +263,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
                 }
             }
         }
+        wq_drain();   // pieces the stage had no N-tile iteration for
         cur = nxt;
         if (p.dbg) { t_a = __builtin_amdgcn_s_memtime(); t_comp += t_a - t_b; }
     }
@@ -387,8 +447,15 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
             if (row < R && c0 < p.Cds) {
                 const long pix = pixel_of(row);
                 if (pix >= 0) {
-                    const uint4 vh = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16);
-                    const uint4 vl = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16 + PLANE);
+                    uint4 vh = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16);
+                    uint4 vl = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16 + PLANE);
+                    if (p.app_hi && c0 == p.app_c0) {   // appended channels (exact zeros so far: padded output channels)
+                        const unsigned ah = *reinterpret_cast<const unsigned*>(p.app_hi + pix * p.app_Cs);
+                        const unsigned al = *reinterpret_cast<const unsigned*>(p.app_lo + pix * p.app_Cs);
+                        if (p.app_word == 1) { vh.y = ah; vl.y = al; }
+                        else if (p.app_word == 2) { vh.z = ah; vl.z = al; }
+                        else { vh.w = ah; vl.w = al; }
+                    }
                     *reinterpret_cast<uint4*>(p.dst_hi + pix * p.Cds + c0) = vh;
                     *reinterpret_cast<uint4*>(p.dst_lo + pix * p.Cds + c0) = vl;
                 }

@@ -52,6 +52,10 @@ struct Launch {
     std::vector<float> head_w;  // [C][K]
     int head_C = 0, head_K = 0;
     // derived
+    // split-precision plan only: after the epilogue, copy `app_C` (<= 2) channels of buffer `app_src` (same pixel grid) into
+    // the spare channels [app_c0, app_c0 + app_C) of this launch's last stored octet -- the raw-input skip of the top
+    // up-layer rides in the up-sampled tensor, so its convolution reads one 5-octet tensor instead of 1 + 5 octets
+    int app_src = -1, app_C = 0, app_c0 = 0;
     int nt = 1, Np = 16, hpix = 2;
     double flops = 0.0;       // algorithmic FLOPs per tile (per image of the batch)
     double exec_flops = 0.0;  // executed incl. channel/N padding
@@ -60,6 +64,8 @@ struct Launch {
     ConvParams cp;
     // split-precision plan (UMX_PREC_F16X3)
     HConvParams hcp;
+    RwParams rw;              // register-resident-weight plan (use_rw): the narrow full-resolution layers
+    bool use_rw = false;
     int nt16 = 1;             // N-tiles per workgroup of the split-precision kernel
     int wshift = 0;           // weights are stored times 2^wshift
     int n_ksteps = 0;         // K-slots of 32 executed per output tile, all phases (for the executed-FLOP figure)
@@ -103,6 +109,7 @@ struct umx_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float* d_tiles32_2 = nullptr;
     int nlanes = 1, lane = 0;
+    int ncu = 256;
     std::vector<void*> allocs;
     std::string err;
     // whole-image scratch (grown on demand)
@@ -222,6 +229,7 @@ struct Builder {
     std::vector<size_t> buf_floats;  // per tile
     std::vector<std::pair<int, int>> buf_geom;  // (spatial size, channels) per buffer
 
+    bool fold_top_skip = false;   // split-precision plan: see Launch::app_src
     explicit Builder(const umx_hparams& h, const float* b) : hp(h), blob(b) {}
 
     const float* take(size_t n) {
@@ -238,7 +246,9 @@ struct Builder {
     }
 
     // pack filter channels [c0, c0+C) of w [kh,kw,Cin,Cout] for the taps of a stride-1 SAME conv
-    void add_conv_group(Launch& L, int src, const HostTensor& w, int c0, int C, const HostTensor* add = nullptr) {
+    // (cmap: input channel c of the group reads filter channel cmap[c] instead of c0 + c)
+    void add_conv_group(Launch& L, int src, const HostTensor& w, int c0, int C, const HostTensor* add = nullptr,
+                        const std::vector<int>* cmap = nullptr) {
         Group& g = L.g[L.ngroups++];
         g.src = src;
         g.C = C;
@@ -252,7 +262,7 @@ struct Builder {
             for (int b = 0; b < w.d1; ++b)
                 for (int c = 0; c < C; ++c)
                     for (int o = 0; o < L.Cout; ++o) {
-                        float v = w.at(a, b, c0 + c, o);
+                        float v = w.at(a, b, cmap ? (*cmap)[c] : c0 + c, o);
                         if (add) {
                             // same-source shortcut folded into the main filter (exact algebra):
                             // ks x ks shortcut -> element-wise sum; 1x1 shortcut -> centre tap
@@ -405,8 +415,21 @@ struct Builder {
             int cv = new_buf(S2, Cup);
             snprintf(nm, sizeof nm, "lu%d.conv", idx);
             Launch Lc = make(nm, S2, Cup, cv, 0, act);
-            add_conv_group(Lc, ds[idx], w2, 0, Cskip);   // concat3([dsX[index], us]): skip channels first
-            add_conv_group(Lc, us, w2, Cskip, Cup);
+            const bool fold = fold_top_skip && idx == 0 && Cskip <= 2 && (Cup % 8) != 0 && (Cup % 8) % 2 == 0 &&
+                              (Cup % 8) + Cskip <= 8 && S2 >= 16;
+            if (fold) {
+                // the transposed convolution's epilogue drops the raw input channels into the spare channels of its last
+                // octet; this convolution then reads [us | skip] as one tensor (filter channels permuted accordingly)
+                Launch& Ltp = plan.back();
+                Ltp.app_src = ds[idx]; Ltp.app_C = Cskip; Ltp.app_c0 = Cup;
+                std::vector<int> cmap(Cup + Cskip);
+                for (int c = 0; c < Cup; ++c) cmap[c] = Cskip + c;
+                for (int c = 0; c < Cskip; ++c) cmap[Cup + c] = c;
+                add_conv_group(Lc, us, w2, 0, Cup + Cskip, nullptr, &cmap);
+            } else {
+                add_conv_group(Lc, ds[idx], w2, 0, Cskip);   // concat3([dsX[index], us]): skip channels first
+                add_conv_group(Lc, us, w2, Cskip, Cup);
+            }
             if (v2 && blob) fold_bn(bn, Cup, &Lc.pre_s, &Lc.pre_b);
             finish(Lc);
             int other = nx > 0 ? new_buf(S2, Cup) : -1;
@@ -538,6 +561,103 @@ int upload_raw(umx_ctx* ctx, const std::vector<T>& h, T** out) {
     return UMX_OK;
 }
 
+// ---- register-resident-weight plan (umx_conv_rw.hip) for a launch plan_f16 has just planned: a plain 3x3/5x5 convolution
+// at >= 16x16 resolution with a fused softmax head, one N-block, and a packed weight set small enough for the register
+// file.  All (tap, octet) pairs of all operand groups form ONE k-step list; the LDS image of a tile holds every octet of
+// every group side by side (pixel pitch OCT*16 bytes, OCT odd: conflict-free fragment reads).
+int plan_rw(umx_ctx* ctx, Launch& L, float wscale, std::string* why) {
+    (void)why;
+    L.use_rw = false;
+    const HConvParams& h = L.hcp;
+    {   // measured on MI355X: equal to conv_f16x3 on the layers it covers -- opt-in until it wins
+        const char* e = getenv("UMX_RW");
+        if (!e || atoi(e) == 0) return UMX_OK;
+    }
+    if (h.fused_phases || L.nphase != 1 || h.nblocks != 1 || h.head_K <= 0) return UMX_OK;
+    if (L.H < 16 || L.W < 16 || (L.H & 15) || (L.W & 15) || h.imgs != 1 || h.twm_log2 != 4 || h.th_log2 != 4) return UMX_OK;
+    auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    const int tx = L.W / 16, ty = L.H / 16;
+    if ((tx & (tx - 1)) || (ty & (ty - 1))) return UMX_OK;
+    RwParams& r = L.rw;
+    memset(&r, 0, sizeof r);
+    int oct_total = 0, npairs = 0;
+    for (int gi = 0; gi < L.ngroups; ++gi) {
+        r.noct[gi] = round_up(L.g[gi].C, 8) / 8;
+        r.goct[gi] = oct_total;
+        oct_total += r.noct[gi];
+        npairs += (int)L.g[gi].taps[0].size() * r.noct[gi];
+    }
+    const int nk = (npairs + 3) / 4;
+    if (!conv_rw_supported(h.NT, nk)) return UMX_OK;
+    r.ngroups = L.ngroups;
+    r.H = L.H; r.W = L.W;
+    r.hh = h.hh; r.hw = h.hw; r.nhalo = h.nhalo; r.ymin = h.ymin; r.xmin = h.xmin;
+    r.inv_hw = 1.f / (float)h.hw;
+    r.OCT = oct_total | 1;   // odd pixel pitch (in 16-byte slots): 16 consecutive pixels at one octet hit 16 distinct bank groups
+    r.pix_bytes = r.OCT * 16;
+    r.PP = 64 / r.OCT;
+    r.nact = r.PP * r.OCT;
+    r.ninst = (r.nhalo + r.PP - 1) / r.PP;
+    if ((r.ninst + 3) / 4 > 12) return UMX_OK;
+    r.piece_bytes = r.nact * 16;
+    r.inv_oct_q16 = 65536 / r.OCT + 1;
+    r.plane_bytes = round_up(r.nhalo * r.pix_bytes, 16);
+    r.ec_off = 4 * r.plane_bytes;
+    r.ec_units = (4 + h.head_K) * (h.NT * 4) + 4;
+    r.lds_bytes = r.ec_off + (8 * h.NT * 16 + 16) * 4;   // the kernel's LDS copy holds four head rows
+    if (r.lds_bytes > 160 * 1024 || r.nhalo * r.OCT > 65535) return UMX_OK;
+    r.tx_log2 = lg2(tx); r.ty_log2 = lg2(ty);
+    r.nk = nk;
+    r.act = L.act; r.head_K = h.head_K;
+    r.econst = h.econst;
+    // k-step list: group-major, tap-major, octet-minor; the tail is padded with zero-weight pairs on a loaded slot
+    struct P { int gi, tap, oct; };
+    std::vector<P> pairs;
+    for (int gi = 0; gi < L.ngroups; ++gi)
+        for (int t = 0; t < (int)L.g[gi].taps[0].size(); ++t)
+            for (int o = 0; o < r.noct[gi]; ++o) pairs.push_back({gi, t, o});
+    while (pairs.size() % 4) pairs.push_back({0, -1, 0});
+    std::vector<unsigned short> kmap((size_t)nk * 4);
+    std::vector<_Float16> W((size_t)nk * h.NT * 2 * 512, (_Float16)0.f);
+    for (int j = 0; j < nk; ++j) {
+        for (int qq = 0; qq < 4; ++qq) {
+            const P& pr = pairs[(size_t)j * 4 + qq];
+            const auto& tp = L.g[pr.gi].taps[0][pr.tap < 0 ? 0 : pr.tap];
+            kmap[(size_t)j * 4 + qq] = (unsigned short)(((tp.first - r.ymin) * r.hw + (tp.second - r.xmin)) * r.OCT +
+                                                        r.goct[pr.gi] + pr.oct);
+        }
+        for (int n = 0; n < h.NT; ++n)
+            for (int lane = 0; lane < 64; ++lane) {
+                const P& pr = pairs[(size_t)j * 4 + (lane >> 4)];
+                if (pr.tap < 0) continue;
+                const Group& G = L.g[pr.gi];
+                const int Cp = round_up(G.C, 4);
+                const int co = n * 16 + (lane & 15);
+                const size_t base = (((size_t)j * h.NT + n) * 2) * 512 + (size_t)lane * 8;
+                for (int e = 0; e < 8; ++e) {
+                    const int c = pr.oct * 8 + e;
+                    if (c >= G.C || co >= L.Cout) continue;
+                    const float v = G.packed[0][((size_t)pr.tap * Cp + c) * L.Np + co] * wscale;
+                    const _Float16 hi = (_Float16)v;
+                    W[base + e] = hi;
+                    W[base + 512 + e] = (_Float16)(v - (float)hi);
+                }
+            }
+    }
+    int rc;
+    unsigned short* dk = nullptr;
+    _Float16* dw = nullptr;
+    if ((rc = upload_raw(ctx, kmap, &dk)) || (rc = upload_raw(ctx, W, &dw))) return rc;
+    r.kmap = dk;
+    r.w = reinterpret_cast<const uint4*>(dw);
+    L.use_rw = true;
+    L.exec_flops = 2.0 * 3.0 * (double)nk * 32.0 * (h.NT * 16) * L.H * L.W;
+    if (getenv("UMX_DEBUG_PLAN"))
+        fprintf(stderr, "[umx plan] %-12s register-resident weights: NT %d, %d k-steps, OCT %d, %d pieces per tile, LDS %d B\n",
+                L.name.c_str(), h.NT, nk, r.OCT, r.ninst, r.lds_bytes);
+    return UMX_OK;
+}
+
 // ---- split-precision plan of one conv launch: chunking of the input octets, k-step table, stage table, weight images
 // (layout documented in umx_conv_f16.hip).  Reads the fp32 packing [tap][Cp][Np] produced by the Builder.
 int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch* head, std::string* why) {
@@ -620,7 +740,9 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         if (!fused && nt16 <= 3 && narrow >= 16 * 1024) lds_cap = std::min(lds_cap, narrow);
     }
     const int stage_rows = fused ? 32 : 16;
-    const int epi_bytes = kWaves * 2 * stage_rows * (nt16 * 32 + 16);   // epilogue transpose staging
+    const int nwaves = kWaves;
+    h.kmt = fused ? 2 : kMT;
+    const int epi_bytes = nwaves * 2 * stage_rows * (nt16 * 32 + 16);   // epilogue transpose staging
 
     // One stage list (= one kernel phase, or the whole fused transposed convolution) for a given (OC, S, slot base E):
     // (tap, octet) pairs of every chunk -> k-steps of 4 -> stages of <= S k-steps.  Pairs left over when a chunk's
@@ -693,6 +815,8 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
             if (ch.size() >= 2) nslots = 2;
             for (const auto& c : ch) sectors += 2.0 * h.nhalo * ((c.o1 - c.o0 + 3) / 4);
         }
+        // the kernel keeps one pixel index per (wave, piece of a chunk) in registers: at most 4 (NT >= 6) or 12 pieces per wave
+        if (((h.nhalo + 64 / OC - 1) / (64 / OC) + nwaves - 1) / nwaves > (nt16 >= 6 ? 4 : 12)) continue;
         for (int S = 1; S <= kStageK; ++S) {
             const int lds = nslots * OC * plane_pair + 2 * (64 + S * nt16 * 2048);
             if (lds > lds_cap) continue;
@@ -712,6 +836,15 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     const int OC = bestOC, S = bestS;
     h.OC = OC;
     h.inv_OC = 1.f / (float)OC;
+    h.PP = 64 / OC;
+    h.nact = h.PP * OC;
+    h.ninst = (h.nhalo + h.PP - 1) / h.PP;
+    h.piece_bytes = h.nact * 16;
+    h.inv_oc_q16 = 65536 / OC + 1;
+    {
+        const char* e = getenv("UMX_CONV_FLAGS");
+        h.flags = e ? atoi(e) : 1;
+    }
     h.pix_bytes = OC * 16;
     h.slot_bytes = h.plane_slots * OC * 16;
     h.lo_off = bestSlots * h.slot_bytes;
@@ -835,7 +968,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         h.ph[list].w = reinterpret_cast<const uint4*>(d);
     }
     L.exec_flops = 2.0 * 3.0 * (double)L.n_ksteps * 32.0 * Np16 * L.H * L.W;   // MFMA work incl. split and padding
-    return UMX_OK;
+    return plan_rw(ctx, L, wscale, why);
 }
 
 int grow(umx_ctx* ctx, void** buf, size_t* cap, size_t bytes) {
@@ -943,9 +1076,15 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
     if (p.head_K > 0) p.probs = probs + (size_t)k0 * L.H * L.W * p.head_K;   // fused softmax head
     else if (db.as_f32) p.dst_f32 = db.d + (size_t)k0 * db.floats_per_tile;
     else { p.dst_hi = hi_at(db); p.dst_lo = lo_at(db); }
+    if (L.app_src >= 0) {
+        const Buffer& ab = cur_bufs(ctx)[L.app_src];
+        p.app_hi = hi_at(ab); p.app_lo = lo_at(ab); p.app_Cs = ab.Cs;
+        p.app_c0 = (L.app_c0 / 8) * 8;            // first channel of the destination octet
+        p.app_word = (L.app_c0 % 8) / 2;          // 32-bit word of that octet the two appended binary16 values fill
+    }
     char kn[48];
     // the instantiation as rocprofv3 names it (<NT, KMT, NPH>): bench.py groups the timed sites by kernel
-    snprintf(kn, sizeof kn, "conv_f16x3<%d, %d, %d>", L.nt16, p.fused_phases ? 2 : kMT, p.fused_phases ? 4 : 1);
+    snprintf(kn, sizeof kn, "conv_f16x3<%d, %d, %d>", L.nt16, p.kmt, p.fused_phases ? 4 : 1);
     {
         // diagnostic: UMX_DEBUG_STAMPS=<layer name> prints the mean s_memtime segments of that layer's workgroups
         static const char* dbg_layer = getenv("UMX_DEBUG_STAMPS");
@@ -967,6 +1106,17 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
                     L.name.c_str(), nwg, p.lds_bytes, p.wbuf_bytes, m[0], m[1], m[5], m[1] - m[5], m[6], m[2] - m[6], m[3], m[4]);
             return UMX_OK;
         }
+    }
+    if (L.use_rw && (size_t)ns * L.H * L.W * std::max(p.Cs[0], p.Cs[1]) * 2 < 0x7fffffffu) {
+        RwParams r = L.rw;
+        r.B = ns;
+        for (int gi = 0; gi < L.ngroups; ++gi) { r.src_hi[gi] = p.src_hi[gi]; r.src_lo[gi] = p.src_lo[gi]; r.Cs[gi] = p.Cs[gi]; }
+        r.probs = p.probs;
+        r.ntiles = ns << (r.tx_log2 + r.ty_log2);
+        snprintf(kn, sizeof kn, "conv_rw<%d, %d>", L.nt16, r.nk);
+        ProfScope ps(ctx, site_of(ctx, L.name, kn), L.flops * ns, L.bytes * ns, L.exec_flops * ns);
+        HIP_TRY(ctx, launch_conv_rw(r, L.nt16, ctx->ncu, run_stream(ctx)));
+        return UMX_OK;
     }
     ProfScope ps(ctx, site_of(ctx, L.name, kn), L.flops * ns, L.bytes * ns, L.exec_flops * ns);
     HIP_TRY(ctx, launch_conv_f16(p, run_stream(ctx)));
@@ -1182,6 +1332,7 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
                     prop.gcnArchName);
 
     std::unique_ptr<umx_ctx> ctx(new umx_ctx());
+    ctx->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->hp = *hp;
     ctx->device = device_ordinal;
     ctx->max_batch = max_batch;
@@ -1193,6 +1344,10 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
     c->stream = c->own_stream;
 
     Builder b(*hp, weight_blob);
+    {   // opt-in: the append costs the transposed convolution more than the convolution gains
+        const char* e = getenv("UMX_FOLD");
+        b.fold_top_skip = precision == UMX_PREC_F16X3 && e && atoi(e) != 0;
+    }
     b.build();
     if (b.pos != blob_floats) { umx_destroy(ctx.release()); return fail(nullptr, UMX_ERR_BLOB, "internal blob walk mismatch"); }
     c->plan = std::move(b.plan);
@@ -1216,7 +1371,7 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
     {
         int lanes = opts->lanes;
         if (const char* e = getenv("UMX_LANES")) lanes = atoi(e);
-        if (lanes == 0) lanes = 2;
+        if (lanes == 0) lanes = 1;   // two lanes measured neutral on MI355X: off by default
         if (lanes < 1 || lanes > 2) { c->err = "lanes must be 1 or 2"; return bail(UMX_ERR_INVALID); }
         c->nlanes = lanes;
     }

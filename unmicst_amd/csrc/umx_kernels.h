@@ -91,6 +91,11 @@ struct HConvParams {
     int plane_slots;             // halo pixels per LDS slot image, rounded up to a multiple of 16
     int OC, pix_bytes, slot_bytes;   // octets per staged pixel (odd), OC*16, bytes of one halo slot's hi image
     float inv_OC;
+    int PP, nact, ninst;           // halo chunk = ninst LDS-DMA pieces of PP = 64/OC pixels x OC octets (nact = PP*OC lanes)
+    int piece_bytes;               // PP*OC*16: LDS bytes one piece fills (the image stays dense: slot = pixel*OC + octet)
+    int inv_oc_q16;                // 65536/OC + 1: lane / OC == (lane * inv_oc_q16) >> 16 for lane < 64
+    int kmt;                       // M-tiles per wave of the plain kernel: 4 (4 waves per workgroup) or 2 (8 waves)
+    int flags;                     // bit 0: hand the next stage's weight pieces out one per N-tile iteration of the MFMA loop
     int lo_off, b_off, lds_bytes;  // LDS byte offsets: lo planes, weight buffers; total dynamic LDS
     int wbuf_bytes;                // one weight buffer (there are two): 64 + S * NT * 2048
     int ymin, xmin, tiles_y, tiles_x;
@@ -101,6 +106,9 @@ struct HConvParams {
     const uint4* zeros;          // >= 16 bytes of zeros in global memory (source for out-of-image halo slots)
     _Float16* dst_hi;
     _Float16* dst_lo;
+    const _Float16* app_hi;      // non-NULL: after the epilogue, word `app_word` (2 channels) of the stored octet that starts
+    const _Float16* app_lo;      // at channel app_c0 is replaced by channels 0..1 of this tensor ([..,app_Cs], same pixel
+    int app_Cs, app_c0, app_word;   // grid as the destination): the raw-input skip rides in the spare channels
     float* dst_f32;              // non-NULL: write fp32 NHWC [..,Cout] instead of the (hi, lo) pair
     float* probs;                // head_K > 0: fused 1x1 conv + BN affine + softmax head, probabilities NHWC [..,head_K]
     int head_K;                  // (needs nblocks == 1: every channel of a pixel in one workgroup)
@@ -116,6 +124,31 @@ struct HConvParams {
 };
 
 hipError_t launch_conv_f16(const HConvParams& p, hipStream_t stream);
+
+// ---- register-resident-weight variant for the narrow full-resolution layers (umx_conv_rw.hip): persistent workgroups,
+// the layer's whole packed weight set in VGPRs, only input halos move (LDS-DMA, double-buffered per 16x16-pixel tile)
+struct RwParams {
+    const _Float16* src_hi[2];   // NHWC binary16 [B,H,W,Cs], hi and lo planes, per operand group
+    const _Float16* src_lo[2];
+    int Cs[2], noct[2], goct[2]; // stored channels; octets loaded; first octet column of the group in the LDS image
+    int ngroups;
+    int B, H, W;                 // H, W multiples of 16 (tile = 16 x 16 output pixels)
+    int hh, hw, nhalo, ymin, xmin;
+    float inv_hw;
+    int OCT, pix_bytes;          // octet columns per halo pixel of the LDS image (all groups side by side), OCT*16
+    int PP, nact, ninst, piece_bytes, inv_oct_q16;   // LDS-DMA pieces of PP = 64/OCT pixels
+    int plane_bytes;             // hi image of one tile buffer (== offset of its lo image); a buffer is 2*plane_bytes
+    int ec_off, ec_units, lds_bytes;
+    int tx_log2, ty_log2, ntiles;   // tiles per image row / column (powers of two), B*tiles
+    int nk;                      // k-steps (the kernel's NK)
+    const unsigned short* kmap;  // [nk][4]: 16-byte slot of the (tap, octet) pair inside a tile buffer's hi image
+    const uint4* w;              // [nk][NT][hi|lo][64 lanes] x 16 B: MFMA A-fragments
+    const uint4* econst;         // as HConvParams::econst (one N-block)
+    int act, head_K;
+    float* probs;                // fused 1x1 head + BN + softmax output, NHWC [B,H,W,head_K]
+};
+bool conv_rw_supported(int NT, int NK);
+hipError_t launch_conv_rw(const RwParams& p, int NT, int ncu, hipStream_t stream);
 hipError_t launch_split_f32(const float* x, size_t npix, int C, int Cs, float scale, _Float16* hi, _Float16* lo,
                             hipStream_t stream);
 
