@@ -1,26 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- whole-slide tiled inference throughput (tiles/s) on N MI355X of one node.
 
-A "step" is one pass of the hot path over one synthetic slide already resident in HBM:
-  PI2D gather + normalise -> UNet forward (all classes) -> fp16-compat stitch  [-> halo exchange + RCCL all-gather, N>1].
+A "step" is one pass of the hot path over one synthetic slide, measured the way SURVEY.md section 8(d) scopes it:
+  H2D of the slide -> PI2D gather + normalise -> UNet forward (all classes) -> fp16-compat stitch
+  [-> band halo exchange + RCCL all-gather, N>1] -> D2H of the probability stack.
+N = 1 goes through the library's host entry point (umx_infer_image_raw: uint16 planes up, uint8 planes down, in row slabs on
+two copy streams under the tile kernels); the same slide resident in HBM (umx_infer_image_dev) is timed right after it
+and reported as `resident` in the same JSON line (kernel-only number, never `value`).
 Default workload (``wsi-synth256``): BASELINE.json's metric tile (256x256x2, v2 graph, duo widths 36..1152, seeded
 weights) on a 2-channel synthetic slide of 2048*N x 16384 px -- each rank holds a 2048-row band, so per-GPU work is
-fixed ("weak") and N=8 is exactly the 16384 x 16384 slide of the north star (86 x 86 = 7396 tiles).
-Other workloads (parity-test configs of BASELINE.json, not the headline): solo-1024, duo-4096, legacy-105.
+fixed ("weak") and N=8 is exactly the 16384 x 16384 slide of the north star (86 x 86 = 7396 tiles).  ``--scaling strong``
+keeps the 16384 x 16384 slide at every N.  Other workloads are parity-test configs of BASELINE.json, not the headline.
 
-Prints ONE JSON line on rank 0.  Launch: `python bench.py` (N=1) or
-`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N`.
+Prints ONE JSON line on rank 0.  Launch: `python bench.py [--gpus N]` -- for N > 1 outside torch.distributed.run this
+process starts `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` as a CHILD (before anything
+touches the GPU) and relays its output and exit code; under torch.distributed.run it is one rank.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: bf16/f16 MFMA dense peak (~2.5 PF; 16x the fp32 matrix rate)
@@ -29,32 +33,84 @@ PEAK_HBM_GBS = 8000.0
 WORKLOADS = {
     # name: (model key, channels in image, band rows per GPU, cols)
     "wsi-synth256": ("synthetic-256", 2, 2048, 16384),
+    "solo-16384": ("nucleiDAPI1-5", 1, 2048, 16384),     # BASELINE.json configs[3] as worded: solo hp, 16384^2 at N = 8
     "solo-1024": ("nucleiDAPI1-5", 1, 1024, 1024),
     "duo-4096": ("nucleiDAPILAMIN", 2, 4096, 4096),
     "legacy-1024": ("nucleiDAPI", 1, 1024, 1024),
 }
+NORMALISATION = {"synthetic-256": (0.18, 0.17), "nucleiDAPI1-5": (0.34, 0.25), "nucleiDAPILAMIN": (0.18, 0.17),
+                 "nucleiDAPI": (0.19808, 0.16236)}
 
 
-def synth_rows(torch, C, row0, rows, W, device):
-    """Deterministic synthetic slide content for image rows [row0, row0+rows): smooth structure + hashed noise in
-    [0, 0.983] (what the driver's rescale_intensity produces), float64 [C, rows, W].  Any rank can generate any rows."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="wsi-synth256", choices=sorted(WORKLOADS) + ["train-synth256"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank holds a band of --band-rows rows (slide grows with N); strong: the slide of "
+                         "8 bands (16384 rows by default) at every N")
+    ap.add_argument("--train-batch", type=int, default=8, help="train-synth256: images per optimisation step")
+    ap.add_argument("--batch", type=int, default=256, help="tiles per UNet launch group")
+    ap.add_argument("--precision", default="default", choices=["default", "f32", "f16x3"],
+                    help="conv arithmetic: exact fp32 MFMA, or 3 binary16 MFMA products per fp32 product (default)")
+    ap.add_argument("--band-rows", type=int, default=0, help="override rows per GPU")
+    ap.add_argument("--cols", type=int, default=0, help="override slide width")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-baseline legs (0 = skip)")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-layer table to stderr")
+    ap.add_argument("--slabs", type=int, default=2, help="N>1 path: row slabs per band (stitch + async all-gather each)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the N>1 code path (band halo exchange + slab all-gathers) even in a world of one rank")
+    ap.add_argument("--resident-only", action="store_true",
+                    help="time only the HBM-resident slide (kernel-only; the line's value is then NOT the section-8(d) metric)")
+    ap.add_argument("--master-port", type=int, default=29577)
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="N>1 launch test: every rank prints its rank/world line and exits before touching a GPU")
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """--gpus N > 1 outside torch.distributed.run: start the N ranks as a child process tree (this process never touches
+    the GPU -- replacing a GPU-initialised process image takes the box down, and nothing here has imported torch yet)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def synth_rows_u16(torch, C, row0, rows, W, device):
+    """Deterministic synthetic slide content for image rows [row0, row0+rows): smooth structure + hashed noise, uint16
+    [C, rows, W] (kept as int32 on the device).  Any rank can generate any rows."""
     y = torch.arange(row0, row0 + rows, device=device, dtype=torch.float64)[None, :, None]
     x = torch.arange(W, device=device, dtype=torch.float64)[None, None, :]
     c = torch.arange(C, device=device, dtype=torch.float64)[:, None, None]
     base = 0.22 + 0.18 * torch.sin(y / 37.0 + c) * torch.cos(x / 53.0) + 0.1 * torch.sin((x + 2 * y) / 11.0 + 2 * c)
     h = torch.frac(torch.sin(x * 12.9898 + y * 78.233 + c * 37.719) * 43758.5453)
-    return torch.clamp(base + 0.12 * h, 0.0, 0.983).contiguous()
+    v = torch.clamp(base + 0.12 * h, 0.0, 0.983)
+    return torch.round(v * 65535.0).to(torch.int32).contiguous()
+
+
+def im2double(torch, u16_i32):
+    """toolbox/imtools.py:42-53 for uint16: np.multiply(I, 1/65535) in float64."""
+    return (u16_i32.to(torch.float64) * (1.0 / 65535)).contiguous()
 
 
 def pmc_traffic(kernel, precision, batch):
     """HBM bytes per launch of `kernel` (a template instantiation as rocprofv3 names it, e.g. "conv_f16x3<9, 4, 1>"),
     averaged over its launches, from the committed rocprofv3 counter passes of this same command
-    (profiles/r01/final_<precision>_b<batch>_by_layer_pmc.csv, written by tools/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE collected
+    (profiles/rNN/final_<precision>_b<batch>_by_layer_pmc.csv, written by tools/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE collected
     in separate --pmc passes, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  None when no profile of
     this configuration is committed."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01", "final_%s_b%d_by_layer_pmc.csv" % (precision, batch))
-    if not os.path.exists(path):
+    path = None
+    for rnd in ("r02", "r01"):
+        cand = os.path.join(ROOT, "profiles", rnd, "final_%s_b%d_by_layer_pmc.csv" % (precision, batch))
+        if os.path.exists(cand):
+            path = cand
+            break
+    if path is None:
         return None
     calls = rd = wr = us = 0.0
     with open(path, newline="") as f:
@@ -72,40 +128,77 @@ def pmc_traffic(kernel, precision, batch):
             "source": os.path.relpath(path, ROOT)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="wsi-synth256", choices=sorted(WORKLOADS) + ["train-synth256"])
-    ap.add_argument("--train-batch", type=int, default=8, help="train-synth256: images per optimisation step")
-    ap.add_argument("--batch", type=int, default=256, help="tiles per UNet launch group")
-    ap.add_argument("--precision", default="default", choices=["default", "f32", "f16x3"],
-                    help="conv arithmetic: exact fp32 MFMA, or 3 binary16 MFMA products per fp32 product (default)")
-    ap.add_argument("--band-rows", type=int, default=0, help="override rows per GPU")
-    ap.add_argument("--cols", type=int, default=0, help="override slide width")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--breakdown", action="store_true", help="print the per-layer table to stderr")
-    ap.add_argument("--slabs", type=int, default=2, help="N>1 path: row slabs per band (stitch + async all-gather each)")
-    ap.add_argument("--force-sharded", action="store_true",
-                    help="run the N>1 code path (band halo exchange + slab all-gathers) even in a world of one rank")
-    args = ap.parse_args()
+def roofline_of(prof, elapsed_s, eng, batch):
+    """Roofline of the dominant kernel = the template instantiation with the largest share of the timed region (what
+    `rocprofv3 --stats` ranks first), from the in-library HIP events recorded on the stream the kernels are launched on;
+    one kernel serves several layers, so the figures are launch-weighted averages over its sites."""
+    convs = [p for p in prof if p["kernel"].startswith("conv_")]
+    by_kernel = {}
+    for p in convs:
+        k = by_kernel.setdefault(p["kernel"], {"ms": 0.0, "flops": 0.0, "exec": 0.0, "bytes": 0.0, "launches": 0, "layers": []})
+        k["ms"] += p["total_ms"]; k["flops"] += p["flops"]; k["exec"] += p["exec_flops"]; k["bytes"] += p["bytes"]
+        k["launches"] += p["launches"]; k["layers"].append(p["name"])
+    dom_name = max(by_kernel, key=lambda n: by_kernel[n]["ms"])
+    dom = by_kernel[dom_name]
+    dom_tflops = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    slow = max(convs, key=lambda p: p["total_ms"])
+    all_flops = sum(p["flops"] for p in convs)
+    all_exec = sum(p["exec_flops"] for p in convs)
+    all_ms = sum(p["total_ms"] for p in convs)
+    peak = PEAK_F16_MFMA_TFLOPS if eng.precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
+    return {
+        # achieved = ALGORITHMIC fp32 FLOPs of the kernel's launches / HIP-event time of those launches; peak = dense MFMA
+        # peak of the dtype the matrix cores run (f16x3 issues 3 binary16 MFMA FLOPs per algorithmic FLOP: "mfma_issued")
+        "bound": "mfma", "achieved": round(dom_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+        "frac": round(dom_tflops / peak, 4), "traffic": pmc_traffic(dom_name, eng.precision, batch),
+        "kernel": dom_name, "layers": dom["layers"], "share_of_step": round(dom["ms"] / (1e3 * elapsed_s), 4),
+        "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
+        "flop_per_launch": dom["flops"] / dom["launches"],
+        "mfma_issued": {"tflops": round(dom["exec"] / (dom["ms"] * 1e-3) / 1e12, 2),
+                        "frac": round(dom["exec"] / (dom["ms"] * 1e-3) / 1e12 / peak, 4)},
+        "compulsory_hbm": {"GBps": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
+                           "frac_of_8TBps": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
+        "slowest_layer": {"layer": slow["name"], "kernel": slow["kernel"],
+                          "achieved": round(slow["flops"] / (slow["total_ms"] * 1e-3) / 1e12, 2),
+                          "frac": round(slow["flops"] / (slow["total_ms"] * 1e-3) / 1e12 / peak, 4),
+                          "avg_launch_us": round(1e3 * slow["total_ms"] / slow["launches"], 2)},
+        "all_conv_launches": {"achieved": round(all_flops / (all_ms * 1e-3) / 1e12, 2),
+                              "frac": round(all_flops / (all_ms * 1e-3) / 1e12 / peak, 4),
+                              "mfma_issued_frac": round(all_exec / (all_ms * 1e-3) / 1e12 / peak, 4),
+                              "share_of_step": round(all_ms / (1e3 * elapsed_s), 4)},
+    }
 
+
+def print_breakdown(prof):
+    print("%-24s %-30s %8s %10s %9s %9s" % ("layer", "kernel", "launches", "total_ms", "TFLOP/s", "GB/s"), file=sys.stderr)
+    for p in sorted(prof, key=lambda p: -p["total_ms"]):
+        s = p["total_ms"] * 1e-3
+        print("%-24s %-30s %8d %10.3f %9.2f %9.1f" % (p["name"], p["kernel"], p["launches"], p["total_ms"],
+                                                      p["flops"] / s / 1e12, p["bytes"] / s / 1e9), file=sys.stderr)
+
+
+def main():
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        sys.exit(self_launch(args))
+    world = int(world_env or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    if args.dry_launch:
+        print("bench.py dry launch: rank %d of %d (local rank %d)" % (rank, world, local_rank), flush=True)
+        return
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     from unmicst_amd import model, sharding, umx
 
     if args.workload == "train-synth256":
         return bench_train(args, torch)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world),
-                  file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py needs a MI355X (there is no CPU fallback)", file=sys.stderr)
         sys.exit(3)
@@ -114,7 +207,7 @@ def main():
     sharded = world > 1 or args.force_sharded
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("MASTER_PORT", str(args.master_port))
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     key, C_img, band_rows, W = WORKLOADS[args.workload]
@@ -122,115 +215,153 @@ def main():
     W = args.cols or W
     hp = model.KNOWN_HP[key]
     blob = model.random_blob(hp, seed=20260101)
-    mean, std = {"synthetic-256": (0.18, 0.17), "nucleiDAPI1-5": (0.34, 0.25), "nucleiDAPILAMIN": (0.18, 0.17),
-                 "nucleiDAPI": (0.19808, 0.16236)}[key]
-    H = band_rows * world
+    mean, std = NORMALISATION[key]
+    H = band_rows * (8 if args.scaling == "strong" else world)
 
     eng = umx.Engine(hp, blob, device=local_rank, max_batch=args.batch, precision=args.precision)
-    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    # every engine launch, torch op and RCCL call of this process is ordered on ONE non-default stream
+    work = torch.cuda.Stream(dev)
+    eng.set_stream(work.cuda_stream)
     npr, npc, _, _ = eng.tile_grid(H, W)
     tiles_total = npr * npc
     margin = hp.margin
     sub = hp.imSize - 2 * margin
     pa, pb = sharding.band_partition(npr, world)[rank]
     r0, r1 = sharding.needed_image_rows(pa, pb, sub, margin, hp.imSize, H)
-    band = synth_rows(torch, C_img, r0, max(r1 - r0, 1), W, dev)   # resident in HBM before the timed region
-    out_full = torch.empty((hp.nClasses, H, W), dtype=torch.float16, device=dev) if not sharded else None
+    rows = max(r1 - r0, 1)
+    # the slide on the HOST, pinned: uint16 planes [C, rows, W], the rows this rank's tiles read
+    with torch.cuda.stream(work):
+        band_i32 = synth_rows_u16(torch, C_img, r0, rows, W, dev)
+        host_u16 = torch.empty((C_img, rows, W), dtype=torch.int16).pin_memory()
+        host_u16.copy_(band_i32.to(torch.int16))                      # bit pattern of the uint16 values
+        band_f64 = im2double(torch, band_i32)                          # the HBM-resident twin (kernel-only timing)
+        del band_i32
+    work.synchronize()
+    K = hp.nClasses
 
-    def step():
-        if not sharded:
-            eng.infer_image_dev(band.data_ptr(), C_img, H, W, mean, std, umx.MODE_ACCUMULATE, umx.STITCH_FP16_COMPAT,
-                                out_full.data_ptr())
-            return out_full
-        return sharding.infer_image_sharded(eng, band, r0, H, W, mean, std, umx.MODE_ACCUMULATE,
-                                            umx.STITCH_FP16_COMPAT, nslabs=args.slabs)
+    if not sharded:
+        host_outs = [torch.empty((K, H, W), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        host_out = host_outs[0]
+        dev_out = torch.empty((K, H, W), dtype=torch.float16, device=dev)
+        inflight = []
+
+        def step_host():
+            # section 8(d): H2D + tiles + stitch + D2H of every slide, through the C ABI's host entry points.  Slides are
+            # streamed the way a per-file driver loop would: slide i+1 is submitted (its upload starts) while slide i
+            # computes, so at most two are in flight; fence() drains the last one inside the timed region.
+            slot = step_host.n & 1
+            step_host.n += 1
+            if len(inflight) == 2:
+                eng.infer_image_wait(inflight.pop(0))
+            eng.infer_image_raw_submit(slot, host_u16.data_ptr(), 16, C_img, H, W, False, mean, std,
+                                       host_outs[slot].data_ptr())
+            inflight.append(slot)
+        step_host.n = 0
+
+        def step_resident():
+            eng.infer_image_dev(band_f64.data_ptr(), C_img, H, W, mean, std, umx.MODE_ACCUMULATE, umx.STITCH_FP16_COMPAT,
+                                dev_out.data_ptr())
+    else:
+        y0, y1 = sharding.owned_rows(pa, pb, npr, sub, margin, H)
+        host_band = torch.empty((K, max(y1 - y0, 0), W), dtype=torch.float16).pin_memory()
+        dev_u16 = torch.empty((C_img, rows, W), dtype=torch.int16, device=dev)
+
+        def step_host():   # H2D of this rank's band + tiles + halo exchange + stitch + all-gather + D2H of its stitched band
+            with torch.cuda.stream(work):
+                dev_u16.copy_(host_u16, non_blocking=True)
+                band = (dev_u16.to(torch.int32) & 0xFFFF).to(torch.float64) * (1.0 / 65535)
+                full = sharding.infer_image_sharded(eng, band, r0, H, W, mean, std, umx.MODE_ACCUMULATE,
+                                                    umx.STITCH_FP16_COMPAT, nslabs=args.slabs)
+                host_band.copy_(full[:, y0:y1], non_blocking=True)
+            return full
+
+        def step_resident():
+            with torch.cuda.stream(work):
+                return sharding.infer_image_sharded(eng, band_f64, r0, H, W, mean, std, umx.MODE_ACCUMULATE,
+                                                    umx.STITCH_FP16_COMPAT, nslabs=args.slabs)
 
     def fence():
+        if not sharded:
+            while inflight:
+                eng.infer_image_wait(inflight.pop(0))
+        eng.synchronize()            # also surfaces UMX_ERR_RANGE of the split-precision path
+        work.synchronize()
         if sharded:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    eng.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof = eng.profile_read()
-    eng.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    checksum = float(res.float().mean().item())
+    def timed(step):
+        for _ in range(args.warmup):
+            step()
+        fence()
+        eng.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = step()
+        fence()
+        dt = time.perf_counter() - t0
+        prof = eng.profile_read()
+        eng.profile_enable(False)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, prof, res
+
+    host_elapsed = host_prof = None
+    if not args.resident_only:
+        host_elapsed, host_prof, res_h = timed(step_host)
+    res_elapsed, res_prof, res_r = timed(step_resident)
+    # the two paths must agree: uint8 planes of the host path == np.uint8(255 * fp16 planes) of the resident path
+    with torch.cuda.stream(work):
+        if not sharded:
+            # the drivers' uint8 recipe (UnMicst1-5.py:848-854): np.uint8(255 * pm) with the product rounded to float16,
+            # resize at the identity grid (u8 * (1/255) in float64), np.uint8(255 * .)
+            want_u8 = None
+            if host_elapsed is not None:
+                first = (dev_out * 255.0).to(torch.uint8)
+                want_u8 = (255.0 * (first.to(torch.float64) * (1.0 / 255))).to(torch.uint8).cpu()
+            agree = None if want_u8 is None else bool(torch.equal(want_u8, host_outs[0]) and torch.equal(want_u8, host_outs[1]))
+            checksum = float(dev_out.float().mean().item())
+        else:
+            agree = None if host_elapsed is None else bool(torch.equal(res_h, res_r))
+            checksum = float(res_r.float().mean().item())
+    elapsed, prof = (host_elapsed, host_prof) if host_elapsed is not None else (res_elapsed, res_prof)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = tiles_total * args.steps / elapsed
-        # ---- roofline of the dominant kernel = the template instantiation with the largest share of the timed region (what
-        # `rocprofv3 --stats` ranks first: profiles/r01/final_*_kernel_stats.csv), from the in-library HIP events; one kernel
-        # serves several layers, so the figures are launch-weighted averages over its sites
-        convs = [p for p in prof if p["kernel"].startswith("conv_")]
-        by_kernel = {}
-        for p in convs:
-            k = by_kernel.setdefault(p["kernel"], {"ms": 0.0, "flops": 0.0, "exec": 0.0, "bytes": 0.0, "launches": 0, "layers": []})
-            k["ms"] += p["total_ms"]; k["flops"] += p["flops"]; k["exec"] += p["exec_flops"]; k["bytes"] += p["bytes"]
-            k["launches"] += p["launches"]; k["layers"].append(p["name"])
-        dom_name = max(by_kernel, key=lambda n: by_kernel[n]["ms"])
-        dom = by_kernel[dom_name]
-        dom_tflops = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        slow = max(convs, key=lambda p: p["total_ms"])          # the single most expensive layer, for the record
-        all_flops = sum(p["flops"] for p in convs)
-        all_exec = sum(p["exec_flops"] for p in convs)
-        all_ms = sum(p["total_ms"] for p in convs)
-        peak = PEAK_F16_MFMA_TFLOPS if eng.precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
-        roofline = {
-            # achieved = ALGORITHMIC fp32 FLOPs of the kernel's launches / HIP-event time of those launches; peak = dense MFMA
-            # peak of the dtype the matrix cores run (f16x3 issues 3 binary16 MFMA FLOPs per algorithmic FLOP: "mfma_issued")
-            "bound": "mfma", "achieved": round(dom_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(dom_tflops / peak, 4), "traffic": pmc_traffic(dom_name, eng.precision, args.batch),
-            "kernel": dom_name, "layers": dom["layers"], "share_of_step": round(dom["ms"] / (1e3 * elapsed), 4),
-            "avg_launch_us": round(1e3 * dom["ms"] / dom["launches"], 2),
-            "flop_per_launch": dom["flops"] / dom["launches"],
-            "mfma_issued": {"tflops": round(dom["exec"] / (dom["ms"] * 1e-3) / 1e12, 2),
-                            "frac": round(dom["exec"] / (dom["ms"] * 1e-3) / 1e12 / peak, 4)},
-            "compulsory_hbm": {"GBps": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
-                               "frac_of_8TBps": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
-            "slowest_layer": {"layer": slow["name"], "kernel": slow["kernel"],
-                              "achieved": round(slow["flops"] / (slow["total_ms"] * 1e-3) / 1e12, 2),
-                              "frac": round(slow["flops"] / (slow["total_ms"] * 1e-3) / 1e12 / peak, 4),
-                              "avg_launch_us": round(1e3 * slow["total_ms"] / slow["launches"], 2)},
-            "all_conv_launches": {"achieved": round(all_flops / (all_ms * 1e-3) / 1e12, 2),
-                                  "frac": round(all_flops / (all_ms * 1e-3) / 1e12 / peak, 4),
-                                  "mfma_issued_frac": round(all_exec / (all_ms * 1e-3) / 1e12 / peak, 4),
-                                  "share_of_step": round(all_ms / (1e3 * elapsed), 4)},
-        }
+        roofline = roofline_of(prof, elapsed, eng, args.batch)
         if args.breakdown:
-            print("%-24s %-30s %8s %10s %9s %9s" % ("layer", "kernel", "launches", "total_ms", "TFLOP/s", "GB/s"),
-                  file=sys.stderr)
-            for p in sorted(prof, key=lambda p: -p["total_ms"]):
-                s = p["total_ms"] * 1e-3
-                print("%-24s %-30s %8d %10.3f %9.2f %9.1f" % (p["name"], p["kernel"], p["launches"], p["total_ms"],
-                                                              p["flops"] / s / 1e12, p["bytes"] / s / 1e9),
-                      file=sys.stderr)
+            print_breakdown(prof)
         cpu = None
         if world == 1 and args.cpu_seconds > 0:
-            cpu = cpu_baseline(hp, blob, band, mean, std, args.cpu_seconds)
+            cpu = cpu_baseline(hp, blob, band_f64, mean, std, args.cpu_seconds)
+        up_b = C_img * H * W * 2
+        dn_b = K * H * W * (1 if not sharded else 2)
+        scope = ("H2D+D2H inside the timed region: uint16 planes up (%.0f MB), uint8 probability planes down (%.0f MB), "
+                 "per launch group on two copy streams under the tile kernels (umx_infer_image_raw_submit / _wait, two slides "
+                 "in flight; im2double on the device, no intensity rescale as in the solo driver)" % (up_b / 1e6, dn_b / 1e6)) if not sharded else (
+                 "H2D+D2H inside the timed region: each rank uploads its uint16 band and downloads its stitched fp16 band; "
+                 "band halo exchange + slab-wise RCCL all-gather of the fp16 stack on every rank")
+        if args.resident_only:
+            scope = "slide resident in HBM, result left in HBM (kernel-only; NOT the section-8(d) metric)"
         line = {
             "metric": "tiles/sec (%dx%dx%d) whole-slide inference" % (hp.imSize, hp.imSize, hp.nChannels),
             "value": round(value, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": {"f32": "f32", "f16x3": "f16x3 (fp32 products as 3 binary16 MFMA products, fp32 accumulate)"}[
                 eng.precision], "data": "synthetic",
             "config": {"workload": "%s: %s hp (%s graph, seeded weights), %d-channel synthetic slide %dx%d, "
-                                   "%d tiles/step, batch %d, fp16-compat stitch%s" % (
+                                   "%d tiles/step, batch %d, fp16-compat stitch; %s" % (
                                        args.workload, key, "v2" if hp.graph else "legacy", C_img, H, W, tiles_total,
-                                       args.batch, ", band halo exchange + slab-wise RCCL all-gather" if sharded else ""),
+                                       args.batch, scope),
                        "tiles_per_step": tiles_total, "slide": [H, W], "flop_per_tile_as_written": hp.flops_per_tile(),
-                       "flop_per_tile_executed_unpadded": umx.describe(hp)["flops_per_tile"], "checksum": checksum},
+                       "flop_per_tile_executed_unpadded": umx.describe(hp)["flops_per_tile"], "checksum": checksum,
+                       "host_path_equals_resident_path": agree},
+            "resident": {"value": round(tiles_total * args.steps / res_elapsed, 2), "unit": "tiles/s",
+                         "ms_per_step": round(1e3 * res_elapsed / args.steps, 3),
+                         "note": "same slide already in HBM as float64, result left in HBM (no H2D / D2H): kernel-only"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
@@ -322,32 +453,71 @@ def cpu_baseline_train(hp, blob, data, labels, weights, budget_s):
                       "optimiser update), %.1f s" % (n, dt)}
 
 
-def cpu_baseline(hp, blob, band, mean, std, budget_s):
-    """The oracle (C restatement, OpenMP on every host core) on a bounded sample of the same workload's tiles."""
+def cpu_baseline(hp, blob, band_f64, mean, std, budget_s):
+    """The reference's CPU path restated (TensorFlow is not installable here: SURVEY.md section 8c), timed on the host
+    cores of the GPU box on a bounded sample of the same slide.  Two figures:
+      value / best_effort   the UNet as torch-CPU float32 on every host core (oracle/train_oracle.py's restatement of the
+                            v2 graph; the C oracle for the legacy graph), tiles batched at the hp's batch size, ONE pass
+                            that yields all classes, PI2D gather + normalise in numpy;
+      reference_faithful    the reference's own loop shape: the Python PI2D tile loop with per-tile patchOutput, run once
+                            PER CLASS (UnMicst1-5.py:697-707,845-848) on the same torch-CPU forward -- a "tile" still
+                            counts once, so this is ~nClasses x slower by construction."""
+    import numpy as np
+    import torch
     from oracle import oracle, pi2d_oracle
     P, m = hp.imSize, hp.margin
     sub = P - 2 * m
-    rows = min(band.shape[1], 2 * sub + 2 * m)
-    cols = min(band.shape[2], 8 * sub + 2 * m)
-    crop = band[:, :rows, :cols].cpu().numpy()
+    B = max(1, int(getattr(hp, "batchSize", 0) or 8))
+    if hp.graph:
+        from oracle import train_oracle as to
+        T = to.split_blob(hp, np.asarray(blob, dtype=np.float64))
+        Pm = {k: torch.tensor(v, dtype=torch.float32) for k, v in T.items()}
+        opts = to.TrainOptions()
+
+        def forward(x):
+            with torch.no_grad():
+                return to.forward(hp, Pm, torch.from_numpy(np.ascontiguousarray(x)), opts, 0, training=False)[0].numpy()
+        cores, what = torch.get_num_threads(), "torch CPU float32 (oracle/train_oracle.py)"
+    else:
+        def forward(x):
+            return oracle.forward(hp, blob, x)
+        cores, what = oracle.num_threads(), "oracle/unet_oracle.c (OpenMP, double accumulate)"
+    rows = min(band_f64.shape[1], 2 * sub + 2 * m)
+    cols = min(band_f64.shape[2], 8 * sub + 2 * m)
+    crop = band_f64[:, :rows, :cols].cpu().numpy()
     if hp.nChannels == 1:
         crop = crop[0]
     pi = pi2d_oracle.PI2DOracle(crop, P, m, "accumulate")
-    x1 = pi2d_oracle.normalised_batch(pi, 0, 1, hp.nChannels, mean, std, False)
+    forward(pi2d_oracle.normalised_batch(pi, 0, 1, hp.nChannels, mean, std, False))          # untimed: thread pool, caches
     t = time.perf_counter()
-    oracle.forward(hp, blob, x1)
-    per_tile = max(time.perf_counter() - t, 1e-4)
-    n = int(max(1, min(pi.num_patches, budget_s / per_tile)))
+    forward(pi2d_oracle.normalised_batch(pi, 0, min(B, pi.num_patches), hp.nChannels, mean, std, False))
+    per_tile = max((time.perf_counter() - t) / min(B, pi.num_patches), 1e-4)
+    # ---- best effort: one batched pass, all classes
+    n = int(max(1, min(pi.num_patches, 0.5 * budget_s / per_tile)))
     t = time.perf_counter()
     done = 0
     while done < n:
-        nb = min(4, n - done)
-        oracle.forward(hp, blob, pi2d_oracle.normalised_batch(pi, done, nb, hp.nChannels, mean, std, False))
+        nb = min(B, n - done)
+        forward(pi2d_oracle.normalised_batch(pi, done, nb, hp.nChannels, mean, std, False))
         done += nb
     dt = time.perf_counter() - t
-    return {"value": round(n / dt, 3), "unit": "tiles/s", "cores": oracle.num_threads(), "kind": "port",
-            "sample": "first %d tiles of the same slide (PI2D gather+normalise + UNet forward, oracle/unet_oracle.c, "
-                      "double-accumulate fp32, OpenMP), %.1f s" % (n, dt)}
+    # ---- reference-faithful: the whole loop once per class on a crop of nf tiles
+    nf = int(max(1, min(pi.num_patches, 0.5 * budget_s / per_tile / hp.nClasses)))
+    fr = max(1, min(2, nf // max(1, min(8, nf))))                # patch rows of the crop
+    fc = max(1, min(nf // fr, 8))
+    crop2 = crop[..., :fr * sub + 2 * m, :fc * sub + 2 * m]
+    t = time.perf_counter()
+    for k in range(hp.nClasses):
+        pi2d_oracle.single_image_inference(crop2, forward, P, hp.nChannels, mean, std, "accumulate", k, B)
+    dtf = time.perf_counter() - t
+    nft = pi2d_oracle.PI2DOracle(crop2, P, m, "accumulate").num_patches
+    return {"value": round(n / dt, 3), "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": "best effort: first %d tiles of the same slide, batch %d, one pass for all classes (PI2D gather + "
+                      "normalise in numpy, UNet forward %s), %.1f s" % (n, B, what, dt),
+            "reference_faithful": {"value": round(nft / dtf, 3), "unit": "tiles/s", "cores": cores,
+                                   "sample": "the reference's loop on a %d-tile crop: Python PI2D tile loop with float16 "
+                                             "patchOutput, one full pass per class (%d passes), same forward, %.1f s" % (
+                                                 nft, hp.nClasses, dtf)}}
 
 
 if __name__ == "__main__":

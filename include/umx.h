@@ -141,6 +141,17 @@ UMX_API int umx_infer_image_dev(umx_ctx* ctx, const double* image_dev, int C_img
 UMX_API int umx_infer_image_raw(umx_ctx* ctx, const void* raw_host, int bits, int C_img, int H, int W, int rescale,
                         double mean, double std, int mode, uint8_t* out_host);
 
+/* How the host entry points move data: the slide goes up and the planes come down in the launch groups of the tile loop,
+ * on two copy streams, under the tile kernels of the neighbouring groups (pinned host buffers make these true DMA; pageable
+ * ones are staged by HIP and still correct).  A stream of slides -- the drivers' per-file loop, reference
+ * UnMicst1-5.py:781-876 run once per file by MCMICRO -- can keep two calls in flight: umx_infer_image_raw_submit enqueues
+ * one slide on `slot` (0 or 1; each slot owns its device buffers) and returns at once; umx_infer_image_wait blocks until
+ * that slot's planes are in out_host and reports its errors (UMX_ERR_RANGE included).  raw_host / out_host must stay
+ * valid until the wait.  umx_infer_image_raw == submit on slot 0 + wait. */
+UMX_API int umx_infer_image_raw_submit(umx_ctx* ctx, int slot, const void* raw_host, int bits, int C_img, int H, int W,
+                                       int rescale, double mean, double std, int mode, uint8_t* out_host);
+UMX_API int umx_infer_image_wait(umx_ctx* ctx, int slot);
+
 /* The two halves of umx_infer_image, exposed for band sharding across GPUs (one process per GPU):
  * umx_band_tiles_dev: PI2D.getPatch + normalise + UNet for patch rows [pr0,pr1) -> probs
  *   [(pr1-pr0)*patch_cols, P,P,K] float32.  image_dev holds image rows [band_row0, band_row0+band_rows) of the

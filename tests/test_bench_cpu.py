@@ -1,0 +1,33 @@
+"""bench.py's launch logic on CPU: `--gpus N` outside torch.distributed.run starts the N ranks as a child process tree
+(before anything touches a GPU) and relays their output and exit code."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_gpus_2_launches_two_ranks():
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--master-port", "29633"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("bench.py dry launch")]
+    assert sorted(lines) == ["bench.py dry launch: rank 0 of 2 (local rank 0)", "bench.py dry launch: rank 1 of 2 (local rank 1)"]
+
+
+def test_bench_rejects_a_world_that_does_not_match_gpus():
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr
+
+
+def test_bench_strong_and_weak_slide_sizes():
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse_args(["--gpus", "4", "--scaling", "strong"])
+    assert a.scaling == "strong" and a.gpus == 4
+    assert bench.WORKLOADS["solo-16384"][0] == "nucleiDAPI1-5"

@@ -182,17 +182,68 @@ hp = helpers.small_hps()["v2_duo_like"]
 blob = model.random_blob(hp, seed=4)
 img = np.random.default_rng(2).random((2, 150, 61)) * 0.5
 with umx.Engine(hp, blob, max_batch=8) as eng:
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
     want = eng.infer_image(img, 0.2, 0.2)
-    band = torch.from_numpy(img).cuda()
-    got = sharding.infer_image_sharded(eng, band, 0, 150, 61, 0.2, 0.2, umx.MODE_ACCUMULATE, umx.STITCH_FP16_COMPAT)
+    work = torch.cuda.Stream()
+    eng.set_stream(work.cuda_stream)
+    with torch.cuda.stream(work):
+        band = torch.from_numpy(img).cuda()
+        got = sharding.infer_image_sharded(eng, band, 0, 150, 61, 0.2, 0.2, umx.MODE_ACCUMULATE, umx.STITCH_FP16_COMPAT)
     torch.cuda.synchronize()
     assert np.array_equal(got.cpu().numpy().view(np.uint16), want.view(np.uint16))
+    try:
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)   # the legacy default stream (handle 0) is refused
+        raise SystemExit("set_stream(0) was accepted")
+    except ValueError:
+        pass
 dist.destroy_process_group()
 print("sharded ok")
 ''' % (helpers.ROOT, helpers.ROOT)
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "sharded ok" in r.stdout, r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_two_and_three_ranks_share_one_gpu(world, tmp_path):
+    """The N>1 path with the REAL engine: `world` processes, all on cuda:0 (RCCL refuses two ranks on one device, so the
+    messages travel over gloo through host memory -- sharding._staged), each holding only its band of the image on the
+    device; every rank's gathered result must equal the single-process umx_infer_image bit for bit."""
+    import subprocess
+    import sys
+    script = tmp_path / "worker.py"
+    script.write_text(r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import helpers
+from unmicst_amd import model, sharding, umx
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+hp = helpers.small_hps()["v2_duo_like"]
+blob = model.random_blob(hp, seed=4)
+H, W = 233, 97
+img = np.random.default_rng(2).random((2, H, W)) * 0.5
+with umx.Engine(hp, blob, max_batch=8) as eng:
+    want = eng.infer_image(img, 0.2, 0.2)
+    npr, npc, _, _ = eng.tile_grid(H, W)
+    m = hp.margin; sub = hp.imSize - 2 * m
+    pa, pb = sharding.band_partition(npr, world)[rank]
+    r0, r1 = sharding.needed_image_rows(pa, pb, sub, m, hp.imSize, H)
+    work = torch.cuda.Stream()
+    eng.set_stream(work.cuda_stream)
+    with torch.cuda.stream(work):
+        band = torch.from_numpy(np.ascontiguousarray(img[:, r0:max(r1, r0 + 1)])).cuda()   # only this rank's rows
+        got = sharding.infer_image_sharded(eng, band, r0, H, W, 0.2, 0.2, umx.MODE_ACCUMULATE, umx.STITCH_FP16_COMPAT,
+                                           nslabs=2)
+    torch.cuda.synchronize()
+    same = np.array_equal(got.cpu().numpy().view(np.uint16), want.view(np.uint16))
+    print("rank %%d of %%d: bands %%s equal=%%s" %% (rank, world, (pa, pb), same), flush=True)
+    assert same
+dist.destroy_process_group()
+''' % (helpers.ROOT, helpers.ROOT))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(29590 + world), str(script)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.count("equal=True") == world, (r.stdout[-2000:], r.stderr[-3000:])
 
 
 @pytest.mark.parametrize("prec", PRECS)

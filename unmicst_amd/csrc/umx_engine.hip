@@ -110,6 +110,17 @@ struct umx_ctx {
     float* d_tiles32_2 = nullptr;
     int nlanes = 1, lane = 0;
     int ncu = 256;
+    // host entry points: uploads / downloads on their own streams, slab by slab, under the tile kernels
+    hipStream_t up_stream = nullptr, dn_stream = nullptr;
+    struct HostSlot {   // device buffers + events of one in-flight host call (two slots: slide i+1 uploads while slide i computes)
+        double* d_image = nullptr;  size_t image_cap = 0;
+        float* d_probs = nullptr;   size_t probs_cap = 0;
+        void* d_out = nullptr;      size_t out_cap = 0;
+        std::vector<hipEvent_t> events;
+        hipEvent_t done = nullptr;
+        int* flag_host = nullptr;   // pinned copy of the range flag, read back behind the slot's last download
+        bool busy = false;
+    } hs[2];
     std::vector<void*> allocs;
     std::string err;
     // whole-image scratch (grown on demand)
@@ -1462,6 +1473,16 @@ void umx_destroy(umx_ctx* ctx) {
     if (ctx->d_out) hipFree(ctx->d_out);
     if (ctx->d_io_tiles) hipFree(ctx->d_io_tiles);
     if (ctx->d_io_probs) hipFree(ctx->d_io_probs);
+    if (ctx->up_stream) { hipStreamSynchronize(ctx->up_stream); hipStreamDestroy(ctx->up_stream); }
+    if (ctx->dn_stream) { hipStreamSynchronize(ctx->dn_stream); hipStreamDestroy(ctx->dn_stream); }
+    for (auto& h : ctx->hs) {
+        for (auto e : h.events) hipEventDestroy(e);
+        if (h.done) hipEventDestroy(h.done);
+        if (h.flag_host) hipHostFree(h.flag_host);
+        if (h.d_image) hipFree(h.d_image);
+        if (h.d_probs) hipFree(h.d_probs);
+        if (h.d_out) hipFree(h.d_out);
+    }
     if (ctx->stream2) { hipStreamSynchronize(ctx->stream2); hipStreamDestroy(ctx->stream2); }
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
@@ -1525,23 +1546,10 @@ int umx_tile_grid(const umx_ctx* ctx, int H, int W, int* patch_rows, int* patch_
     return UMX_OK;
 }
 
-int umx_band_tiles_dev(umx_ctx* ctx, const double* image_dev, int C_img, int H, int W, int band_row0, int band_rows,
-                       double mean, double stdv, int pr0, int pr1, float* probs_dev) {
-    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
-    if (!image_dev || !probs_dev || H < 1 || W < 1) return fail(ctx, UMX_ERR_INVALID, "bad image/probs/H/W");
-    if (C_img != 1 && C_img != ctx->hp.nChannels)
-        return fail(ctx, UMX_ERR_INVALID, "image has %d channels, model wants 1 or %d", C_img, ctx->hp.nChannels);
-    if (!(stdv != 0.0)) return fail(ctx, UMX_ERR_INVALID, "std must be non-zero");
-    const TileGeom g = geom_of(ctx->hp, H, W);
-    if (pr0 < 0 || pr1 > g.npr || pr0 > pr1) return fail(ctx, UMX_ERR_INVALID, "patch rows [%d,%d) outside [0,%d)", pr0, pr1, g.npr);
-    if (pr0 == pr1) return UMX_OK;
-    // image rows the patch rows touch: [pr0*sub - m, (pr1-1)*sub + P - m) clipped to the image
-    const int need0 = std::max(0, pr0 * g.sub - g.margin), need1 = std::min(H, (pr1 - 1) * g.sub + g.P - g.margin);
-    if (band_row0 < 0 || band_rows < 0 || (need1 > need0 && (band_row0 > need0 || band_row0 + band_rows < need1)))
-        return fail(ctx, UMX_ERR_INVALID, "band rows [%d,%d) do not cover the rows [%d,%d) the patch rows need",
-                    band_row0, band_row0 + band_rows, need0, need1);
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int t0 = pr0 * g.npc, t1 = pr1 * g.npc;
+// tiles [t0, t1) of the slide (row-major tile index) -> probs_dev (tile t0 first): gather + normalise + UNet, in launch
+// groups of <= max_batch tiles
+static int tiles_range(umx_ctx* ctx, const double* image_dev, int C_img, const TileGeom& g, int band_row0, int band_rows,
+                       double mean, double stdv, int t0, int t1, float* probs_dev) {
     const size_t prob_f = (size_t)g.P * g.P * ctx->hp.nClasses;
     if (ctx->site_gather < 0) ctx->site_gather = site_of(ctx, "pi2d.gather_normalise", "gather_normalise");
     const bool direct16 = ctx->precision == UMX_PREC_F16X3 && ctx->hp.nChannels <= 8 && ctx->bufs[0].Cs == 8;
@@ -1566,6 +1574,25 @@ int umx_band_tiles_dev(umx_ctx* ctx, const double* image_dev, int C_img, int H, 
         if (rc) return rc;
     }
     return ll.join();
+}
+
+int umx_band_tiles_dev(umx_ctx* ctx, const double* image_dev, int C_img, int H, int W, int band_row0, int band_rows,
+                       double mean, double stdv, int pr0, int pr1, float* probs_dev) {
+    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    if (!image_dev || !probs_dev || H < 1 || W < 1) return fail(ctx, UMX_ERR_INVALID, "bad image/probs/H/W");
+    if (C_img != 1 && C_img != ctx->hp.nChannels)
+        return fail(ctx, UMX_ERR_INVALID, "image has %d channels, model wants 1 or %d", C_img, ctx->hp.nChannels);
+    if (!(stdv != 0.0)) return fail(ctx, UMX_ERR_INVALID, "std must be non-zero");
+    const TileGeom g = geom_of(ctx->hp, H, W);
+    if (pr0 < 0 || pr1 > g.npr || pr0 > pr1) return fail(ctx, UMX_ERR_INVALID, "patch rows [%d,%d) outside [0,%d)", pr0, pr1, g.npr);
+    if (pr0 == pr1) return UMX_OK;
+    // image rows the patch rows touch: [pr0*sub - m, (pr1-1)*sub + P - m) clipped to the image
+    const int need0 = std::max(0, pr0 * g.sub - g.margin), need1 = std::min(H, (pr1 - 1) * g.sub + g.P - g.margin);
+    if (band_row0 < 0 || band_rows < 0 || (need1 > need0 && (band_row0 > need0 || band_row0 + band_rows < need1)))
+        return fail(ctx, UMX_ERR_INVALID, "band rows [%d,%d) do not cover the rows [%d,%d) the patch rows need",
+                    band_row0, band_row0 + band_rows, need0, need1);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return tiles_range(ctx, image_dev, C_img, g, band_row0, band_rows, mean, stdv, pr0 * g.npc, pr1 * g.npc, probs_dev);
 }
 
 int umx_stitch_dev(umx_ctx* ctx, const float* probs_dev, int tpr0, int tpr1, int H, int W, int mode, int stitch, int y0,
@@ -1606,21 +1633,178 @@ int umx_infer_image_dev(umx_ctx* ctx, const double* image_dev, int C_img, int H,
     return umx_stitch_dev(ctx, ctx->d_probs, 0, g.npr, H, W, mode, stitch, 0, H, out_dev);
 }
 
+// ---- host entry points.  The reference hands host arrays across its seam (UnMicst1-5.py:687-710); here the slide goes up
+// and the probability stack comes down in row slabs on two copy streams while the tile kernels of the neighbouring slabs
+// run: slab s = patch rows [cut[s], cut[s+1]); its upload covers the image rows its tiles read that are not on the device
+// yet, its download the image rows no later patch row touches.  With pinned host buffers the transfers are true DMA and
+// all but the first upload and the last download ride under compute; with pageable buffers HIP stages them (still correct).
+// src_bits: 0 = float64 planes (what singleImageInference receives), 8 / 16 = raw integer planes (the driver's file
+// contents; im2double and, with `rescale`, rescale_intensity run on the device).  out_u8: the driver's uint8 planes
+// instead of the stitch result.  A rescale needs the plane's (min, max) before the first tile: the upload then runs
+// ahead of compute (min/max reduced slab by slab as the rows arrive) and only the download is hidden.
+static int host_wait(umx_ctx* ctx, int slot) {
+    if (slot < 0 || slot > 1) return fail(ctx, UMX_ERR_INVALID, "slot must be 0 or 1");
+    umx_ctx::HostSlot& hs = ctx->hs[slot];
+    if (!hs.busy) return UMX_OK;
+    hs.busy = false;
+    HIP_TRY(ctx, hipEventSynchronize(hs.done));
+    if (*hs.flag_host) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return check_range_flag(ctx);
+    }
+    return UMX_OK;
+}
+
+static int host_submit(umx_ctx* ctx, int slot, const void* src, int src_bits, int C_img, int H, int W, int rescale, double mean,
+                       double stdv, int mode, int stitch, int out_u8, void* out_host) {
+    if (slot < 0 || slot > 1) return fail(ctx, UMX_ERR_INVALID, "slot must be 0 or 1");
+    umx_ctx::HostSlot& hs = ctx->hs[slot];
+    if (hs.busy) return fail(ctx, UMX_ERR_INVALID, "slot %d still holds a submitted call: wait for it first", slot);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!hs.done) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&hs.done, hipEventDisableTiming));
+        HIP_TRY(ctx, hipHostMalloc((void**)&hs.flag_host, 64, hipHostMallocDefault));
+    }
+    const TileGeom g = geom_of(ctx->hp, H, W);
+    const size_t plane = (size_t)H * W, K = ctx->hp.nClasses;
+    const size_t in_b = src_bits ? (size_t)(src_bits / 8) : sizeof(double);
+    const size_t oel = stitch == UMX_STITCH_FP32 ? 4 : 2;
+    const size_t pm_b = K * plane * oel, u8_b = out_u8 ? K * plane : 0;
+    const size_t raw_off = (pm_b + u8_b + 255) & ~(size_t)255;
+    const size_t raw_b = src_bits ? plane * C_img * in_b : 0;
+    const size_t mm_off = (raw_off + raw_b + 255) & ~(size_t)255;
+    int rc;
+    if ((rc = grow(ctx, (void**)&hs.d_image, &hs.image_cap, plane * C_img * sizeof(double)))) return rc;
+    if ((rc = grow(ctx, &hs.d_out, &hs.out_cap, mm_off + 64 * (size_t)C_img))) return rc;
+    if ((rc = grow(ctx, (void**)&hs.d_probs, &hs.probs_cap, (size_t)g.npr * g.npc * g.P * g.P * K * sizeof(float)))) return rc;
+    unsigned char* const base = (unsigned char*)hs.d_out;
+    if (!ctx->up_stream) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->dn_stream, hipStreamNonBlocking));
+    }
+    // slabs = the launch groups of the tile loop (equal groups of <= max_batch tiles, exactly what umx_infer_image_dev
+    // runs), so that pipelining the transfers does not change a single kernel launch; UMX_HOST_SLABS=1: no overlap
+    const int T = g.npr * g.npc;
+    int S = std::max(1, (T + ctx->max_batch - 1) / ctx->max_batch);
+    if (const char* e = getenv("UMX_HOST_SLABS")) S = std::max(1, std::min(atoi(e), S));
+    while ((int)hs.events.size() < 2 * S + 1) {
+        hipEvent_t ev;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hs.events.push_back(ev);
+    }
+    hipEvent_t* const ev_up = hs.events.data();
+    hipEvent_t* const ev_dn = hs.events.data() + S;
+    hipEvent_t ev_start = hs.events[2 * S];
+    (void)ev_start;   // (a slot's buffers are private to it and free again once host_wait has returned: no extra ordering)
+    std::vector<int> tcut(S + 1), cut(S + 1);   // tile cuts; cut[i] = patch rows COMPLETE after slab i-1 (cut[S] = npr)
+    for (int i = 0; i <= S; ++i) {
+        tcut[i] = (int)((long long)T * i / S);
+        cut[i] = tcut[i] / g.npc;
+    }
+    auto rows_needed = [&](int pr1) { return std::min(H, (pr1 - 1) * g.sub + g.P - g.margin); };
+    unsigned* const mm = (unsigned*)(base + mm_off);
+    unsigned char* const d_raw = base + raw_off;
+    auto upload = [&](int r0, int r1) -> int {   // image rows [r0, r1) of every plane
+        for (int c = 0; c < C_img && r1 > r0; ++c) {
+            const size_t off = ((size_t)c * H + r0) * W * in_b, n = (size_t)(r1 - r0) * W * in_b;
+            void* const dst = src_bits ? (void*)(d_raw + off) : (void*)((unsigned char*)hs.d_image + off);
+            HIP_TRY(ctx, hipMemcpyAsync(dst, (const unsigned char*)src + off, n, hipMemcpyHostToDevice, ctx->up_stream));
+        }
+        return UMX_OK;
+    };
+    auto convert = [&](int r0, int r1) -> int {   // raw rows -> float64 rows (im2double [+ rescale])
+        for (int c = 0; c < C_img && src_bits && r1 > r0; ++c) {
+            const size_t e0 = ((size_t)c * H + r0) * W;
+            HIP_TRY(ctx, launch_raw_convert(d_raw + e0 * in_b, src_bits, (size_t)(r1 - r0) * W, rescale, mm + 16 * c,
+                                            hs.d_image + e0, ctx->stream));
+        }
+        return UMX_OK;
+    };
+    int up_done = 0;
+    if (src_bits) {
+        for (int c = 0; c < C_img; ++c) HIP_TRY(ctx, launch_minmax_init(mm + 16 * c, ctx->stream));
+        if (rescale) {   // whole planes first: min / max per plane, reduced as the slabs arrive
+            for (int s = 0; s < S; ++s) {
+                const int r1 = s == S - 1 ? H : rows_needed((tcut[s + 1] - 1) / g.npc + 1);
+                if (r1 <= up_done) continue;
+                if ((rc = upload(up_done, r1))) return rc;
+                HIP_TRY(ctx, hipEventRecord(ev_up[s], ctx->up_stream));
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ev_up[s], 0));
+                for (int c = 0; c < C_img && r1 > up_done; ++c)
+                    HIP_TRY(ctx, launch_minmax(d_raw + ((size_t)c * H + up_done) * W * in_b, src_bits, (size_t)(r1 - up_done) * W,
+                                               mm + 16 * c, ctx->stream));
+                up_done = r1;
+            }
+            if ((rc = convert(0, H))) return rc;
+        }
+    }
+    int y_done = 0;
+    for (int s = 0; s < S; ++s) {
+        // rows the tiles of this slab read: up to the last patch row it touches
+        const int r1 = s == S - 1 ? H : rows_needed((tcut[s + 1] - 1) / g.npc + 1);
+        if (r1 > up_done) {
+            if ((rc = upload(up_done, r1))) return rc;
+            HIP_TRY(ctx, hipEventRecord(ev_up[s], ctx->up_stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ev_up[s], 0));
+            if ((rc = convert(up_done, r1))) return rc;
+            up_done = r1;
+        }
+        if (tcut[s + 1] > tcut[s]) {
+            float* const pr = hs.d_probs + (size_t)tcut[s] * g.P * g.P * K;
+            if ((rc = tiles_range(ctx, hs.d_image, C_img, g, 0, H, mean, stdv, tcut[s], tcut[s + 1], pr))) return rc;
+        }
+        // image rows no later tile touches: below the first incomplete patch row
+        const int y1 = s == S - 1 ? H : std::max(y_done, std::min(H, cut[s + 1] * g.sub - g.margin));
+        if (y1 > y_done && cut[s + 1] > 0) {
+            // the stitch writes a compact slab [K][rows][W]; slabs sit one after the other in the device buffer
+            const size_t rows = (size_t)(y1 - y_done), slab_e = K * (size_t)y_done * W;
+            unsigned char* const d_slab = base + slab_e * oel;
+            if ((rc = umx_stitch_dev(ctx, hs.d_probs, 0, cut[s + 1], H, W, mode, stitch, y_done, y1, d_slab))) return rc;
+            if (out_u8) HIP_TRY(ctx, launch_half_to_u8(d_slab, K * rows * W, base + pm_b + slab_e, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ev_dn[s], ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->dn_stream, ev_dn[s], 0));
+            const size_t el = out_u8 ? 1 : oel;
+            const unsigned char* const dsrc = out_u8 ? base + pm_b + slab_e : d_slab;
+            for (size_t k = 0; k < K; ++k)
+                HIP_TRY(ctx, hipMemcpyAsync((unsigned char*)out_host + (k * plane + (size_t)y_done * W) * el,
+                                            dsrc + k * rows * W * el, rows * W * el, hipMemcpyDeviceToHost, ctx->dn_stream));
+            y_done = y1;
+        }
+    }
+    // the range flag of the split-precision path rides down behind the last planes; `done` then says the call is complete
+    // (every upload precedes a kernel that precedes a download on the download stream)
+    if (ctx->d_flag) {
+        hipEvent_t ev_f = hs.events[2 * S];
+        HIP_TRY(ctx, hipEventRecord(ev_f, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->dn_stream, ev_f, 0));
+        HIP_TRY(ctx, hipMemcpyAsync(hs.flag_host, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->dn_stream));
+    } else {
+        *hs.flag_host = 0;
+    }
+    HIP_TRY(ctx, hipEventRecord(hs.done, ctx->dn_stream));
+    hs.busy = true;
+    return UMX_OK;
+}
+
+static int infer_host(umx_ctx* ctx, const void* src, int src_bits, int C_img, int H, int W, int rescale, double mean,
+                      double stdv, int mode, int stitch, int out_u8, void* out_host) {
+    int rc = host_submit(ctx, 0, src, src_bits, C_img, H, W, rescale, mean, stdv, mode, stitch, out_u8, out_host);
+    if (rc) return rc;
+    return host_wait(ctx, 0);
+}
+
+
+
 int umx_infer_image(umx_ctx* ctx, const double* image_host, int C_img, int H, int W, double mean, double stdv, int mode,
                     int stitch, void* out_host) {
     if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
     if (!image_host || !out_host || H < 1 || W < 1 || C_img < 1) return fail(ctx, UMX_ERR_INVALID, "bad image/out/H/W");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t img_b = (size_t)C_img * H * W * sizeof(double);
-    const size_t out_b = (size_t)ctx->hp.nClasses * H * W * (stitch == UMX_STITCH_FP32 ? 4 : 2);
-    int rc;
-    if ((rc = grow(ctx, (void**)&ctx->d_image, &ctx->image_cap, img_b))) return rc;
-    if ((rc = grow(ctx, &ctx->d_out, &ctx->out_cap, out_b))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_image, image_host, img_b, hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = umx_infer_image_dev(ctx, ctx->d_image, C_img, H, W, mean, stdv, mode, stitch, ctx->d_out))) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(out_host, ctx->d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return check_range_flag(ctx);
+    if (C_img != 1 && C_img != ctx->hp.nChannels)
+        return fail(ctx, UMX_ERR_INVALID, "image has %d channels, model wants 1 or %d", C_img, ctx->hp.nChannels);
+    if (!(stdv != 0.0)) return fail(ctx, UMX_ERR_INVALID, "std must be non-zero");
+    if (mode != UMX_MODE_ACCUMULATE && mode != UMX_MODE_REPLACE) return fail(ctx, UMX_ERR_INVALID, "bad mode %d", mode);
+    if (stitch != UMX_STITCH_FP16_COMPAT && stitch != UMX_STITCH_FP32) return fail(ctx, UMX_ERR_INVALID, "bad stitch %d", stitch);
+    return infer_host(ctx, image_host, 0, C_img, H, W, 0, mean, stdv, mode, stitch, 0, out_host);
 }
 
 int umx_infer_image_raw(umx_ctx* ctx, const void* raw_host, int bits, int C_img, int H, int W, int rescale, double mean,
@@ -1628,26 +1812,28 @@ int umx_infer_image_raw(umx_ctx* ctx, const void* raw_host, int bits, int C_img,
     if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
     if (!raw_host || !out_host || H < 1 || W < 1 || C_img < 1) return fail(ctx, UMX_ERR_INVALID, "bad image/out/H/W");
     if (bits != 8 && bits != 16) return fail(ctx, UMX_ERR_INVALID, "raw planes must be uint8 or uint16 (bits = %d)", bits);
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t plane = (size_t)H * W, npx = plane * C_img;
-    const size_t raw_b = npx * (bits / 8), img_b = npx * sizeof(double);
-    const size_t K = ctx->hp.nClasses, pm_b = K * plane * 2, u8_b = K * plane;
-    int rc;
-    if ((rc = grow(ctx, (void**)&ctx->d_image, &ctx->image_cap, img_b))) return rc;
-    // one scratch buffer: [fp16 planes | uint8 planes | raw upload | min/max words]
-    const size_t raw_off = (pm_b + u8_b + 255) & ~(size_t)255, mm_off = (raw_off + raw_b + 255) & ~(size_t)255;
-    if ((rc = grow(ctx, &ctx->d_out, &ctx->out_cap, mm_off + 64 * (size_t)C_img))) return rc;
-    unsigned char* const base = (unsigned char*)ctx->d_out;
-    HIP_TRY(ctx, hipMemcpyAsync(base + raw_off, raw_host, raw_b, hipMemcpyHostToDevice, ctx->stream));
-    for (int c = 0; c < C_img; ++c)   // min/max and rescale are per plane (the drivers loop over channels)
-        HIP_TRY(ctx, launch_raw_to_double(base + raw_off + (size_t)c * plane * (bits / 8), bits, plane, rescale,
-                                          (unsigned*)(base + mm_off + 64 * (size_t)c), ctx->d_image + (size_t)c * plane,
-                                          ctx->stream));
-    if ((rc = umx_infer_image_dev(ctx, ctx->d_image, C_img, H, W, mean, stdv, mode, UMX_STITCH_FP16_COMPAT, base))) return rc;
-    HIP_TRY(ctx, launch_half_to_u8(base, K * plane, base + pm_b, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(out_host, base + pm_b, u8_b, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return check_range_flag(ctx);
+    if (C_img != 1 && C_img != ctx->hp.nChannels)
+        return fail(ctx, UMX_ERR_INVALID, "image has %d channels, model wants 1 or %d", C_img, ctx->hp.nChannels);
+    if (!(stdv != 0.0)) return fail(ctx, UMX_ERR_INVALID, "std must be non-zero");
+    if (mode != UMX_MODE_ACCUMULATE && mode != UMX_MODE_REPLACE) return fail(ctx, UMX_ERR_INVALID, "bad mode %d", mode);
+    return infer_host(ctx, raw_host, bits, C_img, H, W, rescale, mean, stdv, mode, UMX_STITCH_FP16_COMPAT, 1, out_host);
+}
+
+int umx_infer_image_raw_submit(umx_ctx* ctx, int slot, const void* raw_host, int bits, int C_img, int H, int W, int rescale,
+                               double mean, double stdv, int mode, uint8_t* out_host) {
+    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    if (!raw_host || !out_host || H < 1 || W < 1 || C_img < 1) return fail(ctx, UMX_ERR_INVALID, "bad image/out/H/W");
+    if (bits != 8 && bits != 16) return fail(ctx, UMX_ERR_INVALID, "raw planes must be uint8 or uint16 (bits = %d)", bits);
+    if (C_img != 1 && C_img != ctx->hp.nChannels)
+        return fail(ctx, UMX_ERR_INVALID, "image has %d channels, model wants 1 or %d", C_img, ctx->hp.nChannels);
+    if (!(stdv != 0.0)) return fail(ctx, UMX_ERR_INVALID, "std must be non-zero");
+    if (mode != UMX_MODE_ACCUMULATE && mode != UMX_MODE_REPLACE) return fail(ctx, UMX_ERR_INVALID, "bad mode %d", mode);
+    return host_submit(ctx, slot, raw_host, bits, C_img, H, W, rescale, mean, stdv, mode, UMX_STITCH_FP16_COMPAT, 1, out_host);
+}
+
+int umx_infer_image_wait(umx_ctx* ctx, int slot) {
+    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    return host_wait(ctx, slot);
 }
 
 int umx_profile_enable(umx_ctx* ctx, int on) {

@@ -175,6 +175,10 @@ hipError_t launch_stitch(const float* probs, int tpr0, int tpr1, const TileGeom&
 // driver-side pre/post-processing at scalingFactor 1 (raw integer planes in, uint8 probability planes out)
 hipError_t launch_raw_to_double(const void* raw, int bits, size_t n, int rescale, unsigned* mm /*2 words*/, double* out,
                                 hipStream_t stream);
+hipError_t launch_minmax_init(unsigned* mm, hipStream_t stream);
+hipError_t launch_minmax(const void* raw, int bits, size_t n, unsigned* mm, hipStream_t stream);
+hipError_t launch_raw_convert(const void* raw, int bits, size_t n, int rescale, const unsigned* mm, double* out,
+                              hipStream_t stream);
 hipError_t launch_half_to_u8(const void* pm_half, size_t n, unsigned char* out, hipStream_t stream);
 
 

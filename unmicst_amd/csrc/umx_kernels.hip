@@ -595,24 +595,46 @@ __global__ void __launch_bounds__(256) half_to_u8_kernel(const __half* __restric
     }
 }
 
-hipError_t launch_raw_to_double(const void* raw, int bits, size_t n, int rescale, unsigned* mm, double* out, hipStream_t stream) {
+hipError_t launch_minmax_init(unsigned* mm, hipStream_t stream) {
+    const unsigned init[2] = {0xFFFFFFFFu, 0u};
+    return hipMemcpyAsync(mm, init, sizeof init, hipMemcpyHostToDevice, stream);
+}
+
+// mm = (min(mm[0], min x), max(mm[1], max x)): accumulates, so that a plane can be reduced slab by slab as it is uploaded
+hipError_t launch_minmax(const void* raw, int bits, size_t n, unsigned* mm, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
-    const unsigned init[2] = {0xFFFFFFFFu, 0u};
-    hipError_t e = hipMemcpyAsync(mm, init, sizeof init, hipMemcpyHostToDevice, stream);
-    if (e != hipSuccess) return e;
-    if (bits == 16) {
+    if (bits == 16)
         hipLaunchKernelGGL(minmax_kernel<unsigned short>, dim3(blocks), dim3(256), 0, stream, (const unsigned short*)raw, n, mm);
+    else if (bits == 8)
+        hipLaunchKernelGGL(minmax_kernel<unsigned char>, dim3(blocks), dim3(256), 0, stream, (const unsigned char*)raw, n, mm);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// im2double (+ rescale_intensity with the plane's (min, max) in mm) of n raw values
+hipError_t launch_raw_convert(const void* raw, int bits, size_t n, int rescale, const unsigned* mm, double* out,
+                              hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
+    if (bits == 16)
         hipLaunchKernelGGL(raw_to_double_kernel<unsigned short>, dim3(blocks), dim3(256), 0, stream, (const unsigned short*)raw, n,
                            1.0 / 65535, rescale, mm, out);
-    } else if (bits == 8) {
-        hipLaunchKernelGGL(minmax_kernel<unsigned char>, dim3(blocks), dim3(256), 0, stream, (const unsigned char*)raw, n, mm);
+    else if (bits == 8)
         hipLaunchKernelGGL(raw_to_double_kernel<unsigned char>, dim3(blocks), dim3(256), 0, stream, (const unsigned char*)raw, n,
                            1.0 / 255, rescale, mm, out);
-    } else {
+    else
         return hipErrorInvalidValue;
-    }
     return hipGetLastError();
+}
+
+hipError_t launch_raw_to_double(const void* raw, int bits, size_t n, int rescale, unsigned* mm, double* out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipError_t e = launch_minmax_init(mm, stream);
+    if (e != hipSuccess) return e;
+    if ((e = launch_minmax(raw, bits, n, mm, stream)) != hipSuccess) return e;
+    return launch_raw_convert(raw, bits, n, rescale, mm, out, stream);
 }
 
 hipError_t launch_half_to_u8(const void* pm_half, size_t n, unsigned char* out, hipStream_t stream) {

@@ -97,6 +97,57 @@ def slab_rows(pa: int, pb: int, npr: int, sub: int, margin: int, H: int, n: int,
     return (s0, max(s0, s1))
 
 
+class _Done:
+    """A completed request (same surface as the Work objects torch.distributed returns)."""
+
+    def __init__(self, fn=None):
+        self._fn = fn
+
+    def wait(self):
+        if self._fn is not None:
+            self._fn()
+            self._fn = None
+
+
+def _staged(t, group) -> bool:
+    """GPU tensors over the gloo backend (the 2-ranks-on-one-GPU test: RCCL refuses two ranks on one device) travel
+    through host memory; RCCL (backend "nccl") and CPU tensors over gloo go straight to torch.distributed."""
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _isend(t, dst, group):
+    import torch.distributed as dist
+    if _staged(t, group):
+        h = t.cpu()
+        w = dist.isend(h.view(-1), dst=dst, group=group)
+        return _Done(lambda: (w.wait(), h))
+    return dist.isend(t, dst=dst, group=group)
+
+
+def _irecv(t, src, group):
+    import torch
+    import torch.distributed as dist
+    if _staged(t, group):
+        h = torch.empty(t.shape, dtype=t.dtype)
+        w = dist.irecv(h.view(-1), src=src, group=group)
+        return _Done(lambda: (w.wait(), t.copy_(h)))
+    return dist.irecv(t, src=src, group=group)
+
+
+def _all_gather(gathered, padded, group):
+    import torch
+    import torch.distributed as dist
+    if _staged(padded, group):
+        hp_, hg = padded.cpu(), torch.empty(gathered.shape, dtype=gathered.dtype)
+        dist.all_gather_into_tensor(hg.view(torch.uint8), hp_.view(torch.uint8), group=group)
+        gathered.copy_(hg)
+        return _Done()
+    if not padded.is_cuda:   # gloo (CPU tests): move the raw bytes, whatever the element type
+        return dist.all_gather_into_tensor(gathered.view(torch.uint8), padded.view(torch.uint8), group=group, async_op=True)
+    return dist.all_gather_into_tensor(gathered, padded, group=group, async_op=True)
+
+
 def infer_image_sharded(eng, d_band, band_row0: int, H: int, W: int, mean: float, std: float, mode: int, stitch: int,
                         group=None, gather: bool = True, nslabs: int = 2):
     """Distributed whole-slide inference.  Every rank calls this with the image rows it holds.
@@ -105,8 +156,12 @@ def infer_image_sharded(eng, d_band, band_row0: int, H: int, W: int, mean: float
     ``needed_image_rows`` of this rank's patch rows).  Returns the full [K, H, W] result on every rank
     (``gather=True``) or this rank's stitched band and its (y0, y1).
 
-    Schedule -- communication rides under tile compute (on a GPU every engine call is stream-ordered on the engine's
-    stream, which the caller sets to torch's current stream; RCCL work runs on the communicator's stream):
+    Stream contract (GPU): the caller runs this function under a dedicated ``torch.cuda.Stream`` and has handed that
+    stream's handle to the engine (``eng.set_stream(stream.cuda_stream)``; the legacy default stream is refused there),
+    so engine launches, torch copies and the hand-over to RCCL's stream are all ordered on ONE stream: a stitch is queued
+    behind its slab's tiles, the copy into the gather buffer behind the stitch, ``work.wait()`` / ``req.wait()`` make that
+    stream wait for the collective, and the caching allocator recycles a slab only behind the work that used it.
+    Schedule -- communication rides under tile compute:
       1. the LAST patch row of the band is computed first and sent to the next rank (the one exchange step of the path);
       2. the band is then computed in ``nslabs`` slabs of patch rows; as soon as a slab's image rows are final they are
          stitched and their all-gather starts asynchronously, overlapping the next slab's tiles.
@@ -145,9 +200,9 @@ def infer_image_sharded(eng, d_band, band_row0: int, H: int, W: int, mean: float
         tiles(pb - 1, pb)                       # last patch row first: the next rank is waiting for it
         eng.synchronize()
     if has_next:
-        reqs.append(dist.isend(probs[-npc:], dst=glob(active[active.index(rank) + 1]), group=group))
+        reqs.append(_isend(probs[-npc:], glob(active[active.index(rank) + 1]), group))
     if has_prev:
-        reqs.append(dist.irecv(probs[:npc], src=glob(active[active.index(rank) - 1]), group=group))
+        reqs.append(_irecv(probs[:npc], glob(active[active.index(rank) - 1]), group))
 
     cuts = _slab_cuts(pa, pb, n) if pa < pb else [0] * (n + 1)
     full = torch.empty((K, H, W), dtype=out_dtype, device=dev) if gather else None
@@ -169,12 +224,7 @@ def infer_image_sharded(eng, d_band, band_row0: int, H: int, W: int, mean: float
         padded = torch.zeros((K, mx, W), dtype=out_dtype, device=dev)
         padded[:, :s1 - s0] = slab
         gathered = torch.empty((world * K, mx, W), dtype=out_dtype, device=dev)   # concatenation along dim 0
-        if dev.type == "cpu":   # gloo (CPU tests): move the raw bytes, whatever the element type
-            work = dist.all_gather_into_tensor(gathered.view(torch.uint8), padded.view(torch.uint8), group=group,
-                                               async_op=True)
-        else:
-            work = dist.all_gather_into_tensor(gathered, padded, group=group, async_op=True)
-        pending.append((work, gathered, rows, mx))
+        pending.append((_all_gather(gathered, padded, group), gathered, rows, mx))
     if not gather:
         eng.synchronize()
         return (torch.cat(slabs, dim=1) if slabs else torch.empty((K, 0, W), dtype=out_dtype, device=dev)), (y0, y1)
@@ -184,4 +234,5 @@ def infer_image_sharded(eng, d_band, band_row0: int, H: int, W: int, mean: float
         for r, (a, b) in enumerate(rows):
             if b > a:
                 full[:, a:b] = g4[r, :, :b - a]
+    eng.synchronize()   # fence of the engine's stream: raises UmxError (e.g. UMX_ERR_RANGE of the split-precision path)
     return full

@@ -24,7 +24,7 @@ STITCH_FP16_COMPAT, STITCH_FP32 = 0, 1
 EXPORTS = [
     "umx_device_count", "umx_device_mem_info", "umx_create", "umx_create_opts", "umx_precision_of", "umx_destroy", "umx_last_error", "umx_set_stream", "umx_synchronize",
     "umx_forward_tiles", "umx_forward_tiles_dev", "umx_tile_grid", "umx_infer_image", "umx_infer_image_dev",
-    "umx_infer_image_raw",
+    "umx_infer_image_raw", "umx_infer_image_raw_submit", "umx_infer_image_wait",
     "umx_band_tiles_dev", "umx_stitch_dev", "umx_profile_enable", "umx_profile_read", "umx_test_double_to_half",
     "umx_describe", "umx_version",
 ]
@@ -119,6 +119,11 @@ def load(path: Optional[str] = None):
     L.umx_tile_grid.argtypes = [c_void_p, c_int, c_int, ip, ip, ip, ip]
     L.umx_infer_image.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_int, c_int, c_void_p]
     L.umx_infer_image_dev.argtypes = L.umx_infer_image.argtypes
+    L.umx_infer_image_raw_submit.restype = c_int
+    L.umx_infer_image_raw_submit.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_double,
+                                             c_int, c_void_p]
+    L.umx_infer_image_wait.restype = c_int
+    L.umx_infer_image_wait.argtypes = [c_void_p, c_int]
     L.umx_infer_image_raw.restype = c_int
     L.umx_infer_image_raw.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_int,
                                       c_void_p]
@@ -226,8 +231,18 @@ class Engine:
             raise UmxError(rc, self._L.umx_last_error(self._ctx).decode())
 
     # -- plumbing
-    def set_stream(self, hip_stream: int) -> None:
-        self._check(self._L.umx_set_stream(self._ctx, ctypes.c_void_p(hip_stream)))
+    def set_stream(self, hip_stream) -> None:
+        """Run the engine's launches on the caller's HIP stream (a non-zero hipStream_t handle, e.g.
+        ``torch.cuda.Stream().cuda_stream``); ``None`` restores the engine's own stream.  The legacy default stream
+        (handle 0 -- what ``torch.cuda.current_stream()`` is unless a ``torch.cuda.stream`` context is active) is
+        refused: the C ABI reads NULL as "own stream", and that stream is non-blocking, so engine work would NOT be
+        ordered against the caller's default-stream work."""
+        if hip_stream is None:
+            hip_stream = 0
+        elif int(hip_stream) == 0:
+            raise ValueError("set_stream(0): the legacy default stream cannot be shared with the engine; run the caller's "
+                             "work under a dedicated torch.cuda.Stream and pass its cuda_stream handle (None = own stream)")
+        self._check(self._L.umx_set_stream(self._ctx, ctypes.c_void_p(int(hip_stream))))
 
     def synchronize(self) -> None:
         self._check(self._L.umx_synchronize(self._ctx))
@@ -262,6 +277,29 @@ class Engine:
         self._check(self._L.umx_infer_image(self._ctx, image.ctypes.data, C, H, W, float(mean), float(std), int(mode),
                                             int(stitch), out.ctypes.data))
         return out
+
+    def infer_image_ptr(self, image_ptr: int, C: int, H: int, W: int, mean: float, std: float, out_ptr: int,
+                        mode: int = MODE_ACCUMULATE, stitch: int = STITCH_FP16_COMPAT) -> None:
+        """umx_infer_image on raw HOST addresses (e.g. pinned buffers: the slab-wise uploads / downloads are then true DMA
+        under the tile kernels): float64 [C,H,W] in, [K,H,W] float16 / float32 out."""
+        self._check(self._L.umx_infer_image(self._ctx, ctypes.c_void_p(image_ptr), C, H, W, float(mean), float(std),
+                                            int(mode), int(stitch), ctypes.c_void_p(out_ptr)))
+
+    def infer_image_raw_ptr(self, raw_ptr: int, bits: int, C: int, H: int, W: int, rescale: bool, mean: float, std: float,
+                            out_ptr: int, mode: int = MODE_ACCUMULATE) -> None:
+        """umx_infer_image_raw on raw HOST addresses: uint8 / uint16 [C,H,W] in, uint8 [K,H,W] out."""
+        self._check(self._L.umx_infer_image_raw(self._ctx, ctypes.c_void_p(raw_ptr), int(bits), C, H, W, int(bool(rescale)),
+                                                float(mean), float(std), int(mode), ctypes.c_void_p(out_ptr)))
+
+    def infer_image_raw_submit(self, slot: int, raw_ptr: int, bits: int, C: int, H: int, W: int, rescale: bool, mean: float,
+                               std: float, out_ptr: int, mode: int = MODE_ACCUMULATE) -> None:
+        """Enqueue one slide on `slot` (0 / 1) and return; pair with infer_image_wait(slot).  HOST addresses."""
+        self._check(self._L.umx_infer_image_raw_submit(self._ctx, int(slot), ctypes.c_void_p(raw_ptr), int(bits), C, H, W,
+                                                       int(bool(rescale)), float(mean), float(std), int(mode),
+                                                       ctypes.c_void_p(out_ptr)))
+
+    def infer_image_wait(self, slot: int) -> None:
+        self._check(self._L.umx_infer_image_wait(self._ctx, int(slot)))
 
     def infer_image_raw(self, raw: np.ndarray, rescale: bool, mean: float, std: float,
                         mode: int = MODE_ACCUMULATE) -> np.ndarray:
