@@ -152,6 +152,12 @@ UMX_API int umx_infer_image_raw_submit(umx_ctx* ctx, int slot, const void* raw_h
                                        int rescale, double mean, double std, int mode, uint8_t* out_host);
 UMX_API int umx_infer_image_wait(umx_ctx* ctx, int slot);
 
+/* Strip / tile decoders of the drivers' own TIFF reader (unmicst_amd/tiffio.py; the reference reads through tifffile /
+ * imagecodecs, UnMicst1-5.py:794-797): TIFF 6.0 LZW (compression 5, the OME-TIFF / Bio-Formats default) and PackBits
+ * (32773).  Host code, no device needed.  Return the decoded byte count (<= cap) or -1 on a malformed stream. */
+UMX_API long long umx_tiff_lzw_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
+UMX_API long long umx_tiff_packbits_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
+
 /* The two halves of umx_infer_image, exposed for band sharding across GPUs (one process per GPU):
  * umx_band_tiles_dev: PI2D.getPatch + normalise + UNet for patch rows [pr0,pr1) -> probs
  *   [(pr1-pr0)*patch_cols, P,P,K] float32.  image_dev holds image rows [band_row0, band_row0+band_rows) of the

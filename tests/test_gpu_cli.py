@@ -120,3 +120,58 @@ def test_raw_fast_path_is_bit_identical_to_the_host_recipe(workspace):
         pm = eng.infer_image(pre, 0.2, 0.2)
         want = np.stack([imtools.to_uint8_via_resize(pm[k], two.shape[1:]) for k in range(hp2.nClasses)])
         assert np.array_equal(got, want)
+
+
+def test_clean_checkout_runs_on_the_shipped_models_directory(workspace):
+    """`python unmicstWrapper.py --tool unmicst-legacy img.tif` out of the box: no UMX_MODELS_DIR, the converted nucleiDAPI
+    weights come from <repo>/models/nucleiDAPI/umx_model.npz (reference UnMicst.py:547,556: models/<--model>)."""
+    base, _, img = workspace
+    out = str(base / "out_clean")
+    env = {k: v for k, v in os.environ.items() if k != "UMX_MODELS_DIR"}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "unmicstWrapper.py"), "--tool", "unmicst-legacy", img, "--channel", "2",
+                        "--outputPath", out], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cont = tiffio.imread_all(os.path.join(out, "105_ContoursPM_2.tif"))
+    nuc = tiffio.imread_all(os.path.join(out, "105_NucleiPM_2.tif"))
+    _check_planes(cont[0], nuc[0], cont[1])
+
+
+def test_duo_script_on_a_two_page_ome_tiff_4096(tmp_path):
+    """BASELINE configs[2] file to file: UnMicst2.py (unmicst-duo, nucleiDAPILAMIN hyper-parameters from the shipped
+    models/ directory, seeded synthetic weights -- the reference's shard is not in its tree) on a synthetic 4096 x 4096
+    2-page OME-TIFF with --stackOutput; the written pages must equal what the facade returns for the same two planes
+    (reference UnMicst2.py:747-751 channel pair, :780-788 rescale, :813-817 uint8 recipe, pages nuclei / contours /
+    background)."""
+    from unmicst_amd import imtools
+    rng = np.random.default_rng(11)
+    N = 4096
+    y = np.arange(N)[:, None]
+    x = np.arange(N)[None, :]
+    planes = []
+    for c in range(2):
+        v = 0.25 + 0.2 * np.sin(y / (31.0 + 7 * c)) * np.cos(x / 47.0) + 0.1 * rng.random((N, N))
+        planes.append(np.uint16(np.clip(v, 0, 1) * 60000))
+    img = str(tmp_path / "slide.ome.tif")
+    tiffio.imsave(img, planes[0], append=False)
+    tiffio.imsave(img, planes[1], append=True)
+    out = str(tmp_path / "out")
+    env = {k: v for k, v in os.environ.items() if k != "UMX_MODELS_DIR"}
+    env["UMX_SYNTHETIC_WEIGHTS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "UnMicst2.py"), img, "--channel", "0", "1", "--stackOutput",
+                        "--outputPath", out], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = tiffio.imread_all(os.path.join(out, "slide_Probabilities_1.tif"))
+    assert got.shape == (3, N, N) and got.dtype == np.uint8
+    prev = tiffio.imread_all(os.path.join(out, "qc", "slide_Preview_1.tif"))
+    assert prev.shape == (2, N, N)
+    # the same planes through the facade (host-side recipe: resize at the identity grid, rescale to (0, 0.983))
+    art = model.load_model_dir(os.path.join(ROOT, "models", "nucleiDAPILAMIN"), synthetic_if_missing=True)
+    UNet2D.setupWithArtefacts(art)
+    try:
+        cells = np.stack([driver.preprocess(p, 1, -1)[1] for p in planes])
+        want = [imtools.to_uint8_via_resize(UNet2D.singleImageInference(cells, "accumulate", k), (N, N)) for k in (2, 1, 0)]
+    finally:
+        UNet2D.singleImageInferenceCleanup()
+    for page in range(3):
+        assert np.array_equal(got[page], want[page]), page
+    assert np.array_equal(prev[0], want[1])

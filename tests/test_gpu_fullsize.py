@@ -148,3 +148,46 @@ def test_synthetic256_full_16384_slide_in_eight_bands():
     assert np.array_equal(a, b)
     s = full[:, ::7, ::5].astype(np.float32).sum(0)
     assert np.abs(s - 1.0).max() <= 2e-3
+
+
+def test_solo_full_16384_slide_in_eight_bands():
+    """BASELINE configs[3] as worded: unmicst-solo hyper-parameters on a 16384 x 16384 1-channel slide -- 342 x 342 =
+    116 964 tiles of 64 x 64, a very different launch-count regime from the 256-px tile.  Tile-periodic input: the single
+    pass must be bit-periodic in the interior, the 8-band decomposition (`bench.py --gpus 8 --workload solo-16384`, here
+    band after band on one GPU) must reproduce it bit for bit, and spot tiles must match the CPU oracle."""
+    import torch
+    from oracle import oracle, pi2d_oracle
+    from unmicst_amd import sharding
+    hp = model.KNOWN_HP["nucleiDAPI1-5"]
+    blob = model.random_blob(hp, seed=20260101)
+    mean, std = 0.34, 0.25
+    N = 16384
+    sub = hp.imSize - 2 * hp.margin            # 48
+    cell = _slide(1, sub, sub, 9)[0]
+    reps = N // sub + 1
+    img = np.tile(cell, (reps, reps))[:N, :N].copy()
+    with umx.Engine(hp, blob, max_batch=1024) as eng:
+        npr, npc = eng.tile_grid(N, N)[:2]
+        assert (npr, npc) == (342, 342)
+        full = eng.infer_image(img, mean, std)
+        d_img = torch.from_numpy(img[None]).cuda()
+        row = 0
+        for r in range(8):
+            part = sharding.infer_band_local(eng, d_img, mean, std, r, 8, umx.MODE_ACCUMULATE, umx.STITCH_FP16_COMPAT)
+            part = part.cpu().numpy()
+            assert np.array_equal(part.view(np.uint16), full[:, row:row + part.shape[1]].view(np.uint16)), r
+            row += part.shape[1]
+        assert row == N
+        del d_img
+        # interior tiles all see the same input: one oracle tile pins them
+        pi = pi2d_oracle.PI2DOracle(img[:4 * sub + 2 * hp.margin, :4 * sub + 2 * hp.margin], hp.imSize, hp.margin, "accumulate")
+        tiles = pi2d_oracle.normalised_batch(pi, 0, pi.num_patches, 1, mean, std, True)
+        probs = eng.forward_tiles(tiles)
+    ref = oracle.forward(hp, blob, tiles[[0, 5, 10]])
+    assert np.abs(probs[[0, 5, 10]] - ref).max() <= 1e-4
+    P = hp.imSize
+    a = full[:, P:N - P - sub, P:N - P - sub].view(np.uint16)
+    b = full[:, P + sub:N - P, P + sub:N - P].view(np.uint16)
+    assert np.array_equal(a, b)
+    s = full[:, ::7, ::5].astype(np.float32).sum(0)
+    assert np.abs(s - 1.0).max() <= 2e-3

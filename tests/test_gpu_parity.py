@@ -202,6 +202,71 @@ print("sharded ok")
     assert r.returncode == 0 and "sharded ok" in r.stdout, r.stderr[-3000:]
 
 
+def test_range_overflow_is_reported_on_every_path_and_the_facade_falls_back(torch_cuda):
+    """UMX_ERR_RANGE (an activation beyond binary16's range in the split-precision kernels) must surface from the host
+    entry point, from the device entry points' fence (umx_synchronize) and from the sharded path -- and the UNet2D facade
+    must then rebuild the engine with the exact-fp32 kernels and succeed, as the reference's fp32 graph would."""
+    import torch
+    from unmicst_amd import sharding
+    from unmicst_amd.unet2d import UNet2D
+    hp = helpers.small_hps()["v2_duo_like"]
+    blob = model.random_blob(hp, seed=4)
+    img = np.random.default_rng(2).random((2, 70, 45)) * 0.5 + 0.25
+    tiny_std = 1e-7                      # (v - mean) / std ~ 5e6: far outside binary16
+    with umx.Engine(hp, blob, max_batch=8, precision="f16x3") as eng:
+        with pytest.raises(umx.UmxError) as e1:
+            eng.infer_image(img, 0.0, tiny_std)
+        assert e1.value.code == umx.ERR_RANGE
+        good = eng.infer_image(img, 0.2, 0.2)                       # the context stays usable, the flag is cleared
+        assert np.isfinite(good.astype(np.float32)).all()
+        work = torch.cuda.Stream()
+        eng.set_stream(work.cuda_stream)
+        with torch.cuda.stream(work):
+            d = torch.from_numpy(img).cuda()
+            out = torch.empty((hp.nClasses, 70, 45), dtype=torch.float16, device="cuda")
+            eng.infer_image_dev(d.data_ptr(), 2, 70, 45, 0.0, tiny_std, umx.MODE_ACCUMULATE, umx.STITCH_FP16_COMPAT,
+                                out.data_ptr())
+            with pytest.raises(umx.UmxError) as e2:
+                eng.synchronize()
+            assert e2.value.code == umx.ERR_RANGE
+    script = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import helpers
+from unmicst_amd import model, sharding, umx
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29587")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+hp = helpers.small_hps()["v2_duo_like"]
+blob = model.random_blob(hp, seed=4)
+img = np.random.default_rng(2).random((2, 150, 61)) * 0.5 + 0.25
+with umx.Engine(hp, blob, max_batch=8, precision="f16x3") as eng:
+    work = torch.cuda.Stream()
+    eng.set_stream(work.cuda_stream)
+    with torch.cuda.stream(work):
+        band = torch.from_numpy(img).cuda()
+        try:
+            sharding.infer_image_sharded(eng, band, 0, 150, 61, 0.0, 1e-7, umx.MODE_ACCUMULATE, umx.STITCH_FP16_COMPAT)
+            print("no error")
+        except umx.UmxError as e:
+            print("sharded raised code %%d" %% e.code)
+dist.destroy_process_group()
+''' % (helpers.ROOT, helpers.ROOT)
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert "sharded raised code 6" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+    # the facade: same overflow, transparent switch to the fp32 kernels
+    UNet2D.setupWithArtefacts(model.ModelArtefacts(hp, blob, 0.0, tiny_std))
+    try:
+        assert UNet2D.Engine.precision == "f16x3"
+        plane = UNet2D.singleImageInference(img, "accumulate", 1)
+        assert UNet2D.Engine.precision == "f32" and plane.shape == (70, 45)
+        assert np.isfinite(plane.astype(np.float32)).all()
+    finally:
+        UNet2D.singleImageInferenceCleanup()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_two_and_three_ranks_share_one_gpu(world, tmp_path):
     """The N>1 path with the REAL engine: `world` processes, all on cuda:0 (RCCL refuses two ranks on one device, so the

@@ -30,6 +30,20 @@ def test_inference_mode_matches_c_oracle(name):
     assert np.abs(got - want).max() < 2e-6
 
 
+@pytest.mark.parametrize("key", ["nucleiDAPI1-5", "nucleiDAPILAMIN"])
+def test_inference_mode_matches_c_oracle_at_the_shipped_widths(key):
+    """The two independent restatements of the v2 graph (oracle/unet_oracle.c and the torch one here) at the FULL width of
+    the shipped solo (80..1280 channels) and duo (36..1152) hyper-parameters, seeded weights with non-trivial BN statistics:
+    the reference pins neither (no weights, no outputs in its tree -- SURVEY.md section 8c), so the two must at least pin
+    each other."""
+    hp = model.KNOWN_HP[key]
+    blob = model.random_blob(hp, seed=20260101)
+    data = np.random.default_rng(2).normal(0, 1, (1, hp.imSize, hp.imSize, hp.nChannels)).astype(np.float32)
+    want = orc.forward(hp, blob, data)
+    got = to.inference_probs(hp, blob, data)
+    assert np.abs(got - want).max() < 5e-6
+
+
 def test_specs_agree_with_product_blob_order():
     for name in ("v2_solo_like", "v2_duo_like", "v2_wide"):
         hp = small_hps()[name]

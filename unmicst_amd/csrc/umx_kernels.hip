@@ -450,6 +450,9 @@ hipError_t launch_head_softmax(const float* x, size_t npix, int C, int K, const 
 // float16 divide runs in float32).  fp32 mode: blend in double, one rounding to float32.
 // HBM streaming: <= 4*K*4 B read per pixel (1.78*K*4 on average), 2*K (or 4*K) B written.
 // ------------------------------------------------------------------------------------------------------------
+// (contraction off from here on: `o + p*w` must round the product and the sum separately, as numpy does -- with imSize a
+// power of two the product is exact either way, for other tile sizes a fused multiply-add would differ in the last bit)
+#pragma clang fp contract(off)
 __device__ __forceinline__ double blend_weight(int r, int c, int P, int two_m) {
     const int d = min(min(r, c), min(P - 1 - r, P - 1 - c));   // ring index, reference PartitionOfImage.py:30-38
     if (d == 0) return 0.0;

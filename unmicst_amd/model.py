@@ -259,6 +259,7 @@ class ModelArtefacts:
 
 
 CONVERTED_NAME = "umx_model.npz"   # written by tools/convert_model.py: the "converted once" form of a model directory
+HP_ONLY_NAME = "umx_hp.npz"        # hyper-parameters + mean/std of a model whose weight shard is not in the tree
 
 
 def detect_graph(model_path: str) -> int:
@@ -310,6 +311,17 @@ def load_model_dir(model_path: str, graph: int = None, synthetic_if_missing: boo
     if os.path.exists(conv):
         with np.load(conv) as z:
             return ModelArtefacts(hparams_from_vector(z["hp"]), np.array(z["blob"]), float(z["mean"]), float(z["std"]))
+    hp_only = os.path.join(model_path, HP_ONLY_NAME)
+    if os.path.exists(hp_only) and not os.path.exists(os.path.join(model_path, "hp.data")):
+        # the shipped stand-ins for nucleiDAPI1-5 / nucleiDAPILAMIN: hyper-parameters + normalisation scalars, no weights
+        # (the reference downloads those shards at image-build time, Dockerfile:5-6; drop umx_model.npz next to this file)
+        with np.load(hp_only) as z:
+            hp, mean, std = hparams_from_vector(z["hp"]), float(z["mean"]), float(z["std"])
+        if not synthetic_if_missing:
+            raise FileNotFoundError("%s holds hyper-parameters only: convert the model's checkpoint with tools/convert_model.py "
+                                    "(-> %s), or set UMX_SYNTHETIC_WEIGHTS=1 to run with seeded synthetic weights"
+                                    % (model_path, CONVERTED_NAME))
+        return ModelArtefacts(hp, random_blob(hp), mean, std)
     if graph is None:
         graph = detect_graph(model_path)
     hp = hparams_from_dict(load_pickle(os.path.join(model_path, "hp.data")), graph)

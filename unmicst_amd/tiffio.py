@@ -7,9 +7,10 @@ Stands in for the third-party readers/writers the reference drivers call at the 
 live in SubIFDs and are not top-level pages, matching how tifffile indexes ``key``).
 
 Supported on read: classic TIFF and BigTIFF, both byte orders, strips or tiles, 1 sample per pixel,
-uint8/uint16/uint32/int*/float32/float64, compression none (1) or deflate (8 / 32946) with optional horizontal
-predictor.  Anything else raises NotImplementedError (the reference raises NotImplementedError for file types
-it cannot read, UnMicst1-5.py:785-806).
+uint8/uint16/uint32/int*/float32/float64, compression none (1), LZW (5: the Bio-Formats / OME-TIFF default), deflate
+(8 / 32946) or PackBits (32773), with optional horizontal predictor (2).  LZW and PackBits strips are decoded by two host
+functions of libumx (no GPU needed).  JPEG / JPEG-2000 / zstd / floating-point predictor raise NotImplementedError (the
+reference raises NotImplementedError for file types it cannot read, UnMicst1-5.py:785-806).
 """
 from __future__ import annotations
 
@@ -109,12 +110,15 @@ class _Reader:
         if kind is None or bits % 8:
             raise NotImplementedError("unsupported sample format %s / %s bits" % (fmt, bits))
         dt = np.dtype(self.bo + kind + str(bits // 8))
-        if comp not in (1, 8, 32946):
+        if comp not in (1, 5, 8, 32946, 32773):
             raise NotImplementedError("unsupported TIFF compression %d" % comp)
 
         def decode(buf: bytes, rows: int, cols: int) -> np.ndarray:
-            if comp != 1:
+            if comp in (8, 32946):
                 buf = zlib.decompress(buf)
+            elif comp in (5, 32773):
+                from . import umx
+                buf = umx.tiff_decode("lzw" if comp == 5 else "packbits", buf, rows * cols * dt.itemsize)
             a = np.frombuffer(buf, dtype=dt, count=rows * cols).reshape(rows, cols)
             if predictor == 2:
                 a = np.cumsum(a, axis=1, dtype=a.dtype.newbyteorder("="))

@@ -17,6 +17,7 @@ from .model import HParams
 UMX_OK = 0
 PREC_DEFAULT, PREC_F32, PREC_F16X3 = 0, 1, 2      # enum umx_precision
 PRECISIONS = {"default": PREC_DEFAULT, "f32": PREC_F32, "f16x3": PREC_F16X3}
+ERR_RANGE = 6   # UMX_ERR_RANGE
 MODE_ACCUMULATE, MODE_REPLACE = 0, 1
 STITCH_FP16_COMPAT, STITCH_FP32 = 0, 1
 
@@ -24,7 +25,8 @@ STITCH_FP16_COMPAT, STITCH_FP32 = 0, 1
 EXPORTS = [
     "umx_device_count", "umx_device_mem_info", "umx_create", "umx_create_opts", "umx_precision_of", "umx_destroy", "umx_last_error", "umx_set_stream", "umx_synchronize",
     "umx_forward_tiles", "umx_forward_tiles_dev", "umx_tile_grid", "umx_infer_image", "umx_infer_image_dev",
-    "umx_infer_image_raw", "umx_infer_image_raw_submit", "umx_infer_image_wait",
+    "umx_infer_image_raw", "umx_infer_image_raw_submit", "umx_infer_image_wait", "umx_tiff_lzw_decode",
+    "umx_tiff_packbits_decode",
     "umx_band_tiles_dev", "umx_stitch_dev", "umx_profile_enable", "umx_profile_read", "umx_test_double_to_half",
     "umx_describe", "umx_version",
 ]
@@ -124,6 +126,9 @@ def load(path: Optional[str] = None):
                                              c_int, c_void_p]
     L.umx_infer_image_wait.restype = c_int
     L.umx_infer_image_wait.argtypes = [c_void_p, c_int]
+    for fn in (L.umx_tiff_lzw_decode, L.umx_tiff_packbits_decode):
+        fn.restype = ctypes.c_longlong
+        fn.argtypes = [c_void_p, ctypes.c_size_t, c_void_p, ctypes.c_size_t]
     L.umx_infer_image_raw.restype = c_int
     L.umx_infer_image_raw.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_int,
                                       c_void_p]
@@ -184,6 +189,18 @@ def double_to_half(x: np.ndarray) -> np.ndarray:
     out = np.empty(x.shape, np.uint16)
     load().umx_test_double_to_half(x.ctypes.data, out.ctypes.data, x.size)
     return out.view(np.float16)
+
+
+def tiff_decode(kind: str, buf: bytes, nbytes: int) -> bytes:
+    """Decode one TIFF strip / tile: kind "lzw" (compression 5) or "packbits" (32773) -> exactly ``nbytes`` bytes
+    (zero-filled if the stream is short)."""
+    L = load()
+    out = ctypes.create_string_buffer(nbytes)
+    fn = {"lzw": L.umx_tiff_lzw_decode, "packbits": L.umx_tiff_packbits_decode}[kind]
+    n = fn(buf, len(buf), out, nbytes)
+    if n < 0:
+        raise ValueError("malformed %s stream in TIFF strip" % kind)
+    return out.raw
 
 
 class Engine:

@@ -99,6 +99,7 @@ class UNet2D:
         device = _umx.pick_device_most_free_memory() if gpuIndex is None or gpuIndex < 0 else int(gpuIndex)
         # tiles per launch group: enough M to fill 256 CUs at the deepest level (a few hundred MB of activations)
         batch = UNet2D.max_batch or max(hp.batchSize, min(256, (1 << 22) // (hp.imSize * hp.imSize)))
+        UNet2D._engine_args = (hp, art.blob, device, batch)
         UNet2D.Engine = _umx.Engine(hp, art.blob, device=device, max_batch=batch)
         print("Model restored.")
 
@@ -111,6 +112,22 @@ class UNet2D:
         UNet2D._last = None
 
     # ---------------------------------------------------------------- inference
+    @staticmethod
+    def _with_range_fallback(call):
+        """Run ``call()`` on the engine; if the split-precision path reports UMX_ERR_RANGE (an activation left binary16's
+        range -- the reference's fp32 TensorFlow graph has no such limit), rebuild the engine with the exact-fp32 MFMA
+        kernels in this process and run the call again, so the CLI succeeds wherever the reference does."""
+        try:
+            return call()
+        except _umx.UmxError as e:
+            if e.code != _umx.ERR_RANGE or UNet2D.Engine is None or UNet2D.Engine.precision == "f32":
+                raise
+            hp, blob, device, batch = UNet2D._engine_args
+            print("split-precision range exceeded: switching this model to the exact-fp32 kernels")
+            UNet2D.Engine.close()
+            UNet2D.Engine = _umx.Engine(hp, blob, device=device, max_batch=batch, precision="f32")
+            return call()
+
     @staticmethod
     def _check_image(image):
         hp = UNet2D.hparams
@@ -135,7 +152,8 @@ class UNet2D:
         print("Inference...")
         image = UNet2D._check_image(image)
         m = _umx.MODE_ACCUMULATE if mode == "accumulate" else _umx.MODE_REPLACE
-        return UNet2D.Engine.infer_image(image, UNet2D.DatasetMean, UNet2D.DatasetStDev, m, UNet2D.stitch)
+        return UNet2D._with_range_fallback(
+            lambda: UNet2D.Engine.infer_image(image, UNet2D.DatasetMean, UNet2D.DatasetStDev, m, UNet2D.stitch))
 
     @staticmethod
     def singleImageInferenceRaw(raw, rescale, mode="accumulate"):
@@ -151,7 +169,8 @@ class UNet2D:
         if raw.ndim == 3 and raw.shape[0] != UNet2D.hparams.nChannels:
             raise ValueError("image has %d planes, the model takes %d channels" % (raw.shape[0], UNet2D.hparams.nChannels))
         m = _umx.MODE_ACCUMULATE if mode == "accumulate" else _umx.MODE_REPLACE
-        return UNet2D.Engine.infer_image_raw(raw, bool(rescale), UNet2D.DatasetMean, UNet2D.DatasetStDev, m)
+        return UNet2D._with_range_fallback(
+            lambda: UNet2D.Engine.infer_image_raw(raw, bool(rescale), UNet2D.DatasetMean, UNet2D.DatasetStDev, m))
 
     @staticmethod
     def _pass_key(image, mode):
