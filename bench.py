@@ -62,6 +62,9 @@ def parse_args(argv=None):
     ap.add_argument("--slabs", type=int, default=2, help="N>1 path: row slabs per band (stitch + async all-gather each)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N>1 code path (band halo exchange + slab all-gathers) even in a world of one rank")
+    ap.add_argument("--native-shard", action="store_true",
+                    help="N>1 path through the C ABI (umx_infer_image_sharded_dev: RCCL inside libumx) instead of "
+                         "unmicst_amd/sharding.py over torch.distributed; torch only hands the communicator id to the ranks")
     ap.add_argument("--resident-only", action="store_true",
                     help="time only the HBM-resident slide (kernel-only; the line's value is then NOT the section-8(d) metric)")
     ap.add_argument("--master-port", type=int, default=29577)
@@ -262,23 +265,54 @@ def main():
             eng.infer_image_dev(band_f64.data_ptr(), C_img, H, W, mean, std, umx.MODE_ACCUMULATE, umx.STITCH_FP16_COMPAT,
                                 dev_out.data_ptr())
     else:
+        if args.native_shard:
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(umx.Engine.shard_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            eng.shard_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+            full_native = torch.empty((K, H, W), dtype=torch.float16, device=dev)
+
+            def sharded_call(band):
+                eng.infer_image_sharded_dev(band.data_ptr(), C_img, H, W, r0, band.shape[1], mean, std, umx.MODE_ACCUMULATE,
+                                            umx.STITCH_FP16_COMPAT, args.slabs, full_native.data_ptr())
+                return full_native
+        else:
+            def sharded_call(band):
+                return sharding.infer_image_sharded(eng, band, r0, H, W, mean, std, umx.MODE_ACCUMULATE,
+                                                    umx.STITCH_FP16_COMPAT, nslabs=args.slabs, sync=False)
         y0, y1 = sharding.owned_rows(pa, pb, npr, sub, margin, H)
-        host_band = torch.empty((K, max(y1 - y0, 0), W), dtype=torch.float16).pin_memory()
-        dev_u16 = torch.empty((C_img, rows, W), dtype=torch.int16, device=dev)
+        # slides are streamed: the band of slide i+1 goes up on `up` and the stitched band of slide i-1 comes down on `dn`
+        # while slide i computes on `work` (two device input buffers, two pinned output buffers, events between the streams)
+        up, dn = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        host_bands = [torch.empty((K, max(y1 - y0, 0), W), dtype=torch.float16).pin_memory() for _ in range(2)]
+        dev_u16s = [torch.empty((C_img, rows, W), dtype=torch.int16, device=dev) for _ in range(2)]
+        conv_done = [None, None]
 
         def step_host():   # H2D of this rank's band + tiles + halo exchange + stitch + all-gather + D2H of its stitched band
+            i = step_host.n & 1
+            step_host.n += 1
+            with torch.cuda.stream(up):
+                if conv_done[i] is not None:
+                    up.wait_event(conv_done[i])          # the buffer's previous contents have been converted
+                dev_u16s[i].copy_(host_u16, non_blocking=True)
+                ev_up = up.record_event()
             with torch.cuda.stream(work):
-                dev_u16.copy_(host_u16, non_blocking=True)
-                band = (dev_u16.to(torch.int32) & 0xFFFF).to(torch.float64) * (1.0 / 65535)
-                full = sharding.infer_image_sharded(eng, band, r0, H, W, mean, std, umx.MODE_ACCUMULATE,
-                                                    umx.STITCH_FP16_COMPAT, nslabs=args.slabs)
-                host_band.copy_(full[:, y0:y1], non_blocking=True)
+                work.wait_event(ev_up)
+                band = (dev_u16s[i].to(torch.int32) & 0xFFFF).to(torch.float64) * (1.0 / 65535)
+                conv_done[i] = work.record_event()
+                full = sharded_call(band)
+                ev_full = work.record_event()
+            with torch.cuda.stream(dn):
+                dn.wait_event(ev_full)
+                host_bands[i].copy_(full[:, y0:y1], non_blocking=True)
+                full.record_stream(dn)
             return full
+        step_host.n = 0
 
         def step_resident():
             with torch.cuda.stream(work):
-                return sharding.infer_image_sharded(eng, band_f64, r0, H, W, mean, std, umx.MODE_ACCUMULATE,
-                                                    umx.STITCH_FP16_COMPAT, nslabs=args.slabs)
+                return sharded_call(band_f64)
 
     def fence():
         if not sharded:
@@ -286,6 +320,9 @@ def main():
                 eng.infer_image_wait(inflight.pop(0))
         eng.synchronize()            # also surfaces UMX_ERR_RANGE of the split-precision path
         work.synchronize()
+        if sharded:
+            up.synchronize()
+            dn.synchronize()
         if sharded:
             dist.barrier()
         torch.cuda.synchronize(dev)

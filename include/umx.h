@@ -152,6 +152,36 @@ UMX_API int umx_infer_image_raw_submit(umx_ctx* ctx, int slot, const void* raw_h
                                        int rescale, double mean, double std, int mode, uint8_t* out_host);
 UMX_API int umx_infer_image_wait(umx_ctx* ctx, int slot);
 
+/*
+ * Whole-slide inference sharded over the GPUs of one node, RCCL over xGMI inside the library (the reference is
+ * single-device: UnMicst1-5.py:769).  One process (or thread with its own ctx) per GPU:
+ *   rank 0: umx_shard_unique_id(&id); hand the 128 bytes to the other ranks over any channel (file, socket, MPI, ...);
+ *   every rank: umx_shard_init(ctx, &id, rank, world)                      -- collective (ncclCommInitRank);
+ *               umx_shard_plan(&hp, H, W, rank, world, nslabs, 0, ...)     -- which image rows this rank must hold;
+ *               umx_infer_image_sharded_dev(ctx, band_dev, ...)            -- collective; every rank ends up with the full
+ *                                                                             [nClasses,H,W] result in out_full_dev;
+ *               umx_synchronize(ctx); ... ; umx_shard_fini(ctx) (or umx_destroy).
+ * Patch rows are split into contiguous bands; a rank computes the tiles of its band from the image rows [need_row0,
+ * need_row1) it holds (band_dev = those rows, float64 [C_img, band_rows, W], band_row0 = first row held), sends the
+ * probabilities of its last patch row to the next rank, stitches the rows it owns -- visiting tiles in ascending global
+ * index, so the fp16 result is bit-identical to a one-GPU run -- and all-gathers them slab by slab under the tiles of
+ * the next slab.  RCCL is resolved at run time (dlopen of the librccl the process already holds, else ROCm's;
+ * UMX_RCCL_PATH overrides).  unmicst_amd/sharding.py is the same schedule over torch.distributed.
+ */
+typedef struct umx_unique_id { char internal[128]; } umx_unique_id;   /* == ncclUniqueId */
+UMX_API int umx_shard_unique_id(umx_unique_id* out);
+UMX_API int umx_shard_init(umx_ctx* ctx, const umx_unique_id* id, int rank, int world);
+UMX_API int umx_shard_fini(umx_ctx* ctx);
+/* Geometry of rank `rank` of `world` for an H x W image cut into `nslabs` slabs per band (the count actually used --
+ * no more than the smallest band's patch rows -- comes back in nslabs_used): its patch rows, the image rows its tiles read
+ * (what band_dev must cover), the image rows it stitches, and the rows of slab `slab`.  Any output may be NULL. */
+UMX_API int umx_shard_plan(const umx_hparams* hp, int H, int W, int rank, int world, int nslabs, int slab, int* patch_row0,
+                           int* patch_row1, int* need_row0, int* need_row1, int* own_row0, int* own_row1, int* slab_row0,
+                           int* slab_row1, int* nslabs_used);
+UMX_API int umx_infer_image_sharded_dev(umx_ctx* ctx, const double* band_dev, int C_img, int H, int W, int band_row0,
+                                        int band_rows, double mean, double std, int mode, int stitch, int nslabs,
+                                        void* out_full_dev);
+
 /* Strip / tile decoders of the drivers' own TIFF reader (unmicst_amd/tiffio.py; the reference reads through tifffile /
  * imagecodecs, UnMicst1-5.py:794-797): TIFF 6.0 LZW (compression 5, the OME-TIFF / Bio-Formats default) and PackBits
  * (32773).  Host code, no device needed.  Return the decoded byte count (<= cap) or -1 on a malformed stream. */

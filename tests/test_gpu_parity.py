@@ -267,6 +267,39 @@ dist.destroy_process_group()
         UNet2D.singleImageInferenceCleanup()
 
 
+def test_native_sharded_entry_point_world_of_one():
+    """umx_infer_image_sharded_dev (RCCL inside libumx: communicator from umx_shard_unique_id / umx_shard_init, band tiles,
+    slab-wise ncclAllGather on the library's communication stream) in a world of one rank, 1 and 3 slabs, fp16-compat and
+    fp32 stitch: bit-equal to umx_infer_image.  (Its band geometry is checked against the torch.distributed schedule on
+    CPU, tests/test_sharding_cpu.py; RCCL refuses two ranks on one device, so worlds > 1 are the driver's 8-GPU run.)"""
+    import subprocess
+    import sys
+    script = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import helpers
+from unmicst_amd import model, umx
+hp = helpers.small_hps()["v2_duo_like"]
+blob = model.random_blob(hp, seed=4)
+H, W = 233, 97
+img = np.random.default_rng(2).random((2, H, W)) * 0.5
+with umx.Engine(hp, blob, max_batch=8) as eng:
+    eng.shard_init(umx.Engine.shard_unique_id(), 0, 1)
+    band = torch.from_numpy(img).cuda()
+    for stitch, dt in ((umx.STITCH_FP16_COMPAT, torch.float16), (umx.STITCH_FP32, torch.float32)):
+        want = eng.infer_image(img, 0.2, 0.2, stitch=stitch)
+        for nslabs in (1, 3):
+            out = torch.zeros((hp.nClasses, H, W), dtype=dt, device="cuda")
+            eng.infer_image_sharded_dev(band.data_ptr(), 2, H, W, 0, H, 0.2, 0.2, umx.MODE_ACCUMULATE, stitch, nslabs,
+                                        out.data_ptr())
+            eng.synchronize()
+            assert np.array_equal(out.cpu().numpy().view(np.uint8), want.view(np.uint8)), (stitch, nslabs)
+print("native sharded ok")
+''' % (helpers.ROOT, helpers.ROOT)
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "native sharded ok" in r.stdout, r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_two_and_three_ranks_share_one_gpu(world, tmp_path):
     """The N>1 path with the REAL engine: `world` processes, all on cuda:0 (RCCL refuses two ranks on one device, so the

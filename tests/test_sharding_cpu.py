@@ -43,3 +43,34 @@ def test_sharded_equals_single_process(tmp_path, world, hp_name, H, W, C):
         got = np.load("%s.rank%d.npy" % (out, rank))
         assert got.dtype == np.float16 and got.shape == ref.shape
         assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), rank
+
+
+def test_library_band_geometry_equals_the_python_schedule():
+    """umx_shard_plan (the geometry umx_infer_image_sharded_dev runs, unmicst_amd/csrc/umx_shard.hip) against
+    unmicst_amd.sharding's band_partition / needed_image_rows / owned_rows / slab_rows over a grid of image sizes, world
+    sizes and slab counts -- including worlds larger than the number of patch rows."""
+    import helpers
+    from unmicst_amd import model, sharding, umx
+    hps = [helpers.small_hps()["v2_duo_like"], model.KNOWN_HP["nucleiDAPI1-5"], model.KNOWN_HP["synthetic-256"]]
+    checked = 0
+    for hp in hps:
+        m = hp.margin
+        sub = hp.imSize - 2 * m
+        for H in (5, sub, sub + 1, 3 * sub - 1, 7 * sub + 13, 2048, 16384):
+            npr = -(-H // sub)
+            for world in (1, 2, 3, 8):
+                bands = sharding.band_partition(npr, world)
+                active = [b - a for a, b in bands if b > a]
+                for nslabs in (1, 2, 4):
+                    n = max(1, min(nslabs, min(active)))
+                    for rank in range(world):
+                        pa, pb = bands[rank]
+                        for i in range(n):
+                            got = umx.shard_plan(hp, H, 77, rank, world, nslabs, i)
+                            assert (got["patch_row0"], got["patch_row1"]) == (pa, pb)
+                            assert (got["need_row0"], got["need_row1"]) == sharding.needed_image_rows(pa, pb, sub, m, hp.imSize, H)
+                            assert (got["own_row0"], got["own_row1"]) == sharding.owned_rows(pa, pb, npr, sub, m, H)
+                            assert (got["slab_row0"], got["slab_row1"]) == sharding.slab_rows(pa, pb, npr, sub, m, H, n, i)
+                            assert got["nslabs"] == n
+                            checked += 1
+    assert checked > 500

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libumx.so")
-SOURCES = ["umx_kernels.hip", "umx_conv_f16.hip", "umx_conv_rw.hip", "umx_engine.hip", "umx_train_kernels.hip",
+SOURCES = ["umx_kernels.hip", "umx_conv_f16.hip", "umx_conv_rw.hip", "umx_engine.hip", "umx_shard.hip", "umx_train_kernels.hip",
            "umx_train.hip"]
 HEADERS = ["umx_kernels.h", os.path.join("..", "..", "include", "umx.h"), os.path.join("..", "..", "include", "umx_train.h")]
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")

@@ -1231,6 +1231,14 @@ TileGeom geom_of(const umx_hparams& hp, int H, int W) {
 
 }  // namespace
 
+// ---- accessors for umx_shard.hip (same shared object; hidden visibility)
+static void (*g_destroy_hook)(umx_ctx*) = nullptr;
+hipStream_t umx_internal_stream(umx_ctx* ctx) { return ctx->stream; }
+int umx_internal_device(umx_ctx* ctx) { return ctx->device; }
+void umx_internal_hp(const umx_ctx* ctx, umx_hparams* out) { *out = ctx->hp; }
+int umx_internal_fail(umx_ctx* ctx, int code, const char* msg) { return fail(ctx, code, "%s", msg); }
+void umx_internal_set_destroy_hook(void (*hook)(umx_ctx*)) { g_destroy_hook = hook; }
+
 extern "C" {
 
 const char* umx_version(void) { return "umx 0.1 (gfx950)"; }
@@ -1464,6 +1472,7 @@ int umx_precision_of(const umx_ctx* ctx) { return ctx ? ctx->precision : UMX_PRE
 void umx_destroy(umx_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    if (g_destroy_hook) g_destroy_hook(ctx);   // a communicator / buffers umx_shard_init attached to this context
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     for (auto& pe : ctx->pending) { hipEventDestroy(pe.a); hipEventDestroy(pe.b); }
     for (auto e : ctx->free_events) hipEventDestroy(e);

@@ -1,0 +1,352 @@
+// Whole-slide inference sharded over the GPUs of one node INSIDE the library: one process per GPU, RCCL over xGMI.
+// (SURVEY.md section 8(b) lists umx_infer_image_sharded in the C ABI; the reference itself is single-device,
+// UnMicst1-5.py:769.)  The schedule is the one unmicst_amd/sharding.py runs through torch.distributed -- and which the
+// gloo tests (tests/test_sharding_cpu.py, 2 and 3 ranks) and the 2/3-ranks-on-one-GPU test check bit for bit against a
+// single process:
+//   * patch rows are split into contiguous bands, one per rank; a rank holds only the image rows its tiles read;
+//   * the LAST patch row of a band is computed first and sent to the next rank (ncclSend / ncclRecv on a communication
+//     stream, hidden under the rest of the band's tiles): the 2*margin image rows below a band boundary are covered by
+//     patch rows pb-1 and pb;
+//   * the band is computed in slabs of patch rows; as soon as a slab's image rows are final they are stitched (tiles visited
+//     in ascending global index: bit-identical to a one-GPU run) and all-gathered (ncclAllGather on equal-size padded slabs)
+//     while the next slab's tiles run; the gathered rows are scattered into the [K, H, W] result every rank ends up with.
+// RCCL is not linked: the few nccl* entry points are resolved with dlopen / dlsym when a context is given a communicator,
+// from the librccl the process already holds (a Python caller has torch's) or from ROCm's.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/umx.h"
+
+// internal accessors exported by umx_engine.hip (hidden visibility: same shared object only)
+hipStream_t umx_internal_stream(umx_ctx* ctx);
+int umx_internal_device(umx_ctx* ctx);
+void umx_internal_hp(const umx_ctx* ctx, umx_hparams* out);
+int umx_internal_fail(umx_ctx* ctx, int code, const char* msg);
+void umx_internal_set_destroy_hook(void (*hook)(umx_ctx*));
+
+namespace {
+
+struct Rccl {
+    void* h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+};
+
+Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so"};
+        for (const char* n : names)
+            if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);          // the copy the process already uses (torch's)
+        if (!r.h)
+            if (const char* e = getenv("UMX_RCCL_PATH")) r.h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+        for (const char* n : names)
+            if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!r.h) r.h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!r.h) { r.err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return; }
+#define UMX_SYM(f) r.f = reinterpret_cast<decltype(r.f)>(dlsym(r.h, "nccl" #f)); if (!r.f) r.err = "librccl lacks nccl" #f;
+        UMX_SYM(GetUniqueId) UMX_SYM(CommInitRank) UMX_SYM(CommDestroy) UMX_SYM(Send) UMX_SYM(Recv) UMX_SYM(AllGather)
+        UMX_SYM(GroupStart) UMX_SYM(GroupEnd) UMX_SYM(GetErrorString)
+#undef UMX_SYM
+    });
+    return &r;
+}
+
+struct Buf { void* d = nullptr; size_t cap = 0; };
+
+struct Shard {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    hipStream_t comm_stream = nullptr;
+    std::vector<hipEvent_t> events;
+    Buf probs, slab, gathered;
+    std::vector<Buf> send;
+};
+
+std::map<umx_ctx*, Shard> g_shards;
+std::mutex g_mu;
+
+int fail(umx_ctx* ctx, int code, const std::string& msg) { return umx_internal_fail(ctx, code, msg.c_str()); }
+
+#define S_HIP(ctx, expr)                                                                                    \
+    do {                                                                                                    \
+        hipError_t e__ = (expr);                                                                            \
+        if (e__ != hipSuccess) return fail(ctx, e__ == hipErrorOutOfMemory ? UMX_ERR_OOM : UMX_ERR_HIP,     \
+                                           std::string(#expr " failed: ") + hipGetErrorString(e__));        \
+    } while (0)
+#define S_NCCL(ctx, expr)                                                                                   \
+    do {                                                                                                    \
+        ncclResult_t r__ = (expr);                                                                          \
+        if (r__ != ncclSuccess) return fail(ctx, UMX_ERR_HIP, std::string(#expr " failed: ") + rccl()->GetErrorString(r__)); \
+    } while (0)
+
+int grow(umx_ctx* ctx, Buf* b, size_t bytes) {
+    if (b->cap >= bytes) return UMX_OK;
+    if (b->d) { S_HIP(ctx, hipDeviceSynchronize()); S_HIP(ctx, hipFree(b->d)); b->d = nullptr; b->cap = 0; }
+    S_HIP(ctx, hipMalloc(&b->d, bytes ? bytes : 16));
+    b->cap = bytes;
+    return UMX_OK;
+}
+
+void release(Shard& s) {
+    if (s.comm && rccl()->CommDestroy) rccl()->CommDestroy(s.comm);
+    if (s.comm_stream) hipStreamDestroy(s.comm_stream);
+    for (auto e : s.events) hipEventDestroy(e);
+    for (Buf* b : {&s.probs, &s.slab, &s.gathered}) if (b->d) hipFree(b->d);
+    for (auto& b : s.send) if (b.d) hipFree(b.d);
+}
+
+void on_destroy(umx_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_shards.find(ctx);
+    if (it == g_shards.end()) return;
+    release(it->second);
+    g_shards.erase(it);
+}
+
+}  // namespace
+
+// ---- band geometry (the C twin of unmicst_amd/sharding.py: band_partition / owned_rows / needed_image_rows / slab_rows;
+// tests/test_abi.py compares the two over a grid of sizes)
+namespace umx_geom {
+
+void band(int npr, int world, int rank, int* pa, int* pb) {
+    const int active = std::min(world, npr);
+    const int base = active ? npr / active : 0, extra = active ? npr % active : 0;
+    int start = 0;
+    for (int r = 0; r <= rank; ++r) {
+        const int n = r < active ? base + (r < extra ? 1 : 0) : 0;
+        if (r == rank) { *pa = start; *pb = start + n; }
+        start += n;
+    }
+}
+
+void owned(int pa, int pb, int npr, int sub, int margin, int H, int* y0, int* y1) {
+    if (pa >= pb) { *y0 = *y1 = 0; return; }
+    *y0 = pa == 0 ? 0 : std::min(H, std::max(0, pa * sub - margin));
+    *y1 = pb == npr ? H : std::min(H, std::max(0, pb * sub - margin));
+}
+
+void needed(int pa, int pb, int sub, int margin, int patch, int H, int* r0, int* r1) {
+    if (pa >= pb) { *r0 = *r1 = 0; return; }
+    *r0 = std::max(0, pa * sub - margin);
+    *r1 = std::min(H, (pb - 1) * sub + patch - margin);
+}
+
+int cut(int pa, int pb, int n, int i) { return pa + (int)(((long long)(pb - pa) * i) / n); }
+
+void slab(int pa, int pb, int npr, int sub, int margin, int H, int n, int i, int* s0, int* s1) {
+    if (pa >= pb) { *s0 = *s1 = 0; return; }
+    int y0, y1;
+    owned(pa, pb, npr, sub, margin, H, &y0, &y1);
+    const int a = i == 0 ? y0 : std::min(y1, std::max(y0, cut(pa, pb, n, i) * sub - margin));
+    const int b = i == n - 1 ? y1 : std::min(y1, std::max(y0, cut(pa, pb, n, i + 1) * sub - margin));
+    *s0 = a;
+    *s1 = std::max(a, b);
+}
+
+}  // namespace umx_geom
+
+extern "C" {
+
+int umx_shard_unique_id(umx_unique_id* out) {
+    if (!out) return umx_internal_fail(nullptr, UMX_ERR_INVALID, "out is NULL");
+    Rccl* r = rccl();
+    if (!r->err.empty()) return umx_internal_fail(nullptr, UMX_ERR_HIP, r->err.c_str());
+    static_assert(sizeof(umx_unique_id) == sizeof(ncclUniqueId), "umx_unique_id must be ncclUniqueId-sized");
+    ncclUniqueId id;
+    ncclResult_t rc = r->GetUniqueId(&id);
+    if (rc != ncclSuccess) return umx_internal_fail(nullptr, UMX_ERR_HIP, r->GetErrorString(rc));
+    memcpy(out, &id, sizeof id);
+    return UMX_OK;
+}
+
+int umx_shard_init(umx_ctx* ctx, const umx_unique_id* id, int rank, int world) {
+    if (!ctx || !id) return umx_internal_fail(ctx, UMX_ERR_INVALID, "ctx / id is NULL");
+    if (world < 1 || rank < 0 || rank >= world) return umx_internal_fail(ctx, UMX_ERR_INVALID, "bad rank / world");
+    Rccl* r = rccl();
+    if (!r->err.empty()) return umx_internal_fail(ctx, UMX_ERR_HIP, r->err.c_str());
+    S_HIP(ctx, hipSetDevice(umx_internal_device(ctx)));
+    std::lock_guard<std::mutex> lk(g_mu);
+    umx_internal_set_destroy_hook(on_destroy);
+    Shard& s = g_shards[ctx];
+    if (s.comm) { release(s); s = Shard(); }
+    ncclUniqueId nid;
+    memcpy(&nid, id, sizeof nid);
+    S_NCCL(ctx, r->CommInitRank(&s.comm, world, nid, rank));
+    s.rank = rank;
+    s.world = world;
+    S_HIP(ctx, hipStreamCreateWithFlags(&s.comm_stream, hipStreamNonBlocking));
+    return UMX_OK;
+}
+
+int umx_shard_fini(umx_ctx* ctx) {
+    if (!ctx) return UMX_OK;
+    on_destroy(ctx);
+    return UMX_OK;
+}
+
+int umx_shard_plan(const umx_hparams* hpp, int H, int W, int rank, int world, int nslabs, int slab, int* patch_row0,
+                   int* patch_row1, int* need_row0, int* need_row1, int* own_row0, int* own_row1, int* slab_row0,
+                   int* slab_row1, int* nslabs_used) {
+    if (!hpp || hpp->imSize < 8 || H < 1 || W < 1 || world < 1 || rank < 0 || rank >= world)
+        return umx_internal_fail(nullptr, UMX_ERR_INVALID, "bad hp / H / W / rank / world");
+    const umx_hparams hp = *hpp;
+    const int margin = hp.imSize / 8, sub = hp.imSize - 2 * margin;
+    const int npr = (H + sub - 1) / sub;           // PI2D.setup, PartitionOfImage.py:49
+    int pa, pb;
+    umx_geom::band(npr, world, rank, &pa, &pb);
+    int n = std::max(1, nslabs);
+    for (int r = 0; r < world; ++r) {
+        int a, b;
+        umx_geom::band(npr, world, r, &a, &b);
+        if (b > a) n = std::min(n, b - a);
+    }
+    n = std::max(1, n);
+    if (slab < 0 || slab >= n) return umx_internal_fail(nullptr, UMX_ERR_INVALID, "slab index out of range");
+    int v0, v1;
+    if (patch_row0) *patch_row0 = pa;
+    if (patch_row1) *patch_row1 = pb;
+    umx_geom::needed(pa, pb, sub, margin, hp.imSize, H, &v0, &v1);
+    if (need_row0) *need_row0 = v0;
+    if (need_row1) *need_row1 = v1;
+    umx_geom::owned(pa, pb, npr, sub, margin, H, &v0, &v1);
+    if (own_row0) *own_row0 = v0;
+    if (own_row1) *own_row1 = v1;
+    umx_geom::slab(pa, pb, npr, sub, margin, H, n, slab, &v0, &v1);
+    if (slab_row0) *slab_row0 = v0;
+    if (slab_row1) *slab_row1 = v1;
+    if (nslabs_used) *nslabs_used = n;
+    return UMX_OK;
+}
+
+int umx_infer_image_sharded_dev(umx_ctx* ctx, const double* band_dev, int C_img, int H, int W, int band_row0, int band_rows,
+                                double mean, double stdv, int mode, int stitch, int nslabs, void* out_full_dev) {
+    if (!ctx) return umx_internal_fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    if (!out_full_dev || H < 1 || W < 1) return umx_internal_fail(ctx, UMX_ERR_INVALID, "bad out / H / W");
+    Shard* sp;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_shards.find(ctx);
+        if (it == g_shards.end() || !it->second.comm)
+            return umx_internal_fail(ctx, UMX_ERR_INVALID, "call umx_shard_init on this context first");
+        sp = &it->second;
+    }
+    Shard& s = *sp;
+    Rccl* r = rccl();
+    S_HIP(ctx, hipSetDevice(umx_internal_device(ctx)));
+    hipStream_t cs = umx_internal_stream(ctx), ms = s.comm_stream;
+    umx_hparams hp;
+    umx_internal_hp(ctx, &hp);
+    int npr = 0, npc = 0, rc;
+    if ((rc = umx_tile_grid(ctx, H, W, &npr, &npc, nullptr, nullptr))) return rc;
+    const int P = hp.imSize, K = hp.nClasses, margin = P / 8, sub = P - 2 * margin;
+    const size_t el = stitch == UMX_STITCH_FP32 ? 4 : 2;
+    const int world = s.world, rank = s.rank;
+    std::vector<int> A(world), B(world);
+    std::vector<int> active;
+    int n = std::max(1, nslabs);
+    for (int q = 0; q < world; ++q) {
+        umx_geom::band(npr, world, q, &A[q], &B[q]);
+        if (B[q] > A[q]) { active.push_back(q); n = std::min(n, B[q] - A[q]); }
+    }
+    n = std::max(1, n);
+    const int pa = A[rank], pb = B[rank];
+    const bool has_prev = pa < pb && pa > 0, has_next = pa < pb && pb < npr;
+    const int lo = has_prev ? pa - 1 : pa;
+    const size_t tile_f = (size_t)P * P * K, row_f = tile_f * npc;
+    if ((rc = grow(ctx, &s.probs, std::max<size_t>(1, (size_t)std::max(pb - lo, 0)) * row_f * sizeof(float)))) return rc;
+    float* const probs = (float*)s.probs.d;
+    const int nev = 4 + 2 * n;
+    while ((int)s.events.size() < nev) {
+        hipEvent_t e;
+        S_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        s.events.push_back(e);
+    }
+    hipEvent_t ev_in = s.events[0], ev_last = s.events[1], ev_halo = s.events[2], ev_done = s.events[3];
+    // the communication stream starts behind whatever the caller queued on the context's stream
+    S_HIP(ctx, hipEventRecord(ev_in, cs));
+    S_HIP(ctx, hipStreamWaitEvent(ms, ev_in, 0));
+    auto tiles = [&](int r0, int r1) -> int {
+        if (r1 <= r0) return UMX_OK;
+        return umx_band_tiles_dev(ctx, band_dev, C_img, H, W, band_row0, band_rows, mean, stdv, r0, r1,
+                                  probs + (size_t)(r0 - lo) * row_f);
+    };
+    if (pa < pb && (rc = tiles(pb - 1, pb))) return rc;            // last patch row first: the next rank waits for it
+    S_HIP(ctx, hipEventRecord(ev_last, cs));
+    S_HIP(ctx, hipStreamWaitEvent(ms, ev_last, 0));
+    if (has_next || has_prev) {
+        const int me = (int)(std::find(active.begin(), active.end(), rank) - active.begin());
+        S_NCCL(ctx, r->GroupStart());
+        if (has_next) S_NCCL(ctx, r->Send(probs + (size_t)(pb - 1 - lo) * row_f, row_f * sizeof(float), ncclUint8, active[me + 1], s.comm, ms));
+        if (has_prev) S_NCCL(ctx, r->Recv(probs, row_f * sizeof(float), ncclUint8, active[me - 1], s.comm, ms));
+        S_NCCL(ctx, r->GroupEnd());
+    }
+    S_HIP(ctx, hipEventRecord(ev_halo, ms));
+    if ((int)s.send.size() < n) s.send.resize(n);
+    {   // size the slab / gather buffers for the largest slab up front (no reallocation between enqueued operations)
+        int mx_all = 1, own_max = 1;
+        for (int i = 0; i < n; ++i)
+            for (int q = 0; q < world; ++q) {
+                int a, b;
+                umx_geom::slab(A[q], B[q], npr, sub, margin, H, n, i, &a, &b);
+                mx_all = std::max(mx_all, b - a);
+                if (q == rank) own_max = std::max(own_max, b - a);
+            }
+        if ((rc = grow(ctx, &s.gathered, (size_t)world * K * mx_all * W * el))) return rc;
+        if ((rc = grow(ctx, &s.slab, (size_t)K * own_max * W * el))) return rc;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (pa < pb && (rc = tiles(umx_geom::cut(pa, pb, n, i), std::min(umx_geom::cut(pa, pb, n, i + 1), pb - 1)))) return rc;
+        if (i == 0) S_HIP(ctx, hipStreamWaitEvent(cs, ev_halo, 0));   // the previous rank's last patch row feeds this band's first rows
+        int s0, s1;
+        umx_geom::slab(pa, pb, npr, sub, margin, H, n, i, &s0, &s1);
+        std::vector<int> ra(world), rb(world);
+        int mx = 1;
+        for (int q = 0; q < world; ++q) {
+            umx_geom::slab(A[q], B[q], npr, sub, margin, H, n, i, &ra[q], &rb[q]);
+            mx = std::max(mx, rb[q] - ra[q]);
+        }
+        const size_t plane_b = (size_t)mx * W * el, send_b = (size_t)K * plane_b;
+        if ((rc = grow(ctx, &s.send[i], send_b))) return rc;
+        if (s1 > s0) {
+            if ((rc = umx_stitch_dev(ctx, probs, lo, pb, H, W, mode, stitch, s0, s1, s.slab.d))) return rc;
+            for (int k = 0; k < K; ++k)     // compact [K][rows][W] -> padded [K][mx][W]
+                S_HIP(ctx, hipMemcpyAsync((char*)s.send[i].d + k * plane_b, (char*)s.slab.d + (size_t)k * (s1 - s0) * W * el,
+                                          (size_t)(s1 - s0) * W * el, hipMemcpyDeviceToDevice, cs));
+        }
+        hipEvent_t ev_s = s.events[4 + 2 * i];
+        S_HIP(ctx, hipEventRecord(ev_s, cs));
+        S_HIP(ctx, hipStreamWaitEvent(ms, ev_s, 0));
+        // (one gather buffer, reused slab after slab: gather i+1 is queued behind the scatter copies of gather i)
+        S_NCCL(ctx, r->AllGather(s.send[i].d, s.gathered.d, send_b, ncclUint8, s.comm, ms));
+        for (int q = 0; q < world; ++q)
+            for (int k = 0; k < K && rb[q] > ra[q]; ++k)
+                S_HIP(ctx, hipMemcpyAsync((char*)out_full_dev + ((size_t)k * H + ra[q]) * W * el,
+                                          (char*)s.gathered.d + (size_t)q * send_b + k * plane_b,
+                                          (size_t)(rb[q] - ra[q]) * W * el, hipMemcpyDeviceToDevice, ms));
+    }
+    S_HIP(ctx, hipEventRecord(ev_done, ms));
+    S_HIP(ctx, hipStreamWaitEvent(cs, ev_done, 0));   // the result is complete for whatever the caller queues next
+    return UMX_OK;
+}
+
+}  // extern "C"

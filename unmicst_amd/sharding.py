@@ -149,12 +149,16 @@ def _all_gather(gathered, padded, group):
 
 
 def infer_image_sharded(eng, d_band, band_row0: int, H: int, W: int, mean: float, std: float, mode: int, stitch: int,
-                        group=None, gather: bool = True, nslabs: int = 2):
+                        group=None, gather: bool = True, nslabs: int = 2, sync: bool = True):
     """Distributed whole-slide inference.  Every rank calls this with the image rows it holds.
 
     d_band: float64 tensor [C, band_rows, W] = image rows [band_row0, band_row0+band_rows) (must cover
     ``needed_image_rows`` of this rank's patch rows).  Returns the full [K, H, W] result on every rank
     (``gather=True``) or this rank's stitched band and its (y0, y1).
+
+    ``sync=False`` leaves out the two host-side fences (``eng.synchronize()`` after the first patch row and at the end): the
+    call then only ENQUEUES work -- a caller streaming several slides fences once, with ``eng.synchronize()``, which is also
+    where an UMX_ERR_RANGE of the split-precision path surfaces.
 
     Stream contract (GPU): the caller runs this function under a dedicated ``torch.cuda.Stream`` and has handed that
     stream's handle to the engine (``eng.set_stream(stream.cuda_stream)``; the legacy default stream is refused there),
@@ -198,7 +202,8 @@ def infer_image_sharded(eng, d_band, band_row0: int, H: int, W: int, mean: float
     reqs = []
     if pa < pb:
         tiles(pb - 1, pb)                       # last patch row first: the next rank is waiting for it
-        eng.synchronize()
+        if sync:
+            eng.synchronize()
     if has_next:
         reqs.append(_isend(probs[-npc:], glob(active[active.index(rank) + 1]), group))
     if has_prev:
@@ -234,5 +239,6 @@ def infer_image_sharded(eng, d_band, band_row0: int, H: int, W: int, mean: float
         for r, (a, b) in enumerate(rows):
             if b > a:
                 full[:, a:b] = g4[r, :, :b - a]
-    eng.synchronize()   # fence of the engine's stream: raises UmxError (e.g. UMX_ERR_RANGE of the split-precision path)
+    if sync:
+        eng.synchronize()   # fence of the engine's stream: raises UmxError (e.g. UMX_ERR_RANGE of the split-precision path)
     return full

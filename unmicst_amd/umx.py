@@ -26,7 +26,8 @@ EXPORTS = [
     "umx_device_count", "umx_device_mem_info", "umx_create", "umx_create_opts", "umx_precision_of", "umx_destroy", "umx_last_error", "umx_set_stream", "umx_synchronize",
     "umx_forward_tiles", "umx_forward_tiles_dev", "umx_tile_grid", "umx_infer_image", "umx_infer_image_dev",
     "umx_infer_image_raw", "umx_infer_image_raw_submit", "umx_infer_image_wait", "umx_tiff_lzw_decode",
-    "umx_tiff_packbits_decode",
+    "umx_tiff_packbits_decode", "umx_shard_unique_id", "umx_shard_init", "umx_shard_fini", "umx_shard_plan",
+    "umx_infer_image_sharded_dev",
     "umx_band_tiles_dev", "umx_stitch_dev", "umx_profile_enable", "umx_profile_read", "umx_test_double_to_half",
     "umx_describe", "umx_version",
 ]
@@ -126,6 +127,17 @@ def load(path: Optional[str] = None):
                                              c_int, c_void_p]
     L.umx_infer_image_wait.restype = c_int
     L.umx_infer_image_wait.argtypes = [c_void_p, c_int]
+    L.umx_shard_unique_id.restype = c_int
+    L.umx_shard_unique_id.argtypes = [c_void_p]
+    L.umx_shard_init.restype = c_int
+    L.umx_shard_init.argtypes = [c_void_p, c_void_p, c_int, c_int]
+    L.umx_shard_fini.restype = c_int
+    L.umx_shard_fini.argtypes = [c_void_p]
+    L.umx_shard_plan.restype = c_int
+    L.umx_shard_plan.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 9
+    L.umx_infer_image_sharded_dev.restype = c_int
+    L.umx_infer_image_sharded_dev.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_int,
+                                              c_int, c_int, c_void_p]
     for fn in (L.umx_tiff_lzw_decode, L.umx_tiff_packbits_decode):
         fn.restype = ctypes.c_longlong
         fn.argtypes = [c_void_p, ctypes.c_size_t, c_void_p, ctypes.c_size_t]
@@ -203,6 +215,18 @@ def tiff_decode(kind: str, buf: bytes, nbytes: int) -> bytes:
     return out.raw
 
 
+def shard_plan(hp: HParams, H: int, W: int, rank: int, world: int, nslabs: int = 2, slab: int = 0) -> dict:
+    """umx_shard_plan: band / slab geometry of one rank (needs no device)."""
+    L = load()
+    v = [ctypes.c_int() for _ in range(9)]
+    h = _hp_struct(hp)
+    rc = L.umx_shard_plan(ctypes.byref(h), H, W, int(rank), int(world), int(nslabs), int(slab), *[ctypes.byref(x) for x in v])
+    if rc:
+        raise UmxError(rc, L.umx_last_error(None).decode())
+    names = ("patch_row0", "patch_row1", "need_row0", "need_row1", "own_row0", "own_row1", "slab_row0", "slab_row1", "nslabs")
+    return {n: x.value for n, x in zip(names, v)}
+
+
 class Engine:
     """One umx_ctx: a model resident on one MI355X."""
 
@@ -248,6 +272,27 @@ class Engine:
             raise UmxError(rc, self._L.umx_last_error(self._ctx).decode())
 
     # -- plumbing
+    # -- multi-GPU inside the library (RCCL over xGMI): see include/umx.h
+    @staticmethod
+    def shard_unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        rc = load().umx_shard_unique_id(buf)
+        if rc:
+            raise UmxError(rc, load().umx_last_error(None).decode())
+        return buf.raw
+
+    def shard_init(self, unique_id: bytes, rank: int, world: int) -> None:
+        self._check(self._L.umx_shard_init(self._ctx, ctypes.create_string_buffer(unique_id, 128), int(rank), int(world)))
+
+    def shard_plan(self, H: int, W: int, rank: int, world: int, nslabs: int = 2, slab: int = 0) -> dict:
+        return shard_plan(self.hp, H, W, rank, world, nslabs, slab)
+
+    def infer_image_sharded_dev(self, band_ptr: int, C: int, H: int, W: int, band_row0: int, band_rows: int, mean: float,
+                                std: float, mode: int, stitch: int, nslabs: int, out_full_ptr: int) -> None:
+        self._check(self._L.umx_infer_image_sharded_dev(self._ctx, ctypes.c_void_p(band_ptr), C, H, W, int(band_row0),
+                                                        int(band_rows), float(mean), float(std), int(mode), int(stitch),
+                                                        int(nslabs), ctypes.c_void_p(out_full_ptr)))
+
     def set_stream(self, hip_stream) -> None:
         """Run the engine's launches on the caller's HIP stream (a non-zero hipStream_t handle, e.g.
         ``torch.cuda.Stream().cuda_stream``); ``None`` restores the engine's own stream.  The legacy default stream
