@@ -141,6 +141,13 @@ UMX_API int umx_infer_image_dev(umx_ctx* ctx, const double* image_dev, int C_img
 UMX_API int umx_infer_image_raw(umx_ctx* ctx, const void* raw_host, int bits, int C_img, int H, int W, int rescale,
                         double mean, double std, int mode, uint8_t* out_host);
 
+/* The same recipe at --scalingFactor != 1 (reference UnMicst1-5.py:813-816: resize to (int(H*sf), int(W*sf)) before the
+ * inference, :850: resize of the uint8 planes back to (H, W)), with skimage.transform.resize's defaults -- order 1, mode
+ * 'reflect', anti-aliasing Gaussian on shrinking axes, clip to the input range -- evaluated in float64 on the device.
+ * rescale != 0: rescale_intensity of the RESIZED plane to (0, 0.983).  scaling == 1 is umx_infer_image_raw. */
+UMX_API int umx_infer_image_raw_scaled(umx_ctx* ctx, const void* raw_host, int bits, int C_img, int H, int W, double scaling,
+                                       int rescale, double mean, double std, int mode, uint8_t* out_host);
+
 /* How the host entry points move data: the slide goes up and the planes come down in the launch groups of the tile loop,
  * on two copy streams, under the tile kernels of the neighbouring groups (pinned host buffers make these true DMA; pageable
  * ones are staged by HIP and still correct).  A stream of slides -- the drivers' per-file loop, reference

@@ -150,6 +150,14 @@ class _OracleEngine:
         pm = self.infer_image(image, mean, std, mode)
         return np.stack([imtools.to_uint8_via_resize(pm[k], pm.shape[1:]) for k in range(pm.shape[0])])
 
+    def infer_image_raw_scaled(self, raw, scaling, rescale, mean, std, mode=0):
+        """Host restatement of umx_infer_image_raw_scaled: the drivers' general recipe (driver.preprocess / to_uint8_via_resize)."""
+        planes = raw[None] if raw.ndim == 2 else raw
+        pre = [driver.preprocess(p, scaling, -1)[1 if rescale else 0] for p in planes]
+        image = np.stack(pre) if raw.ndim == 3 else pre[0]
+        pm = self.infer_image(image, mean, std, mode)
+        return np.stack([imtools.to_uint8_via_resize(pm[k], planes[0].shape) for k in range(pm.shape[0])])
+
     def close(self):
         pass
 

@@ -175,3 +175,25 @@ def test_duo_script_on_a_two_page_ome_tiff_4096(tmp_path):
     for page in range(3):
         assert np.array_equal(got[page], want[page]), page
     assert np.array_equal(prev[0], want[1])
+
+
+@pytest.mark.parametrize("scaling,rescale", [(0.5, True), (0.75, False), (1.6, True)])
+def test_scaled_raw_path_matches_the_host_recipe(scaling, rescale):
+    """--scalingFactor != 1 on the device (umx_infer_image_raw_scaled: skimage.transform.resize's defaults restated in
+    float64 kernels, both ways) against the host-side recipe (unmicst_amd/imtools.py: scipy.ndimage gaussian_filter + zoom):
+    the resized input agrees to ~1e-15, so the uint8 planes differ at most where a value sits on a truncation boundary or a
+    tile probability moves an fp16 ulp -- <= 1 LSB, and almost nowhere."""
+    from unmicst_amd import imtools
+    hp, blob, mean, std = helpers.load_nuclei_dapi()
+    raw = helpers.load_sample_105()[0][:400, :520]
+    UNet2D.setupWithArtefacts(model.ModelArtefacts(hp, blob, mean, std))
+    try:
+        got = UNet2D.singleImageInferenceRawScaled(raw, scaling, rescale)
+        pre = driver.preprocess(raw, scaling, -1)[1 if rescale else 0]
+        want = np.stack([imtools.to_uint8_via_resize(UNet2D.singleImageInference(pre, "accumulate", k), raw.shape)
+                         for k in range(hp.nClasses)])
+    finally:
+        UNet2D.singleImageInferenceCleanup()
+    assert got.shape == want.shape == (hp.nClasses,) + raw.shape and got.dtype == np.uint8
+    d = np.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= 1 and (d == 0).mean() > 0.995, (d.max(), (d == 0).mean())

@@ -1828,6 +1828,89 @@ int umx_infer_image_raw(umx_ctx* ctx, const void* raw_host, int bits, int C_img,
     return infer_host(ctx, raw_host, bits, C_img, H, W, rescale, mean, stdv, mode, UMX_STITCH_FP16_COMPAT, 1, out_host);
 }
 
+// ---- the drivers' whole recipe at --scalingFactor != 1 on the device (reference UnMicst1-5.py:807-821,845-854):
+// raw planes -> im2double -> resize to (int(H*sf), int(W*sf)) -> [rescale_intensity((min, max) -> (0, 0.983))] -> inference
+// -> np.uint8(255 * pm) -> resize back to (H, W) -> np.uint8(255 * .).  One resize = skimage.transform.resize's defaults
+// (umx_kernels.hip).  Synchronous; the planes are small next to the tile work, so nothing is pipelined here.
+static int resize_plane(umx_ctx* ctx, const double* src, int H, int W, int h, int w, double* tmpA, double* tmpB, double* wdev,
+                        unsigned long long* mm64, double* dst, unsigned char* dst_u8) {
+    const double* cur = src;
+    const double fy = (double)H / h, fx = (double)W / w;
+    const double sig[2] = {std::max(0.0, (fy - 1.0) / 2.0), std::max(0.0, (fx - 1.0) / 2.0)};
+    if (h < H || w < W) {   // anti-aliasing Gaussian, axis by axis (scipy.ndimage.gaussian_filter: axis 0 first)
+        double* bufs[2] = {tmpA, tmpB};
+        int which = 0;
+        for (int axis = 0; axis < 2; ++axis) {
+            if (!(sig[axis] > 1e-15)) continue;   // scipy skips axes with sigma <= 1e-15
+            const int radius = (int)(4.0 * sig[axis] + 0.5);
+            std::vector<double> wts((size_t)radius + 1);
+            double sum = 0.0;
+            std::vector<double> full(2 * (size_t)radius + 1);
+            for (int x = -radius; x <= radius; ++x) full[x + radius] = std::exp(-0.5 / (sig[axis] * sig[axis]) * (double)x * (double)x);
+            for (double v : full) sum += v;
+            for (int j = 0; j <= radius; ++j) wts[j] = full[radius + j] / sum;
+            if (radius + 1 > 4096) return fail(ctx, UMX_ERR_INVALID, "scaling factor too small for the resize kernel");
+            HIP_TRY(ctx, hipMemcpyAsync(wdev + axis * 4096, wts.data(), wts.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // (wts is a stack-lifetime host buffer)
+            HIP_TRY(ctx, launch_gauss1d(cur, bufs[which], H, W, axis, radius, wdev + axis * 4096, ctx->stream));
+            cur = bufs[which];
+            which ^= 1;
+        }
+    }
+    HIP_TRY(ctx, launch_minmax_f64(cur, (size_t)H * W, mm64, ctx->stream));   // resize clips to the (filtered) input's range
+    HIP_TRY(ctx, launch_zoom1(cur, H, W, h, w, mm64, dst, dst_u8, ctx->stream));
+    return UMX_OK;
+}
+
+int umx_infer_image_raw_scaled(umx_ctx* ctx, const void* raw_host, int bits, int C_img, int H, int W, double scaling, int rescale,
+                               double mean, double stdv, int mode, uint8_t* out_host) {
+    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    if (!raw_host || !out_host || H < 1 || W < 1 || C_img < 1) return fail(ctx, UMX_ERR_INVALID, "bad image/out/H/W");
+    if (bits != 8 && bits != 16) return fail(ctx, UMX_ERR_INVALID, "raw planes must be uint8 or uint16 (bits = %d)", bits);
+    if (C_img != 1 && C_img != ctx->hp.nChannels)
+        return fail(ctx, UMX_ERR_INVALID, "image has %d channels, model wants 1 or %d", C_img, ctx->hp.nChannels);
+    if (!(stdv != 0.0)) return fail(ctx, UMX_ERR_INVALID, "std must be non-zero");
+    if (!(scaling > 0.0)) return fail(ctx, UMX_ERR_INVALID, "scaling factor must be positive");
+    const int h = (int)((double)H * scaling), w = (int)((double)W * scaling);   // int(float(I.shape[0]) * float(sf))
+    if (h < 1 || w < 1) return fail(ctx, UMX_ERR_INVALID, "scaled image is empty");
+    if (h == H && w == W) return umx_infer_image_raw(ctx, raw_host, bits, C_img, H, W, rescale, mean, stdv, mode, out_host);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t big = (size_t)std::max(H, h) * std::max(W, w), plane = (size_t)H * W, sp = (size_t)h * w, K = ctx->hp.nClasses;
+    const size_t in_b = bits / 8;
+    // scratch: [raw upload | 3 float64 work planes of the larger size | scaled input planes | fp16 result | u8 out | weights | mm]
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_raw = take(plane * C_img * in_b), o_a = take(big * 8), o_b = take(big * 8), o_c = take(big * 8);
+    const size_t o_in = take(sp * C_img * 8), o_pm = take(K * sp * 2), o_u8 = take(K * plane), o_w = take(2 * 4096 * 8), o_mm = take(256);
+    int rc;
+    umx_ctx::HostSlot& hs = ctx->hs[0];
+    if (hs.busy) return fail(ctx, UMX_ERR_INVALID, "slot 0 still holds a submitted call: wait for it first");
+    if ((rc = grow(ctx, &hs.d_out, &hs.out_cap, off))) return rc;
+    unsigned char* const base = (unsigned char*)hs.d_out;
+    double *A = (double*)(base + o_a), *B = (double*)(base + o_b), *Cw = (double*)(base + o_c), *din = (double*)(base + o_in);
+    double* const wdev = (double*)(base + o_w);
+    unsigned long long* const mm64 = (unsigned long long*)(base + o_mm);
+    unsigned* const mm32 = (unsigned*)(base + o_mm + 64);
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_raw, raw_host, plane * C_img * in_b, hipMemcpyHostToDevice, ctx->stream));
+    for (int c = 0; c < C_img; ++c) {
+        HIP_TRY(ctx, launch_minmax_init(mm32, ctx->stream));
+        HIP_TRY(ctx, launch_raw_convert(base + o_raw + (size_t)c * plane * in_b, bits, plane, 0, mm32, A, ctx->stream));   // im2double
+        if ((rc = resize_plane(ctx, A, H, W, h, w, B, Cw, wdev, mm64, din + (size_t)c * sp, nullptr))) return rc;
+        if (rescale) {   // rescale_intensity(I, (min, max), (0, 0.983)) of the RESIZED plane (UnMicst1-5.py:817-821)
+            HIP_TRY(ctx, launch_minmax_f64(din + (size_t)c * sp, sp, mm64, ctx->stream));
+            HIP_TRY(ctx, launch_rescale_f64(din + (size_t)c * sp, sp, mm64, ctx->stream));
+        }
+    }
+    if ((rc = umx_infer_image_dev(ctx, din, C_img, h, w, mean, stdv, mode, UMX_STITCH_FP16_COMPAT, base + o_pm))) return rc;
+    for (size_t k = 0; k < K; ++k) {
+        HIP_TRY(ctx, launch_half_to_u8_f64(base + o_pm + k * sp * 2, sp, A, ctx->stream));   // np.uint8(255 * pm) as float u8/255
+        if ((rc = resize_plane(ctx, A, h, w, H, W, B, Cw, wdev, mm64, nullptr, base + o_u8 + k * plane))) return rc;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(out_host, base + o_u8, K * plane, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return check_range_flag(ctx);
+}
+
 int umx_infer_image_raw_submit(umx_ctx* ctx, int slot, const void* raw_host, int bits, int C_img, int H, int W, int rescale,
                                double mean, double stdv, int mode, uint8_t* out_host) {
     if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");

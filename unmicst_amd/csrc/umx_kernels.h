@@ -180,6 +180,14 @@ hipError_t launch_minmax(const void* raw, int bits, size_t n, unsigned* mm, hipS
 hipError_t launch_raw_convert(const void* raw, int bits, size_t n, int rescale, const unsigned* mm, double* out,
                               hipStream_t stream);
 hipError_t launch_half_to_u8(const void* pm_half, size_t n, unsigned char* out, hipStream_t stream);
+// skimage.transform.resize on the device (float64; umx_kernels.hip): separable Gaussian, range reduce, order-1 zoom + clip
+hipError_t launch_gauss1d(const double* src, double* dst, int H, int W, int axis, int radius, const double* w_dev,
+                          hipStream_t stream);
+hipError_t launch_minmax_f64(const double* x, size_t n, unsigned long long* mm64, hipStream_t stream);
+hipError_t launch_zoom1(const double* src, int H, int W, int h, int w, const unsigned long long* clip, double* dst,
+                        unsigned char* out_u8, hipStream_t stream);
+hipError_t launch_rescale_f64(double* x, size_t n, const unsigned long long* mm64, hipStream_t stream);
+hipError_t launch_half_to_u8_f64(const void* pm_half, size_t n, double* out, hipStream_t stream);
 
 
 // ---- training step (umx_train_kernels.hip): fp32 everywhere, reductions in fp64 with a fixed summation order ----------

@@ -640,6 +640,135 @@ hipError_t launch_raw_to_double(const void* raw, int bits, size_t n, int rescale
     return launch_raw_convert(raw, bits, n, rescale, mm, out, stream);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// skimage.transform.resize(I, (h, w)) with its defaults (order 1, mode 'reflect' -> scipy 'mirror', anti-aliasing
+// Gaussian when an axis shrinks, clip to the filtered image's range), as the drivers call it around the inference at
+// --scalingFactor != 1 (reference UnMicst1-5.py:813-816,850; toolbox/imtools.py:8).  Restated from scikit-image >= 0.19:
+//   sigma = max(0, (in/out - 1) / 2) per axis; scipy.ndimage.gaussian_filter (truncate 4: radius int(4 sigma + 0.5),
+//   weights exp(-x^2 / (2 sigma^2)) / sum, mode 'mirror': d c b | a b c d | c b a), then scipy.ndimage.zoom(order 1,
+//   mode 'mirror', grid_mode True): input coordinate (o + 0.5) * in / out - 0.5, linear interpolation.
+// float64 throughout, same operation order as scipy's correlate1d (centre tap, then symmetric pairs from the outside in).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int mirror_index(int i, int n) {   // scipy 'mirror' (reflect about the edge sample)
+    if (n == 1) return 0;
+    const int period = 2 * n - 2;
+    i %= period;
+    if (i < 0) i += period;
+    return i < n ? i : period - i;
+}
+
+// one axis of the separable Gaussian: dst[y][x] = sum_j w[j] * src[.. +- j ..]; axis 0 = rows (y), 1 = columns (x)
+__global__ void __launch_bounds__(256) gauss1d_kernel(const double* __restrict__ src, double* __restrict__ dst, int H, int W,
+                                                     int axis, int radius, const double* __restrict__ w /* [radius+1], w[0] = centre */) {
+    const size_t n = (size_t)H * W;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(e / W), x = (int)(e - (size_t)y * W);
+        double acc = src[e] * w[0];
+        for (int j = radius; j >= 1; --j) {
+            double a, b;
+            if (axis == 0) {
+                a = src[(size_t)mirror_index(y - j, H) * W + x];
+                b = src[(size_t)mirror_index(y + j, H) * W + x];
+            } else {
+                a = src[(size_t)y * W + mirror_index(x - j, W)];
+                b = src[(size_t)y * W + mirror_index(x + j, W)];
+            }
+            acc += (a + b) * w[j];
+        }
+        dst[e] = acc;
+    }
+}
+
+// (min, max) of non-negative doubles as ordered bit patterns (mm64[0] = min, mm64[1] = max; initialise to ~0 / 0)
+__global__ void __launch_bounds__(256) minmax_f64_kernel(const double* __restrict__ x, size_t n, unsigned long long* __restrict__ mm64) {
+    unsigned long long lo = ~0ull, hi = 0ull;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(x[i]);
+        lo = b < lo ? b : lo;
+        hi = b > hi ? b : hi;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&mm64[0], lo); atomicMax(&mm64[1], hi); }
+}
+
+// order-1 zoom (grid mode, mirror) of src [H,W] -> [h,w], clipped to [clip[0], clip[1]] (bit patterns of the source range);
+// out_u8 != NULL: the drivers' final np.uint8(255 * .) instead of the float64 plane
+__global__ void __launch_bounds__(256) zoom1_kernel(const double* __restrict__ src, int H, int W, int h, int w,
+                                                   const unsigned long long* __restrict__ clip, double* __restrict__ dst,
+                                                   unsigned char* __restrict__ out_u8) {
+    const double lo = __longlong_as_double((long long)clip[0]), hi = __longlong_as_double((long long)clip[1]);
+    const double zy = (double)H / (double)h, zx = (double)W / (double)w;
+    const size_t n = (size_t)h * w;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int oy = (int)(e / w), ox = (int)(e - (size_t)oy * w);
+        const double cy = ((double)oy + 0.5) * zy - 0.5, cx = ((double)ox + 0.5) * zx - 0.5;
+        const double fy = floor(cy), fx = floor(cx);
+        const double ty = cy - fy, tx = cx - fx;
+        const int y0 = mirror_index((int)fy, H), y1 = mirror_index((int)fy + 1, H);
+        const int x0 = mirror_index((int)fx, W), x1 = mirror_index((int)fx + 1, W);
+        // scipy's separable evaluation: rows weighted (1-ty, ty), columns (1-tx, tx), accumulated in this order
+        double v = 0.0;
+        v += src[(size_t)y0 * W + x0] * (1.0 - ty) * (1.0 - tx);   // value * w_axis0 * w_axis1, C order of the 2x2 support
+        v += src[(size_t)y0 * W + x1] * (1.0 - ty) * tx;
+        v += src[(size_t)y1 * W + x0] * ty * (1.0 - tx);
+        v += src[(size_t)y1 * W + x1] * ty * tx;
+        v = fmin(fmax(v, lo), hi);
+        if (out_u8) out_u8[e] = (unsigned char)(int)(255.0 * v);
+        else dst[e] = v;
+    }
+}
+
+// rescale_intensity(I, in_range = (min, max) from mm64, out_range = (0, 0.983)) in place (reference UnMicst1-5.py:817-821)
+__global__ void __launch_bounds__(256) rescale_f64_kernel(double* __restrict__ x, size_t n, const unsigned long long* __restrict__ mm64) {
+    const double lo = __longlong_as_double((long long)mm64[0]), hi = __longlong_as_double((long long)mm64[1]);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double v = fmin(fmax(x[i], lo), hi);
+        if (lo != hi) v = ((v - lo) / (hi - lo)) * 0.983;
+        else v = fmin(fmax(v, 0.0), 0.983);
+        x[i] = v;
+    }
+}
+
+// uint8 plane -> float64 u8 * (1/255) (resize's img_as_float), or float16 plane -> np.uint8(255 * pm) -> same
+__global__ void __launch_bounds__(256) half_to_u8_f64_kernel(const __half* __restrict__ pm, size_t n, double* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const __half p255 = __hmul(__float2half_rn(255.f), pm[i]);
+        out[i] = (double)(unsigned char)(int)__half2float(p255) * (1.0 / 255);
+    }
+}
+
+static unsigned blocks_for(size_t n) { return (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16); }
+
+hipError_t launch_gauss1d(const double* src, double* dst, int H, int W, int axis, int radius, const double* w_dev,
+                          hipStream_t stream) {
+    hipLaunchKernelGGL(gauss1d_kernel, dim3(blocks_for((size_t)H * W)), dim3(256), 0, stream, src, dst, H, W, axis, radius, w_dev);
+    return hipGetLastError();
+}
+hipError_t launch_minmax_f64(const double* x, size_t n, unsigned long long* mm64, hipStream_t stream) {
+    const unsigned long long init[2] = {~0ull, 0ull};
+    hipError_t e = hipMemcpyAsync(mm64, init, sizeof init, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(minmax_f64_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, x, n, mm64);
+    return hipGetLastError();
+}
+hipError_t launch_zoom1(const double* src, int H, int W, int h, int w, const unsigned long long* clip, double* dst,
+                        unsigned char* out_u8, hipStream_t stream) {
+    hipLaunchKernelGGL(zoom1_kernel, dim3(blocks_for((size_t)h * w)), dim3(256), 0, stream, src, H, W, h, w, clip, dst, out_u8);
+    return hipGetLastError();
+}
+hipError_t launch_rescale_f64(double* x, size_t n, const unsigned long long* mm64, hipStream_t stream) {
+    hipLaunchKernelGGL(rescale_f64_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, x, n, mm64);
+    return hipGetLastError();
+}
+hipError_t launch_half_to_u8_f64(const void* pm_half, size_t n, double* out, hipStream_t stream) {
+    hipLaunchKernelGGL(half_to_u8_f64_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, (const __half*)pm_half, n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_half_to_u8(const void* pm_half, size_t n, unsigned char* out, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
