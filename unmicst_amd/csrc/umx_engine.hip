@@ -576,7 +576,7 @@ int upload_raw(umx_ctx* ctx, const std::vector<T>& h, T** out) {
 // at >= 16x16 resolution with a fused softmax head, one N-block, and a packed weight set small enough for the register
 // file.  All (tap, octet) pairs of all operand groups form ONE k-step list; the LDS image of a tile holds every octet of
 // every group side by side (pixel pitch OCT*16 bytes, OCT odd: conflict-free fragment reads).
-int plan_rw(umx_ctx* ctx, Launch& L, float wscale, std::string* why) {
+int plan_rw(umx_ctx* ctx, Launch& L, float wscale, const Launch* head, std::string* why) {
     (void)why;
     L.use_rw = false;
     const HConvParams& h = L.hcp;
@@ -620,7 +620,40 @@ int plan_rw(umx_ctx* ctx, Launch& L, float wscale, std::string* why) {
     r.tx_log2 = lg2(tx); r.ty_log2 = lg2(ty);
     r.nk = nk;
     r.act = L.act; r.head_K = h.head_K;
+    r.post_affine = (!L.post_s.empty() || !L.post_b.empty()) ? 1 : 0;
     r.econst = h.econst;
+    {   // the fused 1x1 head as MFMA A-fragments (rows = classes): ceil(NT/2) k-steps, k-step s covers N-tiles (2s, 2s+1);
+        // lane (q, class) element j < 4 -> channel 16*(2s) + 4q + j, j >= 4 -> channel 16*(2s+1) + 4q + j - 4: exactly the
+        // channels a lane of group q holds in its accumulators of those two N-tiles, so the activations need no shuffle.
+        // Weights are scaled by 2^hs (their lo parts stay normal binary16); the head's BN scale absorbs 2^-hs.
+        if (!head || (int)head->head_w.size() != L.Cout * head->head_K) return UMX_OK;
+        const int K = head->head_K, hks = (h.NT + 1) / 2;
+        float mx = 0.f;
+        for (float v : head->head_w) mx = std::max(mx, std::fabs(v));
+        int hsft = 0;
+        if (mx > 0.f && std::isfinite(mx)) { int e; std::frexp(mx, &e); hsft = std::max(-24, std::min(30, 14 - e)); }
+        const float hscale = std::ldexp(1.f, hsft);
+        std::vector<_Float16> HF((size_t)hks * 2 * 512, (_Float16)0.f);
+        for (int s2 = 0; s2 < hks; ++s2)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int cls = lane & 15, qq = lane >> 4;
+                if (cls >= K) continue;
+                for (int j = 0; j < 8; ++j) {
+                    const int nt = 2 * s2 + (j >> 2);
+                    const int c = nt * 16 + 4 * qq + (j & 3);
+                    if (nt >= h.NT || c >= L.Cout) continue;
+                    const float v = head->head_w[(size_t)c * K + cls] * hscale;
+                    const _Float16 hi = (_Float16)v;
+                    HF[((size_t)s2 * 2 + 0) * 512 + lane * 8 + j] = hi;
+                    HF[((size_t)s2 * 2 + 1) * 512 + lane * 8 + j] = (_Float16)(v - (float)hi);
+                }
+            }
+        _Float16* dh = nullptr;
+        int rc3;
+        if ((rc3 = upload_raw(ctx, HF, &dh))) return rc3;
+        r.head_frag = reinterpret_cast<const uint4*>(dh);
+        r.head_unscale = std::ldexp(1.f, -hsft);
+    }
     // k-step list: group-major, tap-major, octet-minor; the tail is padded with zero-weight pairs on a loaded slot
     struct P { int gi, tap, oct; };
     std::vector<P> pairs;
@@ -979,7 +1012,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         h.ph[list].w = reinterpret_cast<const uint4*>(d);
     }
     L.exec_flops = 2.0 * 3.0 * (double)L.n_ksteps * 32.0 * Np16 * L.H * L.W;   // MFMA work incl. split and padding
-    return plan_rw(ctx, L, wscale, why);
+    return plan_rw(ctx, L, wscale, head, why);
 }
 
 int grow(umx_ctx* ctx, void** buf, size_t* cap, size_t bytes) {
@@ -1123,6 +1156,7 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
         r.B = ns;
         for (int gi = 0; gi < L.ngroups; ++gi) { r.src_hi[gi] = p.src_hi[gi]; r.src_lo[gi] = p.src_lo[gi]; r.Cs[gi] = p.Cs[gi]; }
         r.probs = p.probs;
+        r.overflow_flag = ctx->d_flag;
         r.ntiles = ns << (r.tx_log2 + r.ty_log2);
         snprintf(kn, sizeof kn, "conv_rw<%d, %d>", L.nt16, r.nk);
         ProfScope ps(ctx, site_of(ctx, L.name, kn), L.flops * ns, L.bytes * ns, L.exec_flops * ns);

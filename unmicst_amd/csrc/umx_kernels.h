@@ -145,7 +145,11 @@ struct RwParams {
     const uint4* w;              // [nk][NT][hi|lo][64 lanes] x 16 B: MFMA A-fragments
     const uint4* econst;         // as HConvParams::econst (one N-block)
     int act, head_K;
+    int post_affine;             // 1: a second affine follows the activation (legacy graph: BN after ReLU)
     float* probs;                // fused 1x1 head + BN + softmax output, NHWC [B,H,W,head_K]
+    const uint4* head_frag;      // the 1x1 head as MFMA A-fragments: [ceil(NT/2) k-steps][hi|lo][64 lanes] x 16 B (rows = classes)
+    float head_unscale;          // 2^-hs: the head weights are stored times 2^hs
+    int* overflow_flag;          // set when an activation feeding the head leaves binary16's range
 };
 bool conv_rw_supported(int NT, int NK);
 hipError_t launch_conv_rw(const RwParams& p, int NT, int ncu, hipStream_t stream);
