@@ -300,13 +300,17 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
     // epilogue arithmetic in place; the constants come from LDS (4 consecutive channels = one float4 per array)
-    bool big = false;
+    float vmax = 0.f;   // max |v| of this lane: one compare against binary16's range at the end
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const float4 ps = ec4[0 * NT * 4 + n * 4 + q], pb = ec4[1 * NT * 4 + n * 4 + q];
-        const float4 qs = ec4[2 * NT * 4 + n * 4 + q], qb = ec4[3 * NT * 4 + n * 4 + q];
         const float psa[4] = {ps.x, ps.y, ps.z, ps.w}, pba[4] = {pb.x, pb.y, pb.z, pb.w};
-        const float qsa[4] = {qs.x, qs.y, qs.z, qs.w}, qba[4] = {qb.x, qb.y, qb.z, qb.w};
+        float qsa[4] = {1.f, 1.f, 1.f, 1.f}, qba[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.post_affine) {   // only the legacy graph (BN after ReLU) and a non-zero activation shift have a second affine
+            const float4 qs = ec4[2 * NT * 4 + n * 4 + q], qb = ec4[3 * NT * 4 + n * 4 + q];
+            qsa[0] = qs.x; qsa[1] = qs.y; qsa[2] = qs.z; qsa[3] = qs.w;
+            qba[0] = qb.x; qba[1] = qb.y; qba[2] = qb.z; qba[3] = qb.w;
+        }
 #pragma unroll
         for (int h = 0; h < NPH; ++h)
 #pragma unroll
@@ -315,9 +319,9 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
                 for (int r = 0; r < 4; ++r) {
                     float v = accs[h][m][n][r] * psa[r] + pba[r];
                     if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.2f * v;
-                    v = v * qsa[r] + qba[r];
-                    big |= !(fabsf(v) < 60000.f);
+                    else if (p.act == ACT_LEAKY) v = fmaxf(v, 0.2f * v);   // == v > 0 ? v : 0.2 v
+                    if (p.post_affine) v = v * qsa[r] + qba[r];
+                    vmax = fmaxf(vmax, fabsf(v));
                     accs[h][m][n][r] = v;
                 }
         if constexpr (NPH == 1) {
@@ -335,6 +339,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
             }
         }
     }
+    const bool big = !(vmax < 60000.f);   // (also true for a NaN)
     if (big && p.dst_f32 == nullptr && p.head_K == 0) atomicOr(p.overflow_flag, 1);   // binary16 range exceeded: the host reports it
 
     if constexpr (NPH == 1) {
@@ -463,6 +468,37 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staged rows are in registers before the next tile overwrites
     };
+    // the same for tiles whose staged rows are the pixels of ONE image row segment (tile width 16: every full-resolution
+    // layer): the row segment's address is wave-uniform (scalar), a lane only adds a 32-bit element offset xo(row)*Cds + c0
+    auto flush_row = [&](int R, long seg_pix /* first pixel of the segment, or -1 */, auto xo) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (seg_pix >= 0) {
+            _Float16* const bh = p.dst_hi + seg_pix * p.Cds;
+            _Float16* const bl = p.dst_lo + seg_pix * p.Cds;
+#pragma unroll
+            for (int k = 0; k < (ROWS * UR + 63) / 64; ++k) {
+                const int u = lane + 64 * k;
+                const int row = u / UR, cu = u - row * UR;
+                const int c0 = nblk * (NT * 16) + cu * 8;
+                if (row < R && c0 < p.Cds) {
+                    const int off = xo(row) * p.Cds + c0;
+                    uint4 vh = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16);
+                    uint4 vl = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16 + PLANE);
+                    if (p.app_hi && c0 == p.app_c0) {   // appended channels (exact zeros so far: padded output channels)
+                        const long pix = seg_pix + xo(row);
+                        const unsigned ah = *reinterpret_cast<const unsigned*>(p.app_hi + pix * p.app_Cs);
+                        const unsigned al = *reinterpret_cast<const unsigned*>(p.app_lo + pix * p.app_Cs);
+                        if (p.app_word == 1) { vh.y = ah; vl.y = al; }
+                        else if (p.app_word == 2) { vh.z = ah; vl.z = al; }
+                        else { vh.w = ah; vl.w = al; }
+                    }
+                    *reinterpret_cast<uint4*>(bh + off) = vh;
+                    *reinterpret_cast<uint4*>(bl + off) = vl;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
 #define UMX_PUT(row, A) /* this lane's 4 channels of every N-tile of accumulator row A -> staged row */ \
     _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                        \
         h4 hi, lo;                                                                                           \
@@ -484,6 +520,12 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
             for (int pu = 0; pu < 2; ++pu) {
                 UMX_PUT(2 * li, accs[pu * 2 + 0][m])
                 UMX_PUT(2 * li + 1, accs[pu * 2 + 1][m])
+                if (p.nimg_m == 1 && (p.flags & 2)) {   // 32 consecutive output pixels of one row
+                    const int img = img0 + ig;
+                    flush_row(32, img < p.B ? (long)(img * p.outH + (y0 + ty) * 2 + pu) * p.outW + x0 * 2 : -1,
+                              [](int row) { return row; });
+                    continue;
+                }
                 flush(32, [&](int row) -> long {
                     const int i = row >> 1;
                     const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
@@ -498,6 +540,12 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
             const int t = wave * KMT + m;
             const int ig = t >> p.th_log2, ty = t & (TH - 1);
             if ((li & 1) == 0) { UMX_PUT(li >> 1, accs[0][m]) }   // pooled pixel j = li/2 of the 8 this M-tile pair produces
+            if (p.nimg_m == 1 && (p.flags & 2)) {   // 8 consecutive pooled pixels of one row
+                const int img = img0 + ig;
+                flush_row(8, img < p.B ? (long)(img * p.outH + ((y0 + ty) >> 1)) * p.outW + (x0 >> 1) : -1,
+                          [](int row) { return row; });
+                continue;
+            }
             flush(8, [&](int j) -> long {
                 const int i = 2 * j;
                 const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
@@ -511,6 +559,13 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
             const int t = wave * KMT + m;
             const int ig = t >> p.th_log2, ty = t & (TH - 1);
             UMX_PUT(li, accs[0][m])
+            if (p.nimg_m == 1 && (p.flags & 2)) {   // 16 pixels of one row (every o_mul-th pixel for a per-phase transposed convolution)
+                const int img = img0 + ig;
+                const int om = p.o_mul;
+                flush_row(16, img < p.B ? (long)(img * p.outH + (y0 + ty) * om + ph.oy_off) * p.outW + x0 * om + ph.ox_off : -1,
+                          [om](int row) { return row * om; });
+                continue;
+            }
             flush(16, [&](int i) -> long {
                 const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
                 if (img >= p.B) return -1;

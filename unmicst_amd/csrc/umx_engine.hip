@@ -887,7 +887,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     h.inv_oc_q16 = 65536 / OC + 1;
     {
         const char* e = getenv("UMX_CONV_FLAGS");
-        h.flags = e ? atoi(e) : 1;
+        h.flags = e ? atoi(e) : 3;
     }
     h.pix_bytes = OC * 16;
     h.slot_bytes = h.plane_slots * OC * 16;
@@ -985,6 +985,13 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                 e[8 + k] = head->pre_b.empty() ? 0.f : head->pre_b[k];
             }
         }
+        h.post_affine = 0;
+        for (int nb = 0; nb < h.nblocks; ++nb)
+            for (int i = 0; i < nb16; ++i) {
+                if (nb * nb16 + i >= L.Cout) continue;
+                const float* e = &ec[(size_t)nb * per_blk];
+                if (e[2 * nb16 + i] != 1.f || e[3 * nb16 + i] != 0.f) h.post_affine = 1;
+            }
         float* d = nullptr;
         int rc2 = upload(ctx, ec, &d);
         if (rc2) return rc2;

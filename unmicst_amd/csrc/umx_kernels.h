@@ -119,6 +119,7 @@ struct HConvParams {
                                  // 2^(activation shift) of the output; everything 0 for padded channels
     float inv_imgplane, inv_hw;  // 1 / imgplane, 1 / hw
     int act;
+    int post_affine;             // 0: post_s == 1 and post_b == 0 on every real channel (the epilogue skips the second affine)
     int* overflow_flag;
     long long* dbg;              // diagnostic builds only (UMX_DEBUG_STAMPS): per-workgroup s_memtime segments, or NULL
 };
