@@ -300,7 +300,8 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
     // epilogue arithmetic in place; the constants come from LDS (4 consecutive channels = one float4 per array)
-    float vmax = 0.f;   // max |v| of this lane: one compare against binary16's range at the end
+    unsigned vmax = 0u;   // max |v| of this lane as a bit pattern (orders NaN and infinity above every finite value): one
+                          // compare against binary16's range at the end
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const float4 ps = ec4[0 * NT * 4 + n * 4 + q], pb = ec4[1 * NT * 4 + n * 4 + q];
@@ -321,7 +322,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
                     if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
                     else if (p.act == ACT_LEAKY) v = fmaxf(v, 0.2f * v);   // == v > 0 ? v : 0.2 v
                     if (p.post_affine) v = v * qsa[r] + qba[r];
-                    vmax = fmaxf(vmax, fabsf(v));
+                    vmax = max(vmax, __float_as_uint(v) & 0x7fffffffu);
                     accs[h][m][n][r] = v;
                 }
         if constexpr (NPH == 1) {
@@ -339,7 +340,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
             }
         }
     }
-    const bool big = !(vmax < 60000.f);   // (also true for a NaN)
+    const bool big = vmax >= 0x476a6000u;   // |v| >= 60000, infinity or NaN
     if (big && p.dst_f32 == nullptr && p.head_K == 0) atomicOr(p.overflow_flag, 1);   // binary16 range exceeded: the host reports it
 
     if constexpr (NPH == 1) {

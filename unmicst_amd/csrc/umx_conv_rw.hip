@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256, 1) conv_rw(const RwParams p) {
             if constexpr (DIAG & 2) { asm volatile("" :: "v"(acc[0]), "v"(acc[NT - 1])); continue; }
             asm volatile("" ::: "memory");   // the constants are re-read from LDS here: hoisted, they cost registers and speed
             float v[NT][4];
-            float vmax = 0.f;
+            unsigned vmax = 0u;   // max |v| as a bit pattern: NaN and infinity order above every finite value
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const float4 ps = ec4[0 * NT * 4 + n * 4 + q], pb = ec4[1 * NT * 4 + n * 4 + q];
@@ -215,11 +215,11 @@ __global__ void __launch_bounds__(256, 1) conv_rw(const RwParams p) {
                     float t = acc[n][r] * psa[r] + pba[r];
                     t = fmaxf(t, t * slope);   // slope 0: ReLU, 0.2: LeakyReLU, 1: none
                     if (p.post_affine) t = t * ecl[2 * NT * 16 + n * 16 + 4 * q + r] + ecl[3 * NT * 16 + n * 16 + 4 * q + r];
-                    vmax = fmaxf(vmax, fabsf(t));
+                    vmax = max(vmax, __float_as_uint(t) & 0x7fffffffu);
                     v[n][r] = t;
                 }
             }
-            const bool big = !(vmax < 60000.f);
+            const bool big = vmax >= 0x476a6000u;   // |v| >= 60000, infinity or NaN
             f32x4 lg = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s2 = 0; s2 < (NT + 1) / 2; ++s2) {
