@@ -14,7 +14,7 @@
 //   LDS          input halo, pixel-major: [halo pixel][OC octets] of 16-byte slots (OC odd: an activation-fragment read of
 //                16 consecutive pixels at one octet is conflict-free), a hi image then a lo image per halo slot, two
 //                slots; then the two weight buffers.
-// Staging is LDS-DMA (global_load_lds_dwordx4: no staging VGPRs) in a two-deep pipeline: two weight buffers and two halo
+// Staging is LDS-DMA (buffer_load_dwordx4 .. lds: no staging VGPRs, out-of-range lanes write the zero padding) in a two-deep pipeline: two weight buffers and two halo
 // slots, the loads of stage s+1 in flight under the MFMAs of stage s, one barrier per stage; 2-3 workgroups per CU.  A k-step is any 4 (tap, octet) pairs (table built on the host), so channel counts
 // only need to be multiples of 8, not 32.
 #include "umx_kernels.h"
