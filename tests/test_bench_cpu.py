@@ -7,13 +7,20 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_bench_gpus_2_launches_two_ranks():
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--master-port", "29633"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch", "--master-port", str(_free_port())],
                        capture_output=True, text=True, timeout=300, env=env)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("bench.py dry launch")]
     assert sorted(lines) == ["bench.py dry launch: rank 0 of 2 (local rank 0)", "bench.py dry launch: rank 1 of 2 (local rank 1)"]
 
