@@ -192,7 +192,8 @@ def main():
         print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
     if args.dry_launch:
-        print("bench.py dry launch: rank %d of %d (local rank %d)" % (rank, world, local_rank), flush=True)
+        sys.stdout.write("bench.py dry launch: rank %d of %d (local rank %d)\n" % (rank, world, local_rank))   # one write
+        sys.stdout.flush()
         return
 
     import numpy as np
