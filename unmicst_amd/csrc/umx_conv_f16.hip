@@ -34,7 +34,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //          once instead of four times, every stage carries the phase whose accumulators it feeds, KMT = 2 (128 input
 //          pixels -> 512 output pixels per workgroup), and the epilogue interleaves the phases so that whole output
 //          rows (32 consecutive pixels) are stored contiguously.
-template <int NT, int KMT, int NPH>
+// DBG = true: the same kernel with in-kernel s_memtime stamps (UMX_DEBUG_STAMPS); the product build carries none of it.
+template <int NT, int KMT, int NPH, bool DBG = false>
 __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -56,7 +57,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     // diagnostic stamps (shader-clock cycles), wave 0 only: [0] prologue, [1] waiting for loads + barriers, [2] MFMA
     // blocks, [3] epilogue, [4] whole kernel
     long long t_in = 0, t_wait = 0, t_comp = 0, t_a = 0, t_b = 0, t_vm = 0, t_iss = 0;
-    if (p.dbg) t_in = __builtin_amdgcn_s_memtime();
+    if (DBG && p.dbg) t_in = __builtin_amdgcn_s_memtime();
     // ---- per-lane A-fragment pixel offsets (bytes) of this wave's M-tiles
     int abase[KMT];
 #pragma unroll
@@ -133,39 +134,37 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
 #pragma unroll
         for (int j = 0; j < MAXP; ++j) {
             const int i = wave + kWaves * j;
-            if (i < p.ninst) {                   // wave-uniform
-                if (pix[j] != -1 && kok) {       // lanes of this piece
-                    const int voff = pix[j] >= 0 ? (int)__umul24(pix[j], Cs2) + kq * 16 : 0x7fffffff;
-                    UMX_BLDS16(rh, slot + i * p.piece_bytes, voff, soff);
-                    UMX_BLDS16(rl, slot + lo_off + i * p.piece_bytes, voff, soff);
-                }
+            if (i >= p.ninst) break;             // wave-uniform: the wave's pieces are the first ones
+            if (pix[j] != -1 && kok) {           // lanes of this piece
+                const int voff = pix[j] >= 0 ? (int)__umul24(pix[j], Cs2) + kq * 16 : 0x7fffffff;
+                UMX_BLDS16(rh, slot + i * p.piece_bytes, voff, soff);
+                UMX_BLDS16(rl, slot + lo_off + i * p.piece_bytes, voff, soff);
             }
         }
     };
     // weight block of a stage: [64 B header: k-map of its k-steps][nk x NT x (hi, lo) images].  The header goes out at once
     // (one 64-byte piece by the last wave); the 1-KiB pieces are handed out one per N-tile iteration of the MFMA loop below
     // (wq_* state), so that a wave never queues a burst of vector-memory instructions in front of its matrix work.
-    int wq_pc = 0, wq_np = 0, wq_soff = 0;
+    // (no queue state: the piece a wave issues at its c-th call is piece wave + 4c, and c is a compile-time constant of the
+    // unrolled loops -- a loop-carried position ended up in a vector register with a waterfall loop around every piece:
+    // per k-step of the 9-tile kernel 68 VALU + 90 SALU + 27 branches)
+    int wq_np = 0, wq_soff = 0;
     unsigned char* wq_dst = Bl;
+    const int wq_w = wave * 1024;
     auto wq_begin = [&](const HStage& st, int buf) {
         unsigned char* const wl = Bl + buf * p.wbuf_bytes;
         if (wave == kWaves - 1 && lane < 4) UMX_BLDS16(rw, wl, lane16, st.woff * 16);
-        wq_pc = wave;
-        wq_np = st.nk * NT * 2;
+        wq_np = st.nk * (NT * 2048);           // bytes of the block's 1-KiB pieces
         wq_soff = st.woff * 16 + 64;
         wq_dst = wl + 64;
     };
-    auto wq_one = [&]() {
-        if (wq_pc < wq_np) {
-            UMX_BLDS16(rw, wq_dst + wq_pc * 1024, lane16, wq_soff + wq_pc * 1024);
-            wq_pc += kWaves;
-        }
+    auto wq_one = [&](int c) {                 // the wave's c-th piece of the block
+        const int pc = wq_w + c * (kWaves * 1024);
+        if (pc < wq_np) UMX_BLDS16(rw, wq_dst + pc, lane16, wq_soff + pc);
     };
-    auto wq_drain = [&]() {
-        while (wq_pc < wq_np) {
-            UMX_BLDS16(rw, wq_dst + wq_pc * 1024, lane16, wq_soff + wq_pc * 1024);
-            wq_pc += kWaves;
-        }
+    auto wq_drain = [&](int c0) {              // pieces c0, c0+1, .. (those the stage had no N-tile iteration for)
+        for (int pc = wq_w + c0 * (kWaves * 1024); pc < wq_np; pc += kWaves * 1024)
+            UMX_BLDS16(rw, wq_dst + pc, lane16, wq_soff + pc);
     };
 
     // epilogue constants of this N-block ([pre_s | pre_b | post_s | post_b] x NT*16 floats, defaults and 2^shift factors
@@ -186,10 +185,10 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     if (ph.nstages > 0) {
         if (cur.group >= 0) issue_halo(cur);
         wq_begin(cur, 0);
-        wq_drain();
+        wq_drain(0);
     }
     long long t_pro = 0;
-    if (p.dbg) { t_pro = __builtin_amdgcn_s_memtime(); t_a = t_pro; }
+    if (DBG && p.dbg) { t_pro = __builtin_amdgcn_s_memtime(); t_a = t_pro; }
     // Two-deep software pipeline: the loads of stage s+1 (next weight block into the other weight buffer, and, at a chunk
     // boundary, the next halo chunk into the other halo slot) are in flight while stage s runs its MFMAs.  One barrier
     // per stage: it orders "everyone's loads of stage s have landed" (each wave waits for its own first) and "everyone is
@@ -197,17 +196,17 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     for (int s = 0; s < ph.nstages; ++s) {
         const HStage nxt = p.stages[ph.stage0 + (s + 1 < ph.nstages ? s + 1 : s)];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (p.dbg) { const long long t_v = __builtin_amdgcn_s_memtime(); t_vm += t_v - t_a; }
+        if (DBG && p.dbg) { const long long t_v = __builtin_amdgcn_s_memtime(); t_vm += t_v - t_a; }
         __syncthreads();
-        if (p.dbg) { t_b = __builtin_amdgcn_s_memtime(); t_wait += t_b - t_a; }
+        if (DBG && p.dbg) { t_b = __builtin_amdgcn_s_memtime(); t_wait += t_b - t_a; }
         if (s + 1 < ph.nstages) {
             if (nxt.group >= 0) issue_halo(nxt);
             wq_begin(nxt, (s + 1) & 1);
-            if (!(p.flags & 1)) wq_drain();   // A/B switch: all weight pieces up front (the round-1 schedule)
         } else {
+            wq_np = 0;   // no block after the last stage
             issue_econst((s + 1) & 1);
         }
-        if (p.dbg) t_iss += (long long)__builtin_amdgcn_s_memtime() - t_b;
+        if (DBG && p.dbg) t_iss += (long long)__builtin_amdgcn_s_memtime() - t_b;
 
         const unsigned char* const wl = Bl + (s & 1) * p.wbuf_bytes;
         // k-map of the stage up front: one LDS round trip per stage instead of one on every k-step's critical path
@@ -221,7 +220,8 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
             if (NPH > 1 && cur.phase != h) continue;   // wave-uniform
 #pragma unroll
             for (int j = 0; j < kStageK; ++j) {
-                if (j < cur.nk) {
+                if (j >= cur.nk) break;
+                {
                     const unsigned char* const bp = wl + 64 + j * (NT * 2048) + lane * 16;
                     const unsigned char* const ap = smem + kbs[j];
                     h8 ah[KMT], al[KMT];
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
                     }
 #pragma unroll
                     for (int n = 0; n < NT; ++n) {
-                        wq_one();   // next stage's weight pieces, one per N-tile: spread under the MFMAs
+                        wq_one(j * NT + n);   // next stage's weight pieces, one per N-tile: spread under the MFMAs
                         __builtin_amdgcn_iglp_opt(0);
                         if (n + kBPre < NT) {
                             bhq[(n + kBPre) % (kBPre + 1)] = *reinterpret_cast<const h8*>(bp + (n + kBPre) * 2048);
@@ -263,21 +263,21 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
                 }
             }
         }
-        wq_drain();   // pieces the stage had no N-tile iteration for
+        wq_drain(cur.nk * NT);
         cur = nxt;
-        if (p.dbg) { t_a = __builtin_amdgcn_s_memtime(); t_comp += t_a - t_b; }
+        if (DBG && p.dbg) { t_a = __builtin_amdgcn_s_memtime(); t_comp += t_a - t_b; }
     }
     struct DbgOut {   // written when the kernel returns (both epilogue paths)
         const HConvParams& p; long long t_in, t_pro, t_wait, t_comp, t_epi; int tid; const long long& t_vm; const long long& t_iss;
         __device__ ~DbgOut() {
-            if (p.dbg && tid == 0) {
+            if (DBG && p.dbg && tid == 0) {
                 const long long t_end = __builtin_amdgcn_s_memtime();
                 const size_t w = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
                 long long* d = p.dbg + w * 7;
                 d[0] = t_pro - t_in; d[1] = t_wait; d[2] = t_comp; d[3] = t_end - t_epi; d[4] = t_end - t_in; d[5] = t_vm; d[6] = t_iss;
             }
         }
-    } dbg_out{p, t_in, t_pro, t_wait, t_comp, p.dbg ? (long long)__builtin_amdgcn_s_memtime() : 0, tid, t_vm, t_iss};
+    } dbg_out{p, t_in, t_pro, t_wait, t_comp, DBG && p.dbg ? (long long)__builtin_amdgcn_s_memtime() : 0, tid, t_vm, t_iss};
 
     // ---- epilogue: (acc * pre_s + pre_b) -> activation -> (* post_s + post_b, output shift folded in) -> [2x2 max-pool]
     //      -> (hi, lo) binary16 NHWC, or fp32 NHWC for the tensor the softmax head reads.
@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
             for (int pu = 0; pu < 2; ++pu) {
                 UMX_PUT(2 * li, accs[pu * 2 + 0][m])
                 UMX_PUT(2 * li + 1, accs[pu * 2 + 1][m])
-                if (p.nimg_m == 1 && (p.flags & 2)) {   // 32 consecutive output pixels of one row
+                if (p.nimg_m == 1) {   // 32 consecutive output pixels of one row
                     const int img = img0 + ig;
                     flush_row(32, img < p.B ? (long)(img * p.outH + (y0 + ty) * 2 + pu) * p.outW + x0 * 2 : -1,
                               [](int row) { return row; });
@@ -541,7 +541,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
             const int t = wave * KMT + m;
             const int ig = t >> p.th_log2, ty = t & (TH - 1);
             if ((li & 1) == 0) { UMX_PUT(li >> 1, accs[0][m]) }   // pooled pixel j = li/2 of the 8 this M-tile pair produces
-            if (p.nimg_m == 1 && (p.flags & 2)) {   // 8 consecutive pooled pixels of one row
+            if (p.nimg_m == 1) {   // 8 consecutive pooled pixels of one row
                 const int img = img0 + ig;
                 flush_row(8, img < p.B ? (long)(img * p.outH + ((y0 + ty) >> 1)) * p.outW + (x0 >> 1) : -1,
                           [](int row) { return row; });
@@ -560,7 +560,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
             const int t = wave * KMT + m;
             const int ig = t >> p.th_log2, ty = t & (TH - 1);
             UMX_PUT(li, accs[0][m])
-            if (p.nimg_m == 1 && (p.flags & 2)) {   // 16 pixels of one row (every o_mul-th pixel for a per-phase transposed convolution)
+            if (p.nimg_m == 1) {   // 16 pixels of one row (every o_mul-th pixel for a per-phase transposed convolution)
                 const int img = img0 + ig;
                 const int om = p.o_mul;
                 flush_row(16, img < p.B ? (long)(img * p.outH + (y0 + ty) * om + ph.oy_off) * p.outW + x0 * om + ph.ox_off : -1,
@@ -582,6 +582,17 @@ static hipError_t launch_h_nt(const HConvParams& p, hipStream_t stream) {
     const int img_groups = (p.B + p.imgs - 1) / p.imgs;
     dim3 grid((unsigned)(img_groups * p.tiles_y * p.tiles_x), (unsigned)p.nblocks, (unsigned)(NPH == 1 ? p.nphase : 1));
     const size_t lds = (size_t)p.lds_bytes;
+    if constexpr (NT == 3 || NT == 5 || NT == 9) {   // the stamped twins exist for the tile counts the bench graphs use
+        if (p.dbg) {
+            const void* kd = reinterpret_cast<const void*>(conv_f16x3<NT, KMT, NPH, true>);
+            if (lds > 48 * 1024) {
+                hipError_t e = hipFuncSetAttribute(kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+            }
+            hipLaunchKernelGGL((conv_f16x3<NT, KMT, NPH, true>), grid, dim3(256), lds, stream, p);
+            return hipGetLastError();
+        }
+    }
     const void* kern = reinterpret_cast<const void*>(conv_f16x3<NT, KMT, NPH>);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

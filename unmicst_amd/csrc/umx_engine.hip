@@ -877,6 +877,28 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         }
     }
     if (!bestOC) { *why = "LDS footprint too large for the split-precision kernel"; return UMX_ERR_INVALID; }
+    if (const char* e = getenv("UMX_PLAN_OVERRIDE")) {   // tuning aid: "layer:OC:S[,layer:OC:S...]" forces a layer's (OC, S)
+        std::string spec(e);
+        size_t pos = 0;
+        while (pos < spec.size()) {
+            const size_t end = spec.find(',', pos);
+            const std::string item = spec.substr(pos, end == std::string::npos ? std::string::npos : end - pos);
+            char nm[64];
+            int oc = 0, ss = 0;
+            if (sscanf(item.c_str(), "%63[^:]:%d:%d", nm, &oc, &ss) == 3 && L.name == nm && oc >= 1 && oc <= 9 && ss >= 1 &&
+                ss <= kStageK) {
+                int nslots = 1;
+                for (int list = 0; list < nlists; ++list)
+                    if (chunks_for(oc, fused ? -1 : list).size() >= 2) nslots = 2;
+                const int lds = nslots * oc * plane_pair + 2 * (64 + ss * nt16 * 2048);
+                const bool pieces_ok = ((h.nhalo + 64 / oc - 1) / (64 / oc) + nwaves - 1) / nwaves <= (nt16 >= 6 ? 4 : 12);
+                if (lds <= kMaxLdsPerWG && pieces_ok) { bestOC = oc; bestS = ss; bestSlots = nslots; }
+                else fprintf(stderr, "[umx plan] override %s ignored (LDS %d B)\n", item.c_str(), lds);
+            }
+            if (end == std::string::npos) break;
+            pos = end + 1;
+        }
+    }
     const int OC = bestOC, S = bestS;
     h.OC = OC;
     h.inv_OC = 1.f / (float)OC;
