@@ -17,6 +17,8 @@
 // Staging is LDS-DMA (buffer_load_dwordx4 .. lds: no staging VGPRs, out-of-range lanes write the zero padding) in a two-deep pipeline: two weight buffers and two halo
 // slots, the loads of stage s+1 in flight under the MFMAs of stage s, one barrier per stage; 2-3 workgroups per CU.  A k-step is any 4 (tap, octet) pairs (table built on the host), so channel counts
 // only need to be multiples of 8, not 32.
+#include <type_traits>
+
 #include "umx_kernels.h"
 
 namespace umx {
@@ -36,7 +38,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //          rows (32 consecutive pixels) are stored contiguously.
 // DBG = true: the same kernel with in-kernel s_memtime stamps (UMX_DEBUG_STAMPS); the product build carries none of it.
 template <int NT, int KMT, int NPH, bool DBG = false>
-__global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
+__global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 3 : 2) conv_f16x3(const HConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -135,8 +137,10 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
         for (int j = 0; j < MAXP; ++j) {
             const int i = wave + kWaves * j;
             if (i >= p.ninst) break;             // wave-uniform: the wave's pieces are the first ones
-            if (pix[j] != -1 && kok) {           // lanes of this piece
-                const int voff = pix[j] >= 0 ? (int)__umul24(pix[j], Cs2) + kq * 16 : 0x7fffffff;
+            int pj = pix[j];
+            asm volatile("" : "+v"(pj));         // compare here: hoisted, the 12 lane masks live in (spilled) scalar pairs
+            if (pj != -1 && kok) {               // lanes of this piece
+                const int voff = pj >= 0 ? (int)__umul24(pj, Cs2) + kq * 16 : 0x7fffffff;
                 UMX_BLDS16(rh, slot + i * p.piece_bytes, voff, soff);
                 UMX_BLDS16(rl, slot + lo_off + i * p.piece_bytes, voff, soff);
             }
@@ -181,7 +185,18 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     };
     const float* const ec = reinterpret_cast<const float*>(Bl + (ph.nstages & 1) * p.wbuf_bytes);
     if (ph.nstages == 0) issue_econst(0);
-    HStage cur = p.stages[ph.stage0];
+    // the stage table is read through the constant address space: a plain global pointer gets a VECTOR load and a full
+    // s_waitcnt vmcnt(0) round trip at the top of every stage (the kernel stores and fences, so the compiler will not
+    // prove the table unclobbered); the host writes it before the launch and nothing writes it afterwards
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    static_assert(sizeof(HStage) == 16, "one stage = one 16-byte scalar load");
+    auto load_stage = [&](int idx) {
+        const u32x4 raw = ((const __attribute__((address_space(4))) u32x4*)(unsigned long long)p.stages)[idx];
+        HStage st;
+        __builtin_memcpy(&st, &raw, sizeof(st));
+        return st;
+    };
+    HStage cur = load_stage(ph.stage0);
     if (ph.nstages > 0) {
         if (cur.group >= 0) issue_halo(cur);
         wq_begin(cur, 0);
@@ -194,7 +209,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     // per stage: it orders "everyone's loads of stage s have landed" (each wave waits for its own first) and "everyone is
     // done computing stage s-1" (so the buffers stage s+1 loads into are free).
     for (int s = 0; s < ph.nstages; ++s) {
-        const HStage nxt = p.stages[ph.stage0 + (s + 1 < ph.nstages ? s + 1 : s)];
+        const HStage nxt = load_stage(ph.stage0 + (s + 1 < ph.nstages ? s + 1 : s));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (DBG && p.dbg) { const long long t_v = __builtin_amdgcn_s_memtime(); t_vm += t_v - t_a; }
         __syncthreads();
@@ -299,45 +314,68 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     unsigned char* const stg = smem + wave * (2 * PLANE);
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
-    // epilogue arithmetic in place; the constants come from LDS (4 consecutive channels = one float4 per array)
+    // epilogue arithmetic in place; the constants come from LDS (4 consecutive channels = one float4 per array).  Nothing in
+    // the per-value code may branch: hipcc does not unswitch the loops on p.act / p.post_affine, it tests them per value
+    // (5 VALU + 3 SALU + 4 branches per value measured).  The activation is max(v, slope*v) with slope 0 (ReLU: a negative
+    // v gives -0, numerically the reference's 0), 0.2 (LeakyReLU, == v > 0 ? v : 0.2 v) or 1 (none), written as the median
+    // of (v, slope*v, +inf) because fmaxf() costs an extra canonicalising v_max per value; the second affine exists only in
+    // the legacy graph (BN after ReLU) and with a non-zero activation shift: two copies of the loop, one uniform branch.
     unsigned vmax = 0u;   // max |v| of this lane as a bit pattern (orders NaN and infinity above every finite value): one
                           // compare against binary16's range at the end
+    const float slope = p.act == ACT_RELU ? 0.f : p.act == ACT_LEAKY ? 0.2f : 1.f;
+    // results as scalars, not written back into the accumulator tuples: a 4-vector rebuilt by inserts gets a fresh
+    // 4-register tuple next to the old one (twice the registers, spilled)
+    float res[NPH][KMT][NT][4];
+    auto arith = [&](auto POST) {
+        constexpr bool post = decltype(POST)::value;
+        // (different first instructions: otherwise the common head of the two copies -- a whole N-tile of fmas and multiplies
+        // -- is hoisted above the branch in one batch, and spilled)
+        if constexpr (post) asm volatile("; epilogue arithmetic, second affine");
+        else asm volatile("; epilogue arithmetic");
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const float4 ps = ec4[0 * NT * 4 + n * 4 + q], pb = ec4[1 * NT * 4 + n * 4 + q];
-        const float psa[4] = {ps.x, ps.y, ps.z, ps.w}, pba[4] = {pb.x, pb.y, pb.z, pb.w};
-        float qsa[4] = {1.f, 1.f, 1.f, 1.f}, qba[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.post_affine) {   // only the legacy graph (BN after ReLU) and a non-zero activation shift have a second affine
-            const float4 qs = ec4[2 * NT * 4 + n * 4 + q], qb = ec4[3 * NT * 4 + n * 4 + q];
-            qsa[0] = qs.x; qsa[1] = qs.y; qsa[2] = qs.z; qsa[3] = qs.w;
-            qba[0] = qb.x; qba[1] = qb.y; qba[2] = qb.z; qba[3] = qb.w;
-        }
+        for (int n = 0; n < NT; ++n) {
+            const float4 ps = ec4[0 * NT * 4 + n * 4 + q], pb = ec4[1 * NT * 4 + n * 4 + q];
+            const float psa[4] = {ps.x, ps.y, ps.z, ps.w}, pba[4] = {pb.x, pb.y, pb.z, pb.w};
+            float qsa[4] = {1.f, 1.f, 1.f, 1.f}, qba[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (post) {
+                const float4 qs = ec4[2 * NT * 4 + n * 4 + q], qb = ec4[3 * NT * 4 + n * 4 + q];
+                qsa[0] = qs.x; qsa[1] = qs.y; qsa[2] = qs.z; qsa[3] = qs.w;
+                qba[0] = qb.x; qba[1] = qb.y; qba[2] = qb.z; qba[3] = qb.w;
+            }
 #pragma unroll
-        for (int h = 0; h < NPH; ++h)
+            for (int h = 0; h < NPH; ++h)
 #pragma unroll
-            for (int m = 0; m < KMT; ++m)
+                for (int m = 0; m < KMT; ++m) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = accs[h][m][n][r] * psa[r] + pba[r];
-                    if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (p.act == ACT_LEAKY) v = fmaxf(v, 0.2f * v);   // == v > 0 ? v : 0.2 v
-                    if (p.post_affine) v = v * qsa[r] + qba[r];
-                    vmax = max(vmax, __float_as_uint(v) & 0x7fffffffu);
-                    accs[h][m][n][r] = v;
+                    for (int r = 0; r < 4; ++r) {
+                        float v = accs[h][m][n][r] * psa[r] + pba[r];
+                        v = __builtin_amdgcn_fmed3f(v, v * slope, INFINITY);
+                        if constexpr (post) v = v * qsa[r] + qba[r];
+                        vmax = max(vmax, __float_as_uint(v) & 0x7fffffffu);
+                        res[h][m][n][r] = v;
+                    }
+                    // four values at a time: left alone, the scheduler runs all fmas of an N-tile, then all multiplies, then
+                    // all medians, and spills the temporaries in between
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-        if constexpr (NPH == 1) {
-            if (p.pool) {   // rows m, m+1 are vertical neighbours; pixels li, li^1 horizontal neighbours
+        }
+    };
+    if (p.post_affine) arith(std::true_type{});
+    else arith(std::false_type{});
+    if constexpr (NPH == 1) {
+        if (p.pool) {   // rows m, m+1 are vertical neighbours; pixels li, li^1 horizontal neighbours
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
 #pragma unroll
                 for (int m = 0; m < KMT; m += 2)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float a = fmaxf(accs[0][m][n][r], accs[0][m + 1][n][r]);
+                        const float a = fmaxf(res[0][m][n][r], res[0][m + 1][n][r]);
                         const float b = __builtin_bit_cast(
                             float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1 /* quad_perm [1,0,3,2] */,
                                                                0xF, 0xF, false));
-                        accs[0][m][n][r] = fmaxf(a, b);   // both lanes of the pair hold the pooled value; the even one stores
+                        res[0][m][n][r] = fmaxf(a, b);   // both lanes of the pair hold the pooled value; the even one stores
                     }
-            }
         }
     }
     const bool big = vmax >= 0x476a6000u;   // |v| >= 60000, infinity or NaN
@@ -366,8 +404,8 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
                     for (int k = 0; k < 4; ++k)
                         if (k < K) {
                             const float4 w = ec4[(4 + k) * (NT * 4) + n * 4 + q];
-                            lg[k] += accs[0][m][n][0] * w.x + accs[0][m][n][1] * w.y + accs[0][m][n][2] * w.z +
-                                     accs[0][m][n][3] * w.w;
+                            lg[k] += res[0][m][n][0] * w.x + res[0][m][n][1] * w.y + res[0][m][n][2] * w.z +
+                                     res[0][m][n][3] * w.w;
                         }
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -425,7 +463,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     const int c0 = nblk * (NT * 16) + n * 16 + 4 * q;
-                    const f32x4 v = accs[0][m][n];
+                    const float* const v = res[0][m][n];
                     float* const d = p.dst_f32 + pix * p.Cout + c0;
                     if ((p.Cout & 3) == 0) {
                         if (c0 < p.Cout) *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
@@ -445,9 +483,11 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
     // staged rows [0, R) -> global; pixel_of(row) gives the NHWC pixel index or -1
     auto flush = [&](int R, auto pixel_of) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        int ln = lane;
+        asm volatile("" : "+v"(ln));   // the unit addressing is computed here, not hoisted across the epilogue arithmetic
 #pragma unroll
         for (int k = 0; k < (ROWS * UR + 63) / 64; ++k) {
-            const int u = lane + 64 * k;
+            const int u = ln + 64 * k;
             const int row = u / UR, cu = u - row * UR;
             const int c0 = nblk * (NT * 16) + cu * 8;
             if (row < R && c0 < p.Cds) {
@@ -476,9 +516,11 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
         if (seg_pix >= 0) {
             _Float16* const bh = p.dst_hi + seg_pix * p.Cds;
             _Float16* const bl = p.dst_lo + seg_pix * p.Cds;
+            int ln = lane;
+            asm volatile("" : "+v"(ln));   // (as in flush)
 #pragma unroll
             for (int k = 0; k < (ROWS * UR + 63) / 64; ++k) {
-                const int u = lane + 64 * k;
+                const int u = ln + 64 * k;
                 const int row = u / UR, cu = u - row * UR;
                 const int c0 = nblk * (NT * 16) + cu * 8;
                 if (row < R && c0 < p.Cds) {
@@ -519,8 +561,8 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
             const int ig = t >> p.th_log2, ty = t & (TH - 1);
 #pragma unroll
             for (int pu = 0; pu < 2; ++pu) {
-                UMX_PUT(2 * li, accs[pu * 2 + 0][m])
-                UMX_PUT(2 * li + 1, accs[pu * 2 + 1][m])
+                UMX_PUT(2 * li, res[pu * 2 + 0][m])
+                UMX_PUT(2 * li + 1, res[pu * 2 + 1][m])
                 if (p.nimg_m == 1) {   // 32 consecutive output pixels of one row
                     const int img = img0 + ig;
                     flush_row(32, img < p.B ? (long)(img * p.outH + (y0 + ty) * 2 + pu) * p.outW + x0 * 2 : -1,
@@ -540,7 +582,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
         for (int m = 0; m < KMT; m += 2) {
             const int t = wave * KMT + m;
             const int ig = t >> p.th_log2, ty = t & (TH - 1);
-            if ((li & 1) == 0) { UMX_PUT(li >> 1, accs[0][m]) }   // pooled pixel j = li/2 of the 8 this M-tile pair produces
+            if ((li & 1) == 0) { UMX_PUT(li >> 1, res[0][m]) }   // pooled pixel j = li/2 of the 8 this M-tile pair produces
             if (p.nimg_m == 1) {   // 8 consecutive pooled pixels of one row
                 const int img = img0 + ig;
                 flush_row(8, img < p.B ? (long)(img * p.outH + ((y0 + ty) >> 1)) * p.outW + (x0 >> 1) : -1,
@@ -559,7 +601,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3(const HConvParams p) {
         for (int m = 0; m < KMT; ++m) {
             const int t = wave * KMT + m;
             const int ig = t >> p.th_log2, ty = t & (TH - 1);
-            UMX_PUT(li, accs[0][m])
+            UMX_PUT(li, res[0][m])
             if (p.nimg_m == 1) {   // 16 pixels of one row (every o_mul-th pixel for a per-phase transposed convolution)
                 const int img = img0 + ig;
                 const int om = p.o_mul;
