@@ -183,8 +183,11 @@ __global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 3 : 2) conv_f16x3
                     UMX_GLDS16(p.econst + (size_t)nblk * ec_units + i * 64 + lane, dst + i * 256);
         }
     };
-    const float* const ec = reinterpret_cast<const float*>(Bl + (ph.nstages & 1) * p.wbuf_bytes);
-    if (ph.nstages == 0) issue_econst(0);
+    // stage s uses weight buffer (s + par0) & 1, with par0 such that the buffer the LAST stage frees -- where the epilogue
+    // constants go -- is always buffer 1: the epilogue's transpose staging may then use everything below it
+    const int par0 = (ph.nstages + 1) & 1;
+    const float* const ec = reinterpret_cast<const float*>(Bl + p.wbuf_bytes);
+    if (ph.nstages == 0) issue_econst(1);
     // the stage table is read through the constant address space: a plain global pointer gets a VECTOR load and a full
     // s_waitcnt vmcnt(0) round trip at the top of every stage (the kernel stores and fences, so the compiler will not
     // prove the table unclobbered); the host writes it before the launch and nothing writes it afterwards
@@ -199,7 +202,7 @@ __global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 3 : 2) conv_f16x3
     HStage cur = load_stage(ph.stage0);
     if (ph.nstages > 0) {
         if (cur.group >= 0) issue_halo(cur);
-        wq_begin(cur, 0);
+        wq_begin(cur, par0);
         wq_drain(0);
     }
     long long t_pro = 0;
@@ -216,14 +219,14 @@ __global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 3 : 2) conv_f16x3
         if (DBG && p.dbg) { t_b = __builtin_amdgcn_s_memtime(); t_wait += t_b - t_a; }
         if (s + 1 < ph.nstages) {
             if (nxt.group >= 0) issue_halo(nxt);
-            wq_begin(nxt, (s + 1) & 1);
+            wq_begin(nxt, (s + 1 + par0) & 1);
         } else {
             wq_np = 0;   // no block after the last stage
-            issue_econst((s + 1) & 1);
+            issue_econst(1);   // == (s + 1 + par0) & 1
         }
         if (DBG && p.dbg) t_iss += (long long)__builtin_amdgcn_s_memtime() - t_b;
 
-        const unsigned char* const wl = Bl + (s & 1) * p.wbuf_bytes;
+        const unsigned char* const wl = Bl + ((s + par0) & 1) * p.wbuf_bytes;
         // k-map of the stage up front: one LDS round trip per stage instead of one on every k-step's critical path
         unsigned kbs[kStageK];
 #pragma unroll
@@ -306,30 +309,29 @@ __global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 3 : 2) conv_f16x3
     // fp32 output: direct 16-byte stores (64 contiguous bytes per pixel and N-tile).
     // (hi, lo) output: through a per-wave LDS transpose -- each lane drops its 4 channels (8 bytes) into a [pixel][channel]
     // row image, then the wave stores whole rows, 16 bytes per lane, consecutive lanes consecutive addresses (pixels
-    // that are neighbours in x are contiguous in NHWC): full-line writes instead of 8-byte fragments.
+    // that are neighbours in x are contiguous in NHWC): full-line writes instead of 8-byte fragments.  The staging area
+    // (p.stg_off, chosen by the planner) stays clear of weight buffer 1, so the constants stay readable and every wave
+    // runs arithmetic -> transpose -> stores one M-tile at a time on its own: accumulators die as they are consumed.
     constexpr int ROWS = NPH == 4 ? 32 : 16;   // staged pixel rows per flush
     constexpr int PITCH = NT * 32 + 16;   // bytes per staged pixel row of one plane
     constexpr int PLANE = ROWS * PITCH;
     constexpr int UR = NT * 2;            // 16-byte units per staged row
-    unsigned char* const stg = smem + wave * (2 * PLANE);
+    unsigned char* const stg = smem + p.stg_off + wave * (2 * PLANE);
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
-    // epilogue arithmetic in place; the constants come from LDS (4 consecutive channels = one float4 per array).  Nothing in
-    // the per-value code may branch: hipcc does not unswitch the loops on p.act / p.post_affine, it tests them per value
-    // (5 VALU + 3 SALU + 4 branches per value measured).  The activation is max(v, slope*v) with slope 0 (ReLU: a negative
-    // v gives -0, numerically the reference's 0), 0.2 (LeakyReLU, == v > 0 ? v : 0.2 v) or 1 (none), written as the median
-    // of (v, slope*v, +inf) because fmaxf() costs an extra canonicalising v_max per value; the second affine exists only in
-    // the legacy graph (BN after ReLU) and with a non-zero activation shift: two copies of the loop, one uniform branch.
+    // One M-tile of one phase: (acc * pre_s + pre_b) -> activation -> [* post_s + post_b].  Nothing in the per-value code may
+    // branch: hipcc does not unswitch loops on p.act / p.post_affine, it tests them per value (5 VALU + 3 SALU + 4 branches
+    // per value measured).  The activation is max(v, slope*v) with slope 0 (ReLU: a negative v gives -0, numerically the
+    // reference's 0), 0.2 (LeakyReLU, == v > 0 ? v : 0.2 v) or 1 (none), written as the median of (v, slope*v, +inf) because
+    // fmaxf() costs an extra canonicalising v_max per value; the second affine exists only in the legacy graph (BN after
+    // ReLU) and with a non-zero activation shift: two copies of the loop behind one uniform branch.  Results are scalars,
+    // not written back into the accumulator tuples (a 4-vector rebuilt by inserts gets a fresh register tuple).
     unsigned vmax = 0u;   // max |v| of this lane as a bit pattern (orders NaN and infinity above every finite value): one
                           // compare against binary16's range at the end
     const float slope = p.act == ACT_RELU ? 0.f : p.act == ACT_LEAKY ? 0.2f : 1.f;
-    // results as scalars, not written back into the accumulator tuples: a 4-vector rebuilt by inserts gets a fresh
-    // 4-register tuple next to the old one (twice the registers, spilled)
-    float res[NPH][KMT][NT][4];
-    auto arith = [&](auto POST) {
-        constexpr bool post = decltype(POST)::value;
-        // (different first instructions: otherwise the common head of the two copies -- a whole N-tile of fmas and multiplies
-        // -- is hoisted above the branch in one batch, and spilled)
+    auto arith_v = [&](const f32x4 (&A)[NT], float (&out)[NT][4], auto POST, auto TRACK) {
+        constexpr bool post = decltype(POST)::value, track = decltype(TRACK)::value;
+        // (different first instructions: otherwise the common head of the two copies is hoisted above the branch in one batch)
         if constexpr (post) asm volatile("; epilogue arithmetic, second affine");
         else asm volatile("; epilogue arithmetic");
 #pragma unroll
@@ -343,43 +345,24 @@ __global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 3 : 2) conv_f16x3
                 qba[0] = qb.x; qba[1] = qb.y; qba[2] = qb.z; qba[3] = qb.w;
             }
 #pragma unroll
-            for (int h = 0; h < NPH; ++h)
-#pragma unroll
-                for (int m = 0; m < KMT; ++m) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = accs[h][m][n][r] * psa[r] + pba[r];
-                        v = __builtin_amdgcn_fmed3f(v, v * slope, INFINITY);
-                        if constexpr (post) v = v * qsa[r] + qba[r];
-                        vmax = max(vmax, __float_as_uint(v) & 0x7fffffffu);
-                        res[h][m][n][r] = v;
-                    }
-                    // four values at a time: left alone, the scheduler runs all fmas of an N-tile, then all multiplies, then
-                    // all medians, and spills the temporaries in between
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            for (int r = 0; r < 4; ++r) {
+                float v = A[n][r] * psa[r] + pba[r];
+                v = __builtin_amdgcn_fmed3f(v, v * slope, INFINITY);
+                if constexpr (post) v = v * qsa[r] + qba[r];
+                if constexpr (track) vmax = max(vmax, __float_as_uint(v) & 0x7fffffffu);
+                out[n][r] = v;
+            }
+            // four values at a time: left alone, the scheduler runs all fmas, then all multiplies, then all medians, and
+            // spills the temporaries in between
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
-    if (p.post_affine) arith(std::true_type{});
-    else arith(std::false_type{});
-    if constexpr (NPH == 1) {
-        if (p.pool) {   // rows m, m+1 are vertical neighbours; pixels li, li^1 horizontal neighbours
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int m = 0; m < KMT; m += 2)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float a = fmaxf(res[0][m][n][r], res[0][m + 1][n][r]);
-                        const float b = __builtin_bit_cast(
-                            float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1 /* quad_perm [1,0,3,2] */,
-                                                               0xF, 0xF, false));
-                        res[0][m][n][r] = fmaxf(a, b);   // both lanes of the pair hold the pooled value; the even one stores
-                    }
-        }
-    }
-    const bool big = vmax >= 0x476a6000u;   // |v| >= 60000, infinity or NaN
-    if (big && p.dst_f32 == nullptr && p.head_K == 0) atomicOr(p.overflow_flag, 1);   // binary16 range exceeded: the host reports it
+    auto arith = [&](const f32x4 (&A)[NT], float (&out)[NT][4], auto TRACK) {
+        if (p.post_affine) arith_v(A, out, std::true_type{}, TRACK);
+        else arith_v(A, out, std::false_type{}, TRACK);
+    };
+    constexpr std::true_type kTrack{};
+    constexpr std::false_type kNoTrack{};
 
     if constexpr (NPH == 1) {
         if (p.head_K > 0) {
@@ -397,6 +380,8 @@ __global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 3 : 2) conv_f16x3
             float mine[4] = {0.f, 0.f, 0.f, 0.f};   // logits of the pixel this lane finishes: pixel li of M-tile q
 #pragma unroll
             for (int m = 0; m < KMT; ++m) {
+                float res[NT][4];
+                arith(accs[0][m], res, kNoTrack);
                 float lg[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
@@ -404,8 +389,7 @@ __global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 3 : 2) conv_f16x3
                     for (int k = 0; k < 4; ++k)
                         if (k < K) {
                             const float4 w = ec4[(4 + k) * (NT * 4) + n * 4 + q];
-                            lg[k] += res[0][m][n][0] * w.x + res[0][m][n][1] * w.y + res[0][m][n][2] * w.z +
-                                     res[0][m][n][3] * w.w;
+                            lg[k] += res[n][0] * w.x + res[n][1] * w.y + res[n][2] * w.z + res[n][3] * w.w;
                         }
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -448,22 +432,21 @@ __global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 3 : 2) conv_f16x3
             }
             return;
         }
-    }
-
-    if (p.dst_f32) {
-        if constexpr (NPH == 1) {
+        if (p.dst_f32) {   // (the planner never pairs fp32 output with the fused transposed convolution)
 #pragma unroll
             for (int m = 0; m < KMT; ++m) {
                 const int t = wave * KMT + m;
                 const int ig = t >> p.th_log2, ty = t & (TH - 1);
                 const int img = img0 + ig * p.nimg_m + (li >> p.twm_log2);
+                float res[NT][4];
+                arith(accs[0][m], res, kNoTrack);
                 if (img >= p.B) continue;
                 const long pix = (long)(img * p.outH + (y0 + ty) * p.o_mul + ph.oy_off) * p.outW +
                                  (x0 + (li & (TWm - 1))) * p.o_mul + ph.ox_off;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     const int c0 = nblk * (NT * 16) + n * 16 + 4 * q;
-                    const float* const v = res[0][m][n];
+                    const float* const v = res[n];
                     float* const d = p.dst_f32 + pix * p.Cout + c0;
                     if ((p.Cout & 3) == 0) {
                         if (c0 < p.Cout) *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
@@ -474,11 +457,9 @@ __global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 3 : 2) conv_f16x3
                     }
                 }
             }
+            return;
         }
-        return;   // (the planner never pairs fp32 output with the fused transposed convolution)
     }
-
-    __syncthreads();   // every wave has read its constants: the LDS is free for the transpose
 
     // staged rows [0, R) -> global; pixel_of(row) gives the NHWC pixel index or -1
     auto flush = [&](int R, auto pixel_of) {
@@ -542,7 +523,7 @@ __global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 3 : 2) conv_f16x3
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
-#define UMX_PUT(row, A) /* this lane's 4 channels of every N-tile of accumulator row A -> staged row */ \
+#define UMX_PUT(row, A) /* this lane's 4 channels of every N-tile of result row A -> staged row */ \
     _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                        \
         h4 hi, lo;                                                                                           \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                      \
@@ -561,8 +542,16 @@ __global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 3 : 2) conv_f16x3
             const int ig = t >> p.th_log2, ty = t & (TH - 1);
 #pragma unroll
             for (int pu = 0; pu < 2; ++pu) {
-                UMX_PUT(2 * li, res[pu * 2 + 0][m])
-                UMX_PUT(2 * li + 1, res[pu * 2 + 1][m])
+                {
+                    float r0[NT][4];
+                    arith(accs[pu * 2 + 0][m], r0, kTrack);
+                    UMX_PUT(2 * li, r0)
+                }
+                {
+                    float r1[NT][4];
+                    arith(accs[pu * 2 + 1][m], r1, kTrack);
+                    UMX_PUT(2 * li + 1, r1)
+                }
                 if (p.nimg_m == 1) {   // 32 consecutive output pixels of one row
                     const int img = img0 + ig;
                     flush_row(32, img < p.B ? (long)(img * p.outH + (y0 + ty) * 2 + pu) * p.outW + x0 * 2 : -1,
@@ -582,7 +571,21 @@ __global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 3 : 2) conv_f16x3
         for (int m = 0; m < KMT; m += 2) {
             const int t = wave * KMT + m;
             const int ig = t >> p.th_log2, ty = t & (TH - 1);
-            if ((li & 1) == 0) { UMX_PUT(li >> 1, res[0][m]) }   // pooled pixel j = li/2 of the 8 this M-tile pair produces
+            float r0[NT][4], r1[NT][4];
+            arith(accs[0][m], r0, kTrack);
+            arith(accs[0][m + 1], r1, kTrack);
+            // rows m, m+1 are vertical neighbours; pixels li, li^1 horizontal neighbours
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = fmaxf(r0[n][r], r1[n][r]);
+                    const float b = __builtin_bit_cast(
+                        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1 /* quad_perm [1,0,3,2] */, 0xF,
+                                                           0xF, false));
+                    r0[n][r] = fmaxf(a, b);   // both lanes of the pair hold the pooled value; the even one stores
+                }
+            if ((li & 1) == 0) { UMX_PUT(li >> 1, r0) }   // pooled pixel j = li/2 of the 8 this M-tile pair produces
             if (p.nimg_m == 1) {   // 8 consecutive pooled pixels of one row
                 const int img = img0 + ig;
                 flush_row(8, img < p.B ? (long)(img * p.outH + ((y0 + ty) >> 1)) * p.outW + (x0 >> 1) : -1,
@@ -601,7 +604,11 @@ __global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 3 : 2) conv_f16x3
         for (int m = 0; m < KMT; ++m) {
             const int t = wave * KMT + m;
             const int ig = t >> p.th_log2, ty = t & (TH - 1);
-            UMX_PUT(li, res[0][m])
+            {
+                float r0[NT][4];
+                arith(accs[0][m], r0, kTrack);
+                UMX_PUT(li, r0)
+            }
             if (p.nimg_m == 1) {   // 16 pixels of one row (every o_mul-th pixel for a per-phase transposed convolution)
                 const int img = img0 + ig;
                 const int om = p.o_mul;
@@ -617,6 +624,7 @@ __global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 3 : 2) conv_f16x3
             });
         }
     }
+    if (vmax >= 0x476a6000u) atomicOr(p.overflow_flag, 1);   // |v| >= 60000, infinity or NaN: binary16 range exceeded, the host reports it
 }
 
 template <int NT, int KMT, int NPH>

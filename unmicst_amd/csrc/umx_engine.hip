@@ -787,6 +787,12 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     const int nwaves = kWaves;
     h.kmt = fused ? 2 : kMT;
     const int epi_bytes = nwaves * 2 * stage_rows * (nt16 * 32 + 16);   // epilogue transpose staging
+    // dynamic LDS of a plan: halo slots (hi + lo) | weight buffer 0 | weight buffer 1 | the staging area, unless it fits below
+    // buffer 1 (the epilogue constants sit in buffer 1 while the staged rows are written: the kernel orders the buffers so)
+    auto lds_total = [&](int nslots, int oc, int ss, int plane_pair_bytes) {
+        const int below = nslots * oc * plane_pair_bytes, wb = 64 + ss * nt16 * 2048;
+        return below + 2 * wb + (epi_bytes <= below + wb ? 0 : epi_bytes);
+    };
 
     // One stage list (= one kernel phase, or the whole fused transposed convolution) for a given (OC, S, slot base E):
     // (tap, octet) pairs of every chunk -> k-steps of 4 -> stages of <= S k-steps.  Pairs left over when a chunk's
@@ -862,7 +868,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         // the kernel keeps one pixel index per (wave, piece of a chunk) in registers: at most 4 (NT >= 6) or 12 pieces per wave
         if (((h.nhalo + 64 / OC - 1) / (64 / OC) + nwaves - 1) / nwaves > (nt16 >= 6 ? 4 : 12)) continue;
         for (int S = 1; S <= kStageK; ++S) {
-            const int lds = nslots * OC * plane_pair + 2 * (64 + S * nt16 * 2048);
+            const int lds = lds_total(nslots, OC, S, plane_pair);
             if (lds > lds_cap) continue;
             int ksteps = 0, nchunks = 0;
             for (int list = 0; list < nlists; ++list) {
@@ -890,7 +896,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                 int nslots = 1;
                 for (int list = 0; list < nlists; ++list)
                     if (chunks_for(oc, fused ? -1 : list).size() >= 2) nslots = 2;
-                const int lds = nslots * oc * plane_pair + 2 * (64 + ss * nt16 * 2048);
+                const int lds = lds_total(nslots, oc, ss, plane_pair);
                 const bool pieces_ok = ((h.nhalo + 64 / oc - 1) / (64 / oc) + nwaves - 1) / nwaves <= (nt16 >= 6 ? 4 : 12);
                 if (lds <= kMaxLdsPerWG && pieces_ok) { bestOC = oc; bestS = ss; bestSlots = nslots; }
                 else fprintf(stderr, "[umx plan] override %s ignored (LDS %d B)\n", item.c_str(), lds);
@@ -907,16 +913,14 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     h.ninst = (h.nhalo + h.PP - 1) / h.PP;
     h.piece_bytes = h.nact * 16;
     h.inv_oc_q16 = 65536 / OC + 1;
-    {
-        const char* e = getenv("UMX_CONV_FLAGS");
-        h.flags = e ? atoi(e) : 3;
-    }
     h.pix_bytes = OC * 16;
     h.slot_bytes = h.plane_slots * OC * 16;
     h.lo_off = bestSlots * h.slot_bytes;
     h.b_off = 2 * h.lo_off;
     h.wbuf_bytes = 64 + S * nt16 * 2048;
-    h.lds_bytes = std::max(h.b_off + 2 * h.wbuf_bytes, epi_bytes);
+    // epilogue transpose staging: below weight buffer 1 when it fits there (the constants sit in buffer 1), else above it
+    h.stg_off = epi_bytes <= h.b_off + h.wbuf_bytes ? 0 : h.b_off + 2 * h.wbuf_bytes;
+    h.lds_bytes = std::max(h.b_off + 2 * h.wbuf_bytes, h.stg_off + epi_bytes);
     if (h.lds_bytes > kMaxLdsPerWG) { *why = "epilogue staging exceeds the LDS budget"; return UMX_ERR_INVALID; }
 
     std::vector<HStage> stages;
