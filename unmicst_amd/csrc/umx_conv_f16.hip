@@ -38,7 +38,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //          rows (32 consecutive pixels) are stored contiguously.
 // DBG = true: the same kernel with in-kernel s_memtime stamps (UMX_DEBUG_STAMPS); the product build carries none of it.
 template <int NT, int KMT, int NPH, bool DBG = false>
-__global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 3 : 2) conv_f16x3(const HConvParams p) {
+__global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 4 : (NT <= 5 && NPH == 1) ? 3 : 2) conv_f16x3(const HConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -60,6 +60,14 @@ __global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 3 : 2) conv_f16x3
     // blocks, [3] epilogue, [4] whole kernel
     long long t_in = 0, t_wait = 0, t_comp = 0, t_a = 0, t_b = 0, t_vm = 0, t_iss = 0;
     if (DBG && p.dbg) t_in = __builtin_amdgcn_s_memtime();
+    // ---- de-phasing.  Workgroups that share a CU start together, do identical work and stay in lockstep: they reach their
+    // MFMA blocks together (each gets half the matrix pipe) and their load / epilogue phases together (the pipe idles), so
+    // the phases add up instead of overlapping.  The first generation is therefore started at different times, by
+    // hardware wave slot; later generations inherit the offset (a workgroup starts when its predecessor in the slot ends).
+    if (p.stagger > 0 && (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) < p.first_gen) {
+        const unsigned slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) % (unsigned)p.nres;   // HW_ID.WAVE_ID
+        for (int c = (int)slot * p.stagger; c > 0; c -= 64 * 64) __builtin_amdgcn_s_sleep(64);
+    }
     // ---- per-lane A-fragment pixel offsets (bytes) of this wave's M-tiles
     int abase[KMT];
 #pragma unroll
@@ -89,7 +97,7 @@ __global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 3 : 2) conv_f16x3
     //           pieces w, w+4, ..; the NHWC pixel index each lane fetches for its j-th piece depends on the tile only, so
     //           it is computed ONCE per workgroup (pix[j]); per chunk a piece costs one multiply-add + one select.
     //   weights a linear copy: per-lane offset lane*16, the piece's position in the scalar offset: no VALU at all.
-    constexpr int MAXP = NT >= 6 ? 4 : 12;   // halo pieces per wave and chunk (the planner keeps ceil(ninst/4) <= MAXP)
+    constexpr int MAXP = (NPH == 4 && NT < 4) ? 12 : 4;   // halo pieces per wave and chunk (the planner keeps ceil(ninst/4) <= MAXP)
     const int pl = (lane * p.inv_oc_q16) >> 16;   // lane / OC   (exact for lane < 64, OC <= 9)
     const int kq = lane - pl * p.OC;              // lane % OC: octet inside the chunk
     int pix[MAXP];   // >= 0: pixel index relative to image img0; -2: zero padding; -1: this lane writes nothing

@@ -781,7 +781,12 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     {
         const char* e = getenv("UMX_LDS_CAP_NARROW");
         const int narrow = e ? atoi(e) : 53 * 1024;
-        if (!fused && nt16 <= 3 && narrow >= 16 * 1024) lds_cap = std::min(lds_cap, narrow);
+        const char* e2 = getenv("UMX_NARROW_NT");
+        const int narrow_nt = e2 ? atoi(e2) : 3;   // (the kernels of 4-5 N-tiles fit 3 waves per SIMD too: ld1.conv -12 %, lu1.conv +1 %)
+        if (!fused && nt16 <= narrow_nt && narrow >= 16 * 1024) lds_cap = std::min(lds_cap, narrow);
+        const char* e3 = getenv("UMX_LDS_CAP_NT3");
+        const int nt3 = e3 ? atoi(e3) : 40 * 1024;   // <= 3 N-tiles: 128 VGPRs, 4 workgroups per CU
+        if (!fused && nt16 <= 3 && nt3 >= 16 * 1024) lds_cap = std::min(lds_cap, nt3);
     }
     const int stage_rows = fused ? 32 : 16;
     const int nwaves = kWaves;
@@ -865,8 +870,8 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
             if (ch.size() >= 2) nslots = 2;
             for (const auto& c : ch) sectors += 2.0 * h.nhalo * ((c.o1 - c.o0 + 3) / 4);
         }
-        // the kernel keeps one pixel index per (wave, piece of a chunk) in registers: at most 4 (NT >= 6) or 12 pieces per wave
-        if (((h.nhalo + 64 / OC - 1) / (64 / OC) + nwaves - 1) / nwaves > (nt16 >= 6 ? 4 : 12)) continue;
+        // the kernel keeps one pixel index per (wave, piece of a chunk) in registers: at most 4 (12 in the fused kernels of < 4 N-tiles) pieces per wave
+        if (((h.nhalo + 64 / OC - 1) / (64 / OC) + nwaves - 1) / nwaves > ((fused && nt16 < 4) ? 12 : 4)) continue;
         for (int S = 1; S <= kStageK; ++S) {
             const int lds = lds_total(nslots, OC, S, plane_pair);
             if (lds > lds_cap) continue;
@@ -897,7 +902,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                 for (int list = 0; list < nlists; ++list)
                     if (chunks_for(oc, fused ? -1 : list).size() >= 2) nslots = 2;
                 const int lds = lds_total(nslots, oc, ss, plane_pair);
-                const bool pieces_ok = ((h.nhalo + 64 / oc - 1) / (64 / oc) + nwaves - 1) / nwaves <= (nt16 >= 6 ? 4 : 12);
+                const bool pieces_ok = ((h.nhalo + 64 / oc - 1) / (64 / oc) + nwaves - 1) / nwaves <= ((fused && nt16 < 4) ? 12 : 4);
                 if (lds <= kMaxLdsPerWG && pieces_ok) { bestOC = oc; bestS = ss; bestSlots = nslots; }
                 else fprintf(stderr, "[umx plan] override %s ignored (LDS %d B)\n", item.c_str(), lds);
             }
@@ -918,6 +923,26 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     h.lo_off = bestSlots * h.slot_bytes;
     h.b_off = 2 * h.lo_off;
     h.wbuf_bytes = 64 + S * nt16 * 2048;
+    {   // de-phasing of the workgroups that share a CU (see conv_f16x3): UMX_STAGGER = "cycles" or "layer:cycles,..."
+        h.stagger = 0;
+        h.nres = std::max(1, std::min((!fused && nt16 <= 3) ? 4 : (!fused && nt16 <= 5) ? 3 : 2, (160 * 1024) / std::max(1, lds_total(bestSlots, OC, S, plane_pair))));
+        h.first_gen = h.nres * ctx->ncu;
+        if (const char* e = getenv("UMX_STAGGER")) {
+            std::string spec(e);
+            if (spec.find(':') == std::string::npos) h.stagger = atoi(e);
+            else {
+                size_t pos = 0;
+                while (pos < spec.size()) {
+                    const size_t end = spec.find(',', pos);
+                    const std::string item = spec.substr(pos, end == std::string::npos ? std::string::npos : end - pos);
+                    const size_t c = item.find(':');
+                    if (c != std::string::npos && item.substr(0, c) == L.name) h.stagger = atoi(item.c_str() + c + 1);
+                    if (end == std::string::npos) break;
+                    pos = end + 1;
+                }
+            }
+        }
+    }
     // epilogue transpose staging: below weight buffer 1 when it fits there (the constants sit in buffer 1), else above it
     h.stg_off = epi_bytes <= h.b_off + h.wbuf_bytes ? 0 : h.b_off + 2 * h.wbuf_bytes;
     h.lds_bytes = std::max(h.b_off + 2 * h.wbuf_bytes, h.stg_off + epi_bytes);
