@@ -37,8 +37,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //          pixels -> 512 output pixels per workgroup), and the epilogue interleaves the phases so that whole output
 //          rows (32 consecutive pixels) are stored contiguously.
 // DBG = true: the same kernel with in-kernel s_memtime stamps (UMX_DEBUG_STAMPS); the product build carries none of it.
-template <int NT, int KMT, int NPH, bool DBG = false>
-__global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 4 : (NT <= 5 && NPH == 1) ? 3 : 2) conv_f16x3(const HConvParams p) {
+// MAXP: halo pieces per wave and chunk the kernel keeps a pixel index for (4 or 12; the planner picks the smallest that holds
+//       its chunking -- 12 costs 8 vector registers, i.e. a wave per SIMD on the narrow kernels).
+constexpr int conv_f16x3_waves(int NT, int NPH, int MAXP) {   // resident waves per SIMD the register budget is set for
+    return NPH != 1 ? 2 : (NT <= 3 && MAXP == 4) ? 4 : (NT <= 3 || (NT <= 5 && MAXP == 4)) ? 3 : 2;
+}
+template <int NT, int KMT, int NPH, bool DBG = false, int MAXP = 4>
+__global__ void __launch_bounds__(256, conv_f16x3_waves(NT, NPH, MAXP)) conv_f16x3(const HConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -97,7 +102,6 @@ __global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 4 : (NT <= 5 && N
     //           pieces w, w+4, ..; the NHWC pixel index each lane fetches for its j-th piece depends on the tile only, so
     //           it is computed ONCE per workgroup (pix[j]); per chunk a piece costs one multiply-add + one select.
     //   weights a linear copy: per-lane offset lane*16, the piece's position in the scalar offset: no VALU at all.
-    constexpr int MAXP = (NPH == 4 && NT < 4) ? 12 : 4;   // halo pieces per wave and chunk (the planner keeps ceil(ninst/4) <= MAXP)
     const int pl = (lane * p.inv_oc_q16) >> 16;   // lane / OC   (exact for lane < 64, OC <= 9)
     const int kq = lane - pl * p.OC;              // lane % OC: octet inside the chunk
     int pix[MAXP];   // >= 0: pixel index relative to image img0; -2: zero padding; -1: this lane writes nothing
@@ -199,6 +203,9 @@ __global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 4 : (NT <= 5 && N
     // the stage table is read through the constant address space: a plain global pointer gets a VECTOR load and a full
     // s_waitcnt vmcnt(0) round trip at the top of every stage (the kernel stores and fences, so the compiler will not
     // prove the table unclobbered); the host writes it before the launch and nothing writes it afterwards
+    // (tried: 32-byte records with every per-stage quantity resolved on the host, loaded two stages ahead -- hipcc waits for
+    // the scalar load where it is issued, because it reuses a destination register at once, and the 8 extra scalar
+    // registers cost more than the arithmetic they save: 1-2 % slower)
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     static_assert(sizeof(HStage) == 16, "one stage = one 16-byte scalar load");
     auto load_stage = [&](int idx) {
@@ -635,29 +642,37 @@ __global__ void __launch_bounds__(256, (NT <= 3 && NPH == 1) ? 4 : (NT <= 5 && N
     if (vmax >= 0x476a6000u) atomicOr(p.overflow_flag, 1);   // |v| >= 60000, infinity or NaN: binary16 range exceeded, the host reports it
 }
 
-template <int NT, int KMT, int NPH>
-static hipError_t launch_h_nt(const HConvParams& p, hipStream_t stream) {
+template <int NT, int KMT, int NPH, bool DBG, int MAXP>
+static hipError_t launch_h_k(const HConvParams& p, hipStream_t stream) {
     const int img_groups = (p.B + p.imgs - 1) / p.imgs;
     dim3 grid((unsigned)(img_groups * p.tiles_y * p.tiles_x), (unsigned)p.nblocks, (unsigned)(NPH == 1 ? p.nphase : 1));
     const size_t lds = (size_t)p.lds_bytes;
-    if constexpr (NT == 3 || NT == 5 || NT == 9) {   // the stamped twins exist for the tile counts the bench graphs use
-        if (p.dbg) {
-            const void* kd = reinterpret_cast<const void*>(conv_f16x3<NT, KMT, NPH, true>);
-            if (lds > 48 * 1024) {
-                hipError_t e = hipFuncSetAttribute(kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return e;
-            }
-            hipLaunchKernelGGL((conv_f16x3<NT, KMT, NPH, true>), grid, dim3(256), lds, stream, p);
-            return hipGetLastError();
-        }
-    }
-    const void* kern = reinterpret_cast<const void*>(conv_f16x3<NT, KMT, NPH>);
+    const void* kern = reinterpret_cast<const void*>(conv_f16x3<NT, KMT, NPH, DBG, MAXP>);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((conv_f16x3<NT, KMT, NPH>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_f16x3<NT, KMT, NPH, DBG, MAXP>), grid, dim3(256), lds, stream, p);
     return hipGetLastError();
+}
+
+// instantiations: MAXP = 4 everywhere; MAXP = 12 in addition for <= 5 N-tiles (12 only for the fused kernels of <= 3)
+template <int NT, int KMT, int NPH>
+static hipError_t launch_h_nt(const HConvParams& p, hipStream_t stream) {
+    constexpr bool has4 = !(NPH == 4 && NT <= 3), has12 = NT <= 5 && !(NPH == 4 && NT > 3);
+    if (p.maxp != 4 && p.maxp != 12) return hipErrorInvalidValue;
+    if constexpr (has12) {
+        if (p.maxp == 12) return launch_h_k<NT, KMT, NPH, false, 12>(p, stream);
+    }
+    if constexpr (has4) {
+        if (p.maxp == 4) {
+            if constexpr (NT == 3 || NT == 5 || NT == 9) {   // the stamped twins exist for the tile counts the bench graphs use
+                if (p.dbg) return launch_h_k<NT, KMT, NPH, true, 4>(p, stream);
+            }
+            return launch_h_k<NT, KMT, NPH, false, 4>(p, stream);
+        }
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_conv_f16(const HConvParams& p, hipStream_t stream) {

@@ -775,18 +775,31 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     };
     const int nlists = fused ? 1 : L.nphase;   // independent stage lists (= kernel phases)
     auto phases_of = [&](int list) { return fused ? std::make_pair(0, L.nphase) : std::make_pair(list, list + 1); };
-    // LDS budget per workgroup: 80 KiB = 2 workgroups per CU; narrow layers (few accumulators -> few VGPRs) get a smaller
-    // budget so that 3 workgroups per CU cover each other
-    int lds_cap = kMaxLdsPerWG;
+    // Search attempts, in order of preference: (pieces per wave and chunk the kernel instantiation indexes, LDS budget per
+    // workgroup).  80 KiB = 2 workgroups per CU; narrow layers (few accumulators -> few VGPRs) first try the budgets that let
+    // 4 (<= 3 N-tiles, 128 VGPRs) or 3 workgroups per CU cover each other, and the 4-piece instantiation (8 VGPRs fewer).
+    struct Attempt { int maxp, cap, max_chunks; };
+    std::vector<Attempt> attempts;
     {
         const char* e = getenv("UMX_LDS_CAP_NARROW");
         const int narrow = e ? atoi(e) : 53 * 1024;
         const char* e2 = getenv("UMX_NARROW_NT");
-        const int narrow_nt = e2 ? atoi(e2) : 3;   // (the kernels of 4-5 N-tiles fit 3 waves per SIMD too: ld1.conv -12 %, lu1.conv +1 %)
-        if (!fused && nt16 <= narrow_nt && narrow >= 16 * 1024) lds_cap = std::min(lds_cap, narrow);
+        const int narrow_nt = e2 ? atoi(e2) : 5;   // the kernels of <= 5 N-tiles fit 3 waves per SIMD
         const char* e3 = getenv("UMX_LDS_CAP_NT3");
-        const int nt3 = e3 ? atoi(e3) : 40 * 1024;   // <= 3 N-tiles: 128 VGPRs, 4 workgroups per CU
-        if (!fused && nt16 <= 3 && nt3 >= 16 * 1024) lds_cap = std::min(lds_cap, nt3);
+        const int nt3 = e3 ? atoi(e3) : 40 * 1024;
+        if (fused) attempts = {{nt16 <= 3 ? 12 : 4, kMaxLdsPerWG, 1 << 30}};   // (the fused kernels exist in one piece count each)
+        else {
+            for (int maxp : {4, 12}) {
+                if (maxp == 12 && nt16 > 5) break;
+                // (4-5 N-tiles: the third workgroup per CU pays only while the smaller chunks stay few -- ld1.conv, 6 chunks:
+                // -12 %; lu1.conv, 24 chunks: +1 %)
+                const char* e4 = getenv("UMX_NARROW_MAXCHUNKS");
+                const int few = nt16 <= 3 ? 1 << 30 : e4 ? atoi(e4) : 8;
+                if (nt16 <= 3 && maxp == 4 && nt3 >= 16 * 1024) attempts.push_back({maxp, std::min(nt3, kMaxLdsPerWG), 1 << 30});
+                if (nt16 <= narrow_nt && narrow >= 16 * 1024) attempts.push_back({maxp, std::min(narrow, kMaxLdsPerWG), few});
+                attempts.push_back({maxp, kMaxLdsPerWG, 1 << 30});
+            }
+        }
     }
     const int stage_rows = fused ? 32 : 16;
     const int nwaves = kWaves;
@@ -814,10 +827,15 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         if (nchunks) *nchunks = (int)ch.size();
         int nsteps = 0;
         std::vector<Pair> carry;
+        const size_t list_base = stages_out ? stages_out->size() : 0;
+        std::vector<int> first_stage(ch.size(), -1);      // per chunk: index (in stages_out) of its first stage
+        std::vector<char> carried_in(ch.size(), 0);       // per chunk: its first k-step still reads the previous chunk's slot
         for (size_t c = 0; c < ch.size(); ++c) {
             const int gi = ch[c].gi, o0 = ch[c].o0, o1 = ch[c].o1;
             const int slot = (int)(c & 1);   // consecutive chunks alternate between the two halo slots
             bool first = true;   // the chunk's first stage carries its halo load
+            carried_in[c] = !carry.empty();
+            if (stages_out) first_stage[c] = (int)stages_out->size();
             for (int ph = pr.first; ph < pr.second; ++ph) {
                 const int nt = (int)L.g[gi].taps[ph].size();
                 if (!nt) continue;
@@ -854,14 +872,35 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                 }
             }
         }
+        // Early halo issue.  The kernel issues the load a stage record carries at the top of the stage BEFORE it, i.e. by
+        // default one stage ahead of the chunk's first k-step -- less than a load's round trip under load on the short
+        // stages of the narrow layers.  The slot of chunk c is free as soon as chunk c-2 is done with it: after the barrier
+        // that opens chunk c-1's first stage, or its second one when chunk c-1's first k-step carries pairs of chunk c-2.
+        // The load record of chunk c therefore moves to the stage after that barrier's stage (never past its own chunk).
+        static const bool early = getenv("UMX_EARLY_HALO") != nullptr;   // opt-in: neutral on the whole step (lu0.conv +6 %, lu2.convT -6 %)
+        if (stages_out && early)
+            for (size_t c = 1; c < ch.size(); ++c) {
+                const int own = first_stage[c], prev = first_stage[c - 1];
+                if (own < 0 || prev < 0) continue;
+                const int tgt = std::max((int)list_base + 1, prev + (carried_in[c - 1] ? 2 : 1));
+                if (tgt >= own) continue;
+                HStage& from = (*stages_out)[own];
+                HStage& to = (*stages_out)[tgt];
+                if (from.group < 0 || to.group >= 0) continue;   // (one load per record)
+                to.group = from.group; to.oct0 = from.oct0; to.noct = from.noct; to.plane0 = from.plane0;
+                from.group = -1;
+            }
         return nsteps;
     };
 
     // (OC, S) search.  OC = octets per staged pixel (pixel pitch OC*16 B in the LDS image).  Odd OC maps 16 consecutive pixels
     // at one octet to 16 distinct 16-byte bank groups (conflict-free fragment reads); even OC costs 2- to 4-way conflicts
     // on those reads, which the kernels tolerate (LDS reads are not their limit) -- a mild penalty only.
-    int bestOC = 0, bestS = 0, bestSlots = 1;
+    int bestOC = 0, bestS = 0, bestSlots = 1, maxp = 4;
     double bestCost = 1e30;
+    for (size_t at = 0; at < attempts.size() && !bestOC; ++at) {
+    maxp = attempts[at].maxp;
+    const int lds_cap = attempts[at].cap;
     for (int OC = 1; OC <= 9; ++OC) {
         int nslots = 1;
         double sectors = 0;   // 64-byte memory requests of the halo loads of one workgroup
@@ -870,8 +909,8 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
             if (ch.size() >= 2) nslots = 2;
             for (const auto& c : ch) sectors += 2.0 * h.nhalo * ((c.o1 - c.o0 + 3) / 4);
         }
-        // the kernel keeps one pixel index per (wave, piece of a chunk) in registers: at most 4 (12 in the fused kernels of < 4 N-tiles) pieces per wave
-        if (((h.nhalo + 64 / OC - 1) / (64 / OC) + nwaves - 1) / nwaves > ((fused && nt16 < 4) ? 12 : 4)) continue;
+        // the kernel keeps one pixel index per (wave, piece of a chunk) in registers
+        if (((h.nhalo + 64 / OC - 1) / (64 / OC) + nwaves - 1) / nwaves > maxp) continue;
         for (int S = 1; S <= kStageK; ++S) {
             const int lds = lds_total(nslots, OC, S, plane_pair);
             if (lds > lds_cap) continue;
@@ -884,8 +923,10 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
             // executed k-steps (exact) with a barrier/latency charge per stage, a charge per halo chunk load (measured
             // ~0.35 k-steps on the deep layers) and per 64-byte halo request (halo reloads measured at 8-22 % of a layer)
             const double cost = (ksteps * (1.0 + 0.30 / S) + 0.35 * nchunks + sectors / 1500.0) * ((OC & 1) ? 1.0 : 1.03);
+            if (nchunks > attempts[at].max_chunks) continue;
             if (cost < bestCost) { bestCost = cost; bestOC = OC; bestS = S; bestSlots = nslots; }
         }
+    }
     }
     if (!bestOC) { *why = "LDS footprint too large for the split-precision kernel"; return UMX_ERR_INVALID; }
     if (const char* e = getenv("UMX_PLAN_OVERRIDE")) {   // tuning aid: "layer:OC:S[,layer:OC:S...]" forces a layer's (OC, S)
@@ -895,14 +936,15 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
             const size_t end = spec.find(',', pos);
             const std::string item = spec.substr(pos, end == std::string::npos ? std::string::npos : end - pos);
             char nm[64];
-            int oc = 0, ss = 0;
-            if (sscanf(item.c_str(), "%63[^:]:%d:%d", nm, &oc, &ss) == 3 && L.name == nm && oc >= 1 && oc <= 9 && ss >= 1 &&
-                ss <= kStageK) {
+            int oc = 0, ss = 0, mp = 0;
+            const int nf = sscanf(item.c_str(), "%63[^:]:%d:%d:%d", nm, &oc, &ss, &mp);
+            if (nf >= 3 && L.name == nm && oc >= 1 && oc <= 9 && ss >= 1 && ss <= kStageK) {
+                if (nf == 4 && (mp == 4 || (mp == 12 && nt16 <= 5)) && !fused) maxp = mp;
                 int nslots = 1;
                 for (int list = 0; list < nlists; ++list)
                     if (chunks_for(oc, fused ? -1 : list).size() >= 2) nslots = 2;
                 const int lds = lds_total(nslots, oc, ss, plane_pair);
-                const bool pieces_ok = ((h.nhalo + 64 / oc - 1) / (64 / oc) + nwaves - 1) / nwaves <= ((fused && nt16 < 4) ? 12 : 4);
+                const bool pieces_ok = ((h.nhalo + 64 / oc - 1) / (64 / oc) + nwaves - 1) / nwaves <= maxp;
                 if (lds <= kMaxLdsPerWG && pieces_ok) { bestOC = oc; bestS = ss; bestSlots = nslots; }
                 else fprintf(stderr, "[umx plan] override %s ignored (LDS %d B)\n", item.c_str(), lds);
             }
@@ -914,6 +956,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     h.OC = OC;
     h.inv_OC = 1.f / (float)OC;
     h.PP = 64 / OC;
+    h.maxp = maxp;
     h.nact = h.PP * OC;
     h.ninst = (h.nhalo + h.PP - 1) / h.PP;
     h.piece_bytes = h.nact * 16;
@@ -925,7 +968,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     h.wbuf_bytes = 64 + S * nt16 * 2048;
     {   // de-phasing of the workgroups that share a CU (see conv_f16x3): UMX_STAGGER = "cycles" or "layer:cycles,..."
         h.stagger = 0;
-        h.nres = std::max(1, std::min((!fused && nt16 <= 3) ? 4 : (!fused && nt16 <= 5) ? 3 : 2, (160 * 1024) / std::max(1, lds_total(bestSlots, OC, S, plane_pair))));
+        h.nres = std::max(1, std::min(fused ? 2 : (nt16 <= 3 && maxp == 4) ? 4 : (nt16 <= 3 || (nt16 <= 5 && maxp == 4)) ? 3 : 2, (160 * 1024) / std::max(1, lds_total(bestSlots, OC, S, plane_pair))));
         h.first_gen = h.nres * ctx->ncu;
         if (const char* e = getenv("UMX_STAGGER")) {
             std::string spec(e);
