@@ -101,7 +101,7 @@ def im2double(torch, u16_i32):
 
 
 def pmc_traffic(kernel, precision, batch):
-    """HBM bytes per launch of `kernel` (a template instantiation as rocprofv3 names it, e.g. "conv_f16x3<9, 4, 1>"),
+    """HBM bytes per launch of `kernel` (a template instantiation as rocprofv3 names it, e.g. "conv_f16x3<9, 4, 1, false, 4>": N-tiles, M-tiles per wave, phases, stamped twin, pixel-index array),
     averaged over its launches, from the committed rocprofv3 counter passes of this same command
     (profiles/rNN/final_<precision>_b<batch>_by_layer_pmc.csv, written by tools/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE collected
     in separate --pmc passes, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  None when no profile of
