@@ -31,7 +31,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
 // NPH = 1: one output phase per workgroup (plain convolutions; transposed convolutions one sub-pixel phase at a time,
-//          phase = blockIdx.z), KMT = 4 M-tiles per wave (256 pixels per workgroup).
+//          phase = blockIdx.z), KMT = 4 M-tiles per wave (256 pixels per workgroup: a 16 x 16 tile), or KMT = 8 for the
+//          layers of <= 3 N-tiles (512 pixels: 16 wide x 32 tall -- half the weight traffic, stage overhead and weight
+//          fragment reads per MFMA, at 2 instead of 4 resident workgroups per CU).
 // NPH = 4: stride-2 transposed convolution with all four sub-pixel phases in one workgroup: the input halo is loaded
 //          once instead of four times, every stage carries the phase whose accumulators it feeds, KMT = 2 (128 input
 //          pixels -> 512 output pixels per workgroup), and the epilogue interleaves the phases so that whole output
@@ -39,11 +41,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // DBG = true: the same kernel with in-kernel s_memtime stamps (UMX_DEBUG_STAMPS); the product build carries none of it.
 // MAXP: halo pieces per wave and chunk the kernel keeps a pixel index for (4 or 12; the planner picks the smallest that holds
 //       its chunking -- 12 costs 8 vector registers, i.e. a wave per SIMD on the narrow kernels).
-constexpr int conv_f16x3_waves(int NT, int NPH, int MAXP) {   // resident waves per SIMD the register budget is set for
-    return NPH != 1 ? 2 : (NT <= 3 && MAXP == 4) ? 4 : (NT <= 3 || (NT <= 5 && MAXP == 4)) ? 3 : 2;
+constexpr int conv_f16x3_waves(int NT, int KMT, int NPH, int MAXP) {   // resident waves per SIMD the register budget is set for
+    return (NPH != 1 || KMT > 4) ? 2 : (NT <= 3 && MAXP == 4) ? 4 : (NT <= 3 || (NT <= 5 && MAXP == 4)) ? 3 : 2;
 }
 template <int NT, int KMT, int NPH, bool DBG = false, int MAXP = 4>
-__global__ void __launch_bounds__(256, conv_f16x3_waves(NT, NPH, MAXP)) conv_f16x3(const HConvParams p) {
+__global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) conv_f16x3(const HConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -659,7 +661,7 @@ static hipError_t launch_h_k(const HConvParams& p, hipStream_t stream) {
 // instantiations: MAXP = 4 everywhere; MAXP = 12 in addition for <= 5 N-tiles (12 only for the fused kernels of <= 3)
 template <int NT, int KMT, int NPH>
 static hipError_t launch_h_nt(const HConvParams& p, hipStream_t stream) {
-    constexpr bool has4 = !(NPH == 4 && NT <= 3), has12 = NT <= 5 && !(NPH == 4 && NT > 3);
+    constexpr bool has4 = !(NPH == 4 && NT <= 3), has12 = NT <= 5 && !(NPH == 4 && NT > 3) && KMT <= 4;
     if (p.maxp != 4 && p.maxp != 12) return hipErrorInvalidValue;
     if constexpr (has12) {
         if (p.maxp == 12) return launch_h_k<NT, KMT, NPH, false, 12>(p, stream);
@@ -683,6 +685,14 @@ hipError_t launch_conv_f16(const HConvParams& p, hipStream_t stream) {
             case 3: return launch_h_nt<3, 2, 4>(p, stream);
             case 4: return launch_h_nt<4, 2, 4>(p, stream);
             case 5: return launch_h_nt<5, 2, 4>(p, stream);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    if (p.kmt == 8) {
+        switch (p.NT) {
+            case 1: return launch_h_nt<1, 8, 1>(p, stream);
+            case 2: return launch_h_nt<2, 8, 1>(p, stream);
+            case 3: return launch_h_nt<3, 8, 1>(p, stream);
             default: return hipErrorInvalidValue;
         }
     }

@@ -723,6 +723,15 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         h.twm_log2 = g.twm_log2; h.th_log2 = g.th_log2; h.nimg_m = g.nimg_m; h.imgs = g.imgs;
         h.hh = g.hh; h.hw = g.hw; h.tiles_y = g.tiles_y; h.tiles_x = g.tiles_x;
     }
+    // narrow layers on full 16 x 16 tiles: 16 x 32 tiles, 8 M-tiles per wave.  Opt-in (UMX_TALL=1): half the weight traffic
+    // and stage overhead per MFMA, but 215 VGPRs = 2 resident workgroups instead of 4 -- measured lu0.conv +14 %, ld0.conv +15 %
+    static const bool tall_ok = getenv("UMX_TALL") && atoi(getenv("UMX_TALL")) != 0;
+    const bool tall = tall_ok && !fused && t16 <= 3 && g.twm_log2 == 4 && g.th_log2 == 4 && g.imgs == 1 && L.H >= 32 && (L.H & 31) == 0;
+    if (tall) {
+        h.th_log2 = 5;
+        h.hh = 32 + (g.hh - 16);
+        h.tiles_y = L.H / 32;
+    }
     h.imgplane = h.hh * h.hw; h.nhalo = h.imgs * h.imgplane;
     h.ymin = g.ymin; h.xmin = g.xmin;
     h.nphase = L.nphase; h.o_mul = L.o_mul;
@@ -788,6 +797,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         const char* e3 = getenv("UMX_LDS_CAP_NT3");
         const int nt3 = e3 ? atoi(e3) : 40 * 1024;
         if (fused) attempts = {{nt16 <= 3 ? 12 : 4, kMaxLdsPerWG, 1 << 30}};   // (the fused kernels exist in one piece count each)
+        else if (tall) attempts = {{4, kMaxLdsPerWG, 1 << 30}};   // (192+ VGPRs: two workgroups per CU whatever the LDS)
         else {
             for (int maxp : {4, 12}) {
                 if (maxp == 12 && nt16 > 5) break;
@@ -803,7 +813,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     }
     const int stage_rows = fused ? 32 : 16;
     const int nwaves = kWaves;
-    h.kmt = fused ? 2 : kMT;
+    h.kmt = fused ? 2 : tall ? 8 : kMT;
     const int epi_bytes = nwaves * 2 * stage_rows * (nt16 * 32 + 16);   // epilogue transpose staging
     // dynamic LDS of a plan: halo slots (hi + lo) | weight buffer 0 | weight buffer 1 | the staging area, unless it fits below
     // buffer 1 (the epilogue constants sit in buffer 1 while the staged rows are written: the kernel orders the buffers so)
@@ -968,7 +978,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     h.wbuf_bytes = 64 + S * nt16 * 2048;
     {   // de-phasing of the workgroups that share a CU (see conv_f16x3): UMX_STAGGER = "cycles" or "layer:cycles,..."
         h.stagger = 0;
-        h.nres = std::max(1, std::min(fused ? 2 : (nt16 <= 3 && maxp == 4) ? 4 : (nt16 <= 3 || (nt16 <= 5 && maxp == 4)) ? 3 : 2, (160 * 1024) / std::max(1, lds_total(bestSlots, OC, S, plane_pair))));
+        h.nres = std::max(1, std::min((fused || tall) ? 2 : (nt16 <= 3 && maxp == 4) ? 4 : (nt16 <= 3 || (nt16 <= 5 && maxp == 4)) ? 3 : 2, (160 * 1024) / std::max(1, lds_total(bestSlots, OC, S, plane_pair))));
         h.first_gen = h.nres * ctx->ncu;
         if (const char* e = getenv("UMX_STAGGER")) {
             std::string spec(e);
