@@ -140,12 +140,16 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lptr), 16, voff, soff, 0, 0)
 
     // all pieces of one halo chunk: octets [oct0, oct0+noct) of operand group `group` into halo slot `plane0`
+    // (pixel, octet) -> byte offset inside the image: pixel * A + octet * B, (A, B) = (2 Cs, 16) for NHWC planes and
+    // (16, H*W*16) for octet-planar ones (every 128-byte line is then read by exactly one octet chunk)
+    const int kqB0 = kq * p.srcB[0], kqB1 = kq * p.srcB[1];
     auto issue_halo = [&](const HStage& st) {
         const bool g1 = st.group > 0;
-        const int Cs2 = p.Cs[g1 ? 1 : 0] * 2;               // bytes per pixel of one plane
+        const int pixA = p.srcA[g1 ? 1 : 0];
+        const int kqB = g1 ? kqB1 : kqB0;
         const __amdgpu_buffer_rsrc_t rh = g1 ? r1h : r0h, rl = g1 ? r1l : r0l;
         unsigned char* const slot = smem + st.plane0 * p.slot_bytes;
-        const int soff = st.oct0 * 16;
+        const int soff = st.oct0 * p.srcB[g1 ? 1 : 0];
         const bool kok = kq < st.noct;
 #pragma unroll
         for (int j = 0; j < MAXP; ++j) {
@@ -154,7 +158,7 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
             int pj = pix[j];
             asm volatile("" : "+v"(pj));         // compare here: hoisted, the 12 lane masks live in (spilled) scalar pairs
             if (pj != -1 && kok) {               // lanes of this piece
-                const int voff = pj >= 0 ? (int)__umul24(pj, Cs2) + kq * 16 : 0x7fffffff;
+                const int voff = pj >= 0 ? (int)__umul24(pj, pixA) + kqB : 0x7fffffff;
                 UMX_BLDS16(rh, slot + i * p.piece_bytes, voff, soff);
                 UMX_BLDS16(rl, slot + lo_off + i * p.piece_bytes, voff, soff);
             }
@@ -478,55 +482,66 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
         }
     }
 
-    // staged rows [0, R) -> global; pixel_of(row) gives the NHWC pixel index or -1
-    auto flush = [&](int R, auto pixel_of) {
+    // Destination addressing, in binary16 elements from the plane's start: image * dImg + pixel * dPix + octet * dOct --
+    // NHWC: (Cds, 8); octet-planar (per image [octet][pixel][8]): (8, outH*outW*8).  In the planar form a wave's lanes walk
+    // pixels first (16 consecutive pixels of one octet = 256 contiguous bytes), in NHWC octets first (one pixel's channels).
+    const bool dpl = p.dst_planar != 0;
+    const long dImg = (long)p.Cds * p.outH * p.outW;
+    const int dPix = dpl ? 8 : p.Cds;
+    const int dOct = dpl ? p.outH * p.outW * 8 : 8;
+    // staged rows [0, R) -> global; elem_of(row) gives the element offset of the row's pixel (octet 0) or -1
+    auto flush = [&](auto RC, auto elem_of) {
+        constexpr int R = decltype(RC)::value;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         int ln = lane;
         asm volatile("" : "+v"(ln));   // the unit addressing is computed here, not hoisted across the epilogue arithmetic
 #pragma unroll
         for (int k = 0; k < (ROWS * UR + 63) / 64; ++k) {
             const int u = ln + 64 * k;
-            const int row = u / UR, cu = u - row * UR;
+            const int row = dpl ? (u & (R - 1)) : u / UR, cu = dpl ? u / R : u - (u / UR) * UR;
             const int c0 = nblk * (NT * 16) + cu * 8;
-            if (row < R && c0 < p.Cds) {
-                const long pix = pixel_of(row);
-                if (pix >= 0) {
+            if (row < R && cu < UR && c0 < p.Cds) {
+                const long e0 = elem_of(row);
+                if (e0 >= 0) {
                     uint4 vh = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16);
                     uint4 vl = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16 + PLANE);
-                    if (p.app_hi && c0 == p.app_c0) {   // appended channels (exact zeros so far: padded output channels)
+                    const long e = e0 + (long)(c0 >> 3) * dOct;
+                    if (p.app_hi && c0 == p.app_c0) {   // appended channels (NHWC plans only; exact zeros so far: padded output channels)
+                        const long pix = e0 / p.Cds;
                         const unsigned ah = *reinterpret_cast<const unsigned*>(p.app_hi + pix * p.app_Cs);
                         const unsigned al = *reinterpret_cast<const unsigned*>(p.app_lo + pix * p.app_Cs);
                         if (p.app_word == 1) { vh.y = ah; vl.y = al; }
                         else if (p.app_word == 2) { vh.z = ah; vl.z = al; }
                         else { vh.w = ah; vl.w = al; }
                     }
-                    *reinterpret_cast<uint4*>(p.dst_hi + pix * p.Cds + c0) = vh;
-                    *reinterpret_cast<uint4*>(p.dst_lo + pix * p.Cds + c0) = vl;
+                    *reinterpret_cast<uint4*>(p.dst_hi + e) = vh;
+                    *reinterpret_cast<uint4*>(p.dst_lo + e) = vl;
                 }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staged rows are in registers before the next tile overwrites
     };
     // the same for tiles whose staged rows are the pixels of ONE image row segment (tile width 16: every full-resolution
-    // layer): the row segment's address is wave-uniform (scalar), a lane only adds a 32-bit element offset xo(row)*Cds + c0
-    auto flush_row = [&](int R, long seg_pix /* first pixel of the segment, or -1 */, auto xo) {
+    // layer): the segment's address is wave-uniform (scalar), a lane only adds a 32-bit element offset
+    auto flush_row = [&](auto RC, long seg_elem /* element offset of the segment's first pixel, or -1 */, auto xo) {
+        constexpr int R = decltype(RC)::value;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (seg_pix >= 0) {
-            _Float16* const bh = p.dst_hi + seg_pix * p.Cds;
-            _Float16* const bl = p.dst_lo + seg_pix * p.Cds;
+        if (seg_elem >= 0) {
+            _Float16* const bh = p.dst_hi + seg_elem;
+            _Float16* const bl = p.dst_lo + seg_elem;
             int ln = lane;
             asm volatile("" : "+v"(ln));   // (as in flush)
 #pragma unroll
             for (int k = 0; k < (ROWS * UR + 63) / 64; ++k) {
                 const int u = ln + 64 * k;
-                const int row = u / UR, cu = u - row * UR;
+                const int row = dpl ? (u & (R - 1)) : u / UR, cu = dpl ? u / R : u - (u / UR) * UR;
                 const int c0 = nblk * (NT * 16) + cu * 8;
-                if (row < R && c0 < p.Cds) {
-                    const int off = xo(row) * p.Cds + c0;
+                if (row < R && cu < UR && c0 < p.Cds) {
+                    const int off = xo(row) * dPix + (c0 >> 3) * dOct;
                     uint4 vh = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16);
                     uint4 vl = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16 + PLANE);
-                    if (p.app_hi && c0 == p.app_c0) {   // appended channels (exact zeros so far: padded output channels)
-                        const long pix = seg_pix + xo(row);
+                    if (p.app_hi && c0 == p.app_c0) {   // appended channels (NHWC plans only)
+                        const long pix = seg_elem / p.Cds + xo(row);
                         const unsigned ah = *reinterpret_cast<const unsigned*>(p.app_hi + pix * p.app_Cs);
                         const unsigned al = *reinterpret_cast<const unsigned*>(p.app_lo + pix * p.app_Cs);
                         if (p.app_word == 1) { vh.y = ah; vl.y = al; }
@@ -540,6 +555,10 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
+    auto elem_at = [&](int img, int y, int x) -> long { return (long)img * dImg + ((long)y * p.outW + x) * dPix; };
+    constexpr std::integral_constant<int, 8> kR8{};
+    constexpr std::integral_constant<int, 16> kR16{};
+    constexpr std::integral_constant<int, 32> kR32{};
 #define UMX_PUT(row, A) /* this lane's 4 channels of every N-tile of result row A -> staged row */ \
     _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                        \
         h4 hi, lo;                                                                                           \
@@ -571,15 +590,14 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
                 }
                 if (p.nimg_m == 1) {   // 32 consecutive output pixels of one row
                     const int img = img0 + ig;
-                    flush_row(32, img < p.B ? (long)(img * p.outH + (y0 + ty) * 2 + pu) * p.outW + x0 * 2 : -1,
-                              [](int row) { return row; });
+                    flush_row(kR32, img < p.B ? elem_at(img, (y0 + ty) * 2 + pu, x0 * 2) : -1, [](int row) { return row; });
                     continue;
                 }
-                flush(32, [&](int row) -> long {
+                flush(kR32, [&](int row) -> long {
                     const int i = row >> 1;
                     const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
                     if (img >= p.B) return -1;
-                    return (long)(img * p.outH + (y0 + ty) * 2 + pu) * p.outW + (x0 + (i & (TWm - 1))) * 2 + (row & 1);
+                    return elem_at(img, (y0 + ty) * 2 + pu, (x0 + (i & (TWm - 1))) * 2 + (row & 1));
                 });
             }
         }
@@ -605,15 +623,14 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
             if ((li & 1) == 0) { UMX_PUT(li >> 1, r0) }   // pooled pixel j = li/2 of the 8 this M-tile pair produces
             if (p.nimg_m == 1) {   // 8 consecutive pooled pixels of one row
                 const int img = img0 + ig;
-                flush_row(8, img < p.B ? (long)(img * p.outH + ((y0 + ty) >> 1)) * p.outW + (x0 >> 1) : -1,
-                          [](int row) { return row; });
+                flush_row(kR8, img < p.B ? elem_at(img, (y0 + ty) >> 1, x0 >> 1) : -1, [](int row) { return row; });
                 continue;
             }
-            flush(8, [&](int j) -> long {
+            flush(kR8, [&](int j) -> long {
                 const int i = 2 * j;
                 const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
                 if (img >= p.B) return -1;
-                return (long)(img * p.outH + ((y0 + ty) >> 1)) * p.outW + ((x0 + (i & (TWm - 1))) >> 1);
+                return elem_at(img, (y0 + ty) >> 1, (x0 + (i & (TWm - 1))) >> 1);
             });
         }
     } else {
@@ -629,15 +646,14 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
             if (p.nimg_m == 1) {   // 16 pixels of one row (every o_mul-th pixel for a per-phase transposed convolution)
                 const int img = img0 + ig;
                 const int om = p.o_mul;
-                flush_row(16, img < p.B ? (long)(img * p.outH + (y0 + ty) * om + ph.oy_off) * p.outW + x0 * om + ph.ox_off : -1,
+                flush_row(kR16, img < p.B ? elem_at(img, (y0 + ty) * om + ph.oy_off, x0 * om + ph.ox_off) : -1,
                           [om](int row) { return row * om; });
                 continue;
             }
-            flush(16, [&](int i) -> long {
+            flush(kR16, [&](int i) -> long {
                 const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
                 if (img >= p.B) return -1;
-                return (long)(img * p.outH + (y0 + ty) * p.o_mul + ph.oy_off) * p.outW +
-                       (x0 + (i & (TWm - 1))) * p.o_mul + ph.ox_off;
+                return elem_at(img, (y0 + ty) * p.o_mul + ph.oy_off, (x0 + (i & (TWm - 1))) * p.o_mul + ph.ox_off);
             });
         }
     }

@@ -78,6 +78,7 @@ struct Buffer {
     int S = 0, C = 0;        // spatial size and real channels of the tensor
     int Cs = 0;              // stored channels of the (hi, lo) binary16 form
     bool as_f32 = true;      // fp32 NHWC (f32 path, and the head's input in the f16 path) or (hi, lo) binary16 planes
+    bool planar = false;     // (hi, lo) planes stored per image as [octet][pixel][8] instead of NHWC (tensors of >= 16 x 16 pixels)
     float* d = nullptr;
 };
 
@@ -1221,16 +1222,21 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
     }
     HConvParams p = L.hcp;
     p.B = ns;
+    bool any_planar = false;
     for (int gi = 0; gi < L.ngroups; ++gi) {
         const Buffer& sb = cur_bufs(ctx)[L.g[gi].src];
         p.src_hi[gi] = hi_at(sb);
         p.src_lo[gi] = lo_at(sb);
         p.Cs[gi] = sb.Cs;
+        p.srcA[gi] = sb.planar ? 16 : sb.Cs * 2;
+        p.srcB[gi] = sb.planar ? sb.S * sb.S * 16 : 16;
+        if (sb.planar) any_planar = true;
     }
+    if (L.ngroups < 2) { p.srcA[1] = p.srcA[0]; p.srcB[1] = p.srcB[0]; }
     const Buffer& db = cur_bufs(ctx)[L.dst];
     if (p.head_K > 0) p.probs = probs + (size_t)k0 * L.H * L.W * p.head_K;   // fused softmax head
     else if (db.as_f32) p.dst_f32 = db.d + (size_t)k0 * db.floats_per_tile;
-    else { p.dst_hi = hi_at(db); p.dst_lo = lo_at(db); }
+    else { p.dst_hi = hi_at(db); p.dst_lo = lo_at(db); p.dst_planar = db.planar ? 1 : 0; }
     if (L.app_src >= 0) {
         const Buffer& ab = cur_bufs(ctx)[L.app_src];
         p.app_hi = hi_at(ab); p.app_lo = lo_at(ab); p.app_Cs = ab.Cs;
@@ -1262,7 +1268,7 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
             return UMX_OK;
         }
     }
-    if (L.use_rw && (size_t)ns * L.H * L.W * std::max(p.Cs[0], p.Cs[1]) * 2 < 0x7fffffffu) {
+    if (L.use_rw && !any_planar && (size_t)ns * L.H * L.W * std::max(p.Cs[0], p.Cs[1]) * 2 < 0x7fffffffu) {
         RwParams r = L.rw;
         r.B = ns;
         for (int gi = 0; gi < L.ngroups; ++gi) { r.src_hi[gi] = p.src_hi[gi]; r.src_lo[gi] = p.src_lo[gi]; r.Cs[gi] = p.Cs[gi]; }
@@ -1526,6 +1532,18 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
         B.C = b.buf_geom[i].second;
         B.Cs = round_up(B.C, 8);
         B.as_f32 = !f16 || (int)i == head_src;
+        // Octet-planar storage for the tensors whose consumers work on whole 16 x 16 (or 8 x 16) tiles of ONE image: a
+        // workgroup reads its halo once per octet chunk, and in NHWC every chunk touches every 128-byte line of the
+        // footprint (lu0.conv fetched 8.9 GB per launch through L2 for a 3 GB tensor); planar, a line belongs to one chunk.
+        // Same bytes per image either way, so batches slice identically.  With 8 stored channels the two forms coincide.
+        // Not for the output of a transposed convolution that runs one sub-pixel phase per workgroup (> 5 N-tiles): its
+        // stores are every second pixel of a row, 16 bytes at a 32-byte stride in the planar form (lu2.convT +19 %).
+        static const int planar_mode = getenv("UMX_PLANAR") ? atoi(getenv("UMX_PLANAR")) : 2;   // 0: NHWC everywhere, 1: planar wherever eligible, 2: the rule below
+        bool phase_written = false;
+        for (const Launch& Lp : c->plan)
+            if (Lp.dst == (int)i && Lp.nphase == 4 && !(Lp.o_mul == 2 && Lp.ngroups == 1 && (Lp.Cout + 15) / 16 <= 5 && Lp.H >= 8 && Lp.W >= 16))
+                phase_written = true;
+        B.planar = planar_mode != 0 && !(planar_mode == 2 && phase_written) && !B.as_f32 && B.S >= 16 && B.Cs > 8 && !b.fold_top_skip;
         // (hi, lo) binary16 planes with Cs channels take 4*Cs bytes per pixel
         const size_t bytes_per_tile = B.as_f32 ? B.floats_per_tile * sizeof(float) : (size_t)B.S * B.S * B.Cs * 4;
         void* d = nullptr;

@@ -84,6 +84,9 @@ struct HConvParams {
     const _Float16* src_hi[2];   // NHWC binary16 [B,H,W,Cs], hi and lo planes
     const _Float16* src_lo[2];
     int Cs[2];                   // stored channels (multiple of 8)
+    int srcA[2], srcB[2];        // address form of an operand plane: byte offset of (pixel, octet) inside an image =
+                                 // pixel * srcA + octet * srcB -- NHWC: (2 * Cs, 16); octet-planar [octet][pixel][8]: (16, H*W*16)
+    int dst_planar;              // the output planes are octet-planar (per image [octet][pixel][8]) instead of NHWC
     int B, H, W;
     int Cout, Cds, NT, nblocks;  // real / stored output channels; N-tiles per workgroup; N blocks
     int twm_log2, th_log2, nimg_m, imgs;
