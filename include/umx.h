@@ -148,6 +148,13 @@ UMX_API int umx_infer_image_raw(umx_ctx* ctx, const void* raw_host, int bits, in
 UMX_API int umx_infer_image_raw_scaled(umx_ctx* ctx, const void* raw_host, int bits, int C_img, int H, int W, double scaling,
                                        int rescale, double mean, double std, int mode, uint8_t* out_host);
 
+/* The same with the drivers' --outlier percentile (reference UnMicst1-5.py:817-821, UnMicst2.py:780-788, UnMicst.py:606-610):
+ * rescale_intensity of the resized plane to (min, np.percentile(plane, outlier)) -> (0, 0.983), values above the percentile
+ * clipped.  The percentile is exact: the two order statistics numpy interpolates between are found on the device by radix
+ * selection over the float64 plane, the interpolation is numpy's (method 'linear').  outlier in [0, 100]; scaling may be 1. */
+UMX_API int umx_infer_image_raw_outlier(umx_ctx* ctx, const void* raw_host, int bits, int C_img, int H, int W, double scaling,
+                                        double outlier, double mean, double std, int mode, uint8_t* out_host);
+
 /* How the host entry points move data: the slide goes up and the planes come down in the launch groups of the tile loop,
  * on two copy streams, under the tile kernels of the neighbouring groups (pinned host buffers make these true DMA; pageable
  * ones are staged by HIP and still correct).  A stream of slides -- the drivers' per-file loop, reference

@@ -158,6 +158,14 @@ class _OracleEngine:
         pm = self.infer_image(image, mean, std, mode)
         return np.stack([imtools.to_uint8_via_resize(pm[k], planes[0].shape) for k in range(pm.shape[0])])
 
+    def infer_image_raw_outlier(self, raw, scaling, outlier, mean, std, mode=0):
+        """Host restatement of umx_infer_image_raw_outlier (np.percentile in driver.preprocess)."""
+        planes = raw[None] if raw.ndim == 2 else raw
+        pre = [driver.preprocess(p, scaling, outlier)[1] for p in planes]
+        image = np.stack(pre) if raw.ndim == 3 else pre[0]
+        pm = self.infer_image(image, mean, std, mode)
+        return np.stack([imtools.to_uint8_via_resize(pm[k], planes[0].shape) for k in range(pm.shape[0])])
+
     def close(self):
         pass
 

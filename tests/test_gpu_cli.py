@@ -197,3 +197,29 @@ def test_scaled_raw_path_matches_the_host_recipe(scaling, rescale):
     assert got.shape == want.shape == (hp.nClasses,) + raw.shape and got.dtype == np.uint8
     d = np.abs(got.astype(int) - want.astype(int))
     assert d.max() <= 1 and (d == 0).mean() > 0.995, (d.max(), (d == 0).mean())
+
+
+@pytest.mark.parametrize("scaling,outlier", [(1, 99.0), (1, 37.5), (0.5, 99.9), (1.6, 50.0)])
+def test_outlier_percentile_on_the_device_matches_numpy(scaling, outlier):
+    """--outlier on the device (umx_infer_image_raw_outlier: the two order statistics by radix selection over the float64
+    plane + numpy's linear interpolation) against the host recipe (np.percentile in driver.preprocess, reference
+    UnMicst1-5.py:817-821).  At --scalingFactor 1 the rescaled planes are the same doubles, so the uint8 planes are equal; with
+    a resize in front they inherit that path's <= 1 LSB."""
+    from unmicst_amd import imtools
+    hp, blob, mean, std = helpers.load_nuclei_dapi()
+    raw = helpers.load_sample_105()[0][:380, :500]
+    UNet2D.setupWithArtefacts(model.ModelArtefacts(hp, blob, mean, std))
+    try:
+        got = UNet2D.singleImageInferenceRawOutlier(raw, scaling, outlier)
+        pre = driver.preprocess(raw, scaling, outlier)[1]
+        want = np.stack([imtools.to_uint8_via_resize(UNet2D.singleImageInference(pre, "accumulate", k), raw.shape)
+                         for k in range(hp.nClasses)])
+    finally:
+        UNet2D.singleImageInferenceCleanup()
+    assert got.shape == want.shape == (hp.nClasses,) + raw.shape and got.dtype == np.uint8
+    d = np.abs(got.astype(int) - want.astype(int))
+    if scaling == 1:
+        assert d.max() == 0, (d.max(), (d == 0).mean())
+    else:
+        assert d.max() <= 1 and (d == 0).mean() > 0.995, (d.max(), (d == 0).mean())
+

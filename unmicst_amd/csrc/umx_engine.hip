@@ -2025,8 +2025,9 @@ static int resize_plane(umx_ctx* ctx, const double* src, int H, int W, int h, in
     return UMX_OK;
 }
 
-int umx_infer_image_raw_scaled(umx_ctx* ctx, const void* raw_host, int bits, int C_img, int H, int W, double scaling, int rescale,
-                               double mean, double stdv, int mode, uint8_t* out_host) {
+// outlier < 0: rescale (if set) to the plane's (min, max); outlier in [0, 100]: to (min, np.percentile(plane, outlier))
+static int infer_raw_scaled_impl(umx_ctx* ctx, const void* raw_host, int bits, int C_img, int H, int W, double scaling, int rescale,
+                                 double outlier, double mean, double stdv, int mode, uint8_t* out_host) {
     if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
     if (!raw_host || !out_host || H < 1 || W < 1 || C_img < 1) return fail(ctx, UMX_ERR_INVALID, "bad image/out/H/W");
     if (bits != 8 && bits != 16) return fail(ctx, UMX_ERR_INVALID, "raw planes must be uint8 or uint16 (bits = %d)", bits);
@@ -2036,7 +2037,9 @@ int umx_infer_image_raw_scaled(umx_ctx* ctx, const void* raw_host, int bits, int
     if (!(scaling > 0.0)) return fail(ctx, UMX_ERR_INVALID, "scaling factor must be positive");
     const int h = (int)((double)H * scaling), w = (int)((double)W * scaling);   // int(float(I.shape[0]) * float(sf))
     if (h < 1 || w < 1) return fail(ctx, UMX_ERR_INVALID, "scaled image is empty");
-    if (h == H && w == W) return umx_infer_image_raw(ctx, raw_host, bits, C_img, H, W, rescale, mean, stdv, mode, out_host);
+    const bool same = h == H && w == W;   // resize(I, I.shape) leaves im2double(I): the pipelined path does all but the percentile
+    if (same && outlier < 0) return umx_infer_image_raw(ctx, raw_host, bits, C_img, H, W, rescale, mean, stdv, mode, out_host);
+    if (mode != UMX_MODE_ACCUMULATE && mode != UMX_MODE_REPLACE) return fail(ctx, UMX_ERR_INVALID, "bad mode %d", mode);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t big = (size_t)std::max(H, h) * std::max(W, w), plane = (size_t)H * W, sp = (size_t)h * w, K = ctx->hp.nClasses;
     const size_t in_b = bits / 8;
@@ -2045,6 +2048,7 @@ int umx_infer_image_raw_scaled(umx_ctx* ctx, const void* raw_host, int bits, int
     auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
     const size_t o_raw = take(plane * C_img * in_b), o_a = take(big * 8), o_b = take(big * 8), o_c = take(big * 8);
     const size_t o_in = take(sp * C_img * 8), o_pm = take(K * sp * 2), o_u8 = take(K * plane), o_w = take(2 * 4096 * 8), o_mm = take(256);
+    const size_t o_sel = take(64 + 512 * 4);   // radix-selection state + histograms of the percentile
     int rc;
     umx_ctx::HostSlot& hs = ctx->hs[0];
     if (hs.busy) return fail(ctx, UMX_ERR_INVALID, "slot 0 still holds a submitted call: wait for it first");
@@ -2058,20 +2062,39 @@ int umx_infer_image_raw_scaled(umx_ctx* ctx, const void* raw_host, int bits, int
     for (int c = 0; c < C_img; ++c) {
         HIP_TRY(ctx, launch_minmax_init(mm32, ctx->stream));
         HIP_TRY(ctx, launch_raw_convert(base + o_raw + (size_t)c * plane * in_b, bits, plane, 0, mm32, A, ctx->stream));   // im2double
-        if ((rc = resize_plane(ctx, A, H, W, h, w, B, Cw, wdev, mm64, din + (size_t)c * sp, nullptr))) return rc;
-        if (rescale) {   // rescale_intensity(I, (min, max), (0, 0.983)) of the RESIZED plane (UnMicst1-5.py:817-821)
+        if (same) HIP_TRY(ctx, hipMemcpyAsync(din + (size_t)c * sp, A, sp * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        else if ((rc = resize_plane(ctx, A, H, W, h, w, B, Cw, wdev, mm64, din + (size_t)c * sp, nullptr))) return rc;
+        if (rescale) {   // rescale_intensity(I, (min, max | percentile), (0, 0.983)) of the RESIZED plane (UnMicst1-5.py:817-821)
             HIP_TRY(ctx, launch_minmax_f64(din + (size_t)c * sp, sp, mm64, ctx->stream));
+            if (outlier >= 0)
+                HIP_TRY(ctx, launch_percentile_f64(din + (size_t)c * sp, sp, outlier, (unsigned long long*)(base + o_sel),
+                                                   (unsigned*)(base + o_sel + 64), mm64, ctx->stream));
             HIP_TRY(ctx, launch_rescale_f64(din + (size_t)c * sp, sp, mm64, ctx->stream));
         }
     }
     if ((rc = umx_infer_image_dev(ctx, din, C_img, h, w, mean, stdv, mode, UMX_STITCH_FP16_COMPAT, base + o_pm))) return rc;
     for (size_t k = 0; k < K; ++k) {
+        if (same) {   // resize of a uint8 plane to its own shape and back through np.uint8(255 * .): the plane itself
+            HIP_TRY(ctx, launch_half_to_u8(base + o_pm + k * sp * 2, sp, base + o_u8 + k * plane, ctx->stream));
+            continue;
+        }
         HIP_TRY(ctx, launch_half_to_u8_f64(base + o_pm + k * sp * 2, sp, A, ctx->stream));   // np.uint8(255 * pm) as float u8/255
         if ((rc = resize_plane(ctx, A, h, w, H, W, B, Cw, wdev, mm64, nullptr, base + o_u8 + k * plane))) return rc;
     }
     HIP_TRY(ctx, hipMemcpyAsync(out_host, base + o_u8, K * plane, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return check_range_flag(ctx);
+}
+
+int umx_infer_image_raw_scaled(umx_ctx* ctx, const void* raw_host, int bits, int C_img, int H, int W, double scaling, int rescale,
+                               double mean, double stdv, int mode, uint8_t* out_host) {
+    return infer_raw_scaled_impl(ctx, raw_host, bits, C_img, H, W, scaling, rescale, -1.0, mean, stdv, mode, out_host);
+}
+
+int umx_infer_image_raw_outlier(umx_ctx* ctx, const void* raw_host, int bits, int C_img, int H, int W, double scaling, double outlier,
+                                double mean, double stdv, int mode, uint8_t* out_host) {
+    if (!(outlier >= 0.0 && outlier <= 100.0)) return fail(ctx, UMX_ERR_INVALID, "outlier percentile must be in [0, 100]");
+    return infer_raw_scaled_impl(ctx, raw_host, bits, C_img, H, W, scaling, 1, outlier, mean, stdv, mode, out_host);
 }
 
 int umx_infer_image_raw_submit(umx_ctx* ctx, int slot, const void* raw_host, int bits, int C_img, int H, int W, int rescale,

@@ -199,6 +199,8 @@ hipError_t launch_gauss1d(const double* src, double* dst, int H, int W, int axis
 hipError_t launch_minmax_f64(const double* x, size_t n, unsigned long long* mm64, hipStream_t stream);
 hipError_t launch_zoom1(const double* src, int H, int W, int h, int w, const unsigned long long* clip, double* dst,
                         unsigned char* out_u8, hipStream_t stream);
+hipError_t launch_percentile_f64(const double* x, size_t n, double q, unsigned long long* st, unsigned* hist,
+                                 unsigned long long* mm64, hipStream_t stream);
 hipError_t launch_rescale_f64(double* x, size_t n, const unsigned long long* mm64, hipStream_t stream);
 hipError_t launch_half_to_u8_f64(const void* pm_half, size_t n, double* out, hipStream_t stream);
 

@@ -1,5 +1,7 @@
 // HIP kernels of libumx -- written for gfx950 (MI355X, CDNA4) only: 64-wide waves, v_mfma_f32_16x16x4_f32,
 // 160 KiB LDS per CU.  No other target is supported.
+#include <cmath>
+
 #include "umx_kernels.h"
 
 #include <hip/hip_fp16.h>
@@ -741,6 +743,67 @@ __global__ void __launch_bounds__(256) half_to_u8_f64_kernel(const __half* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// np.percentile(I, q) of a float64 plane of non-negative values (reference UnMicst1-5.py:820, the --outlier limit), exact:
+// the two order statistics a[k], a[k+1] by radix selection on the bit patterns (non-negative doubles order like their
+// bits), 8 passes of 8 bits, both targets in one read of the plane per pass; then numpy's linear interpolation.
+// st[t] = {prefix bits found so far, rank left inside the bucket}; hist = 2 x 256 counters, zeroed by the pick kernel.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rsel_hist_kernel(const double* __restrict__ x, size_t n, const unsigned long long* __restrict__ st,
+                                                       int pass, unsigned* __restrict__ hist) {
+    __shared__ unsigned h[2][256];
+    h[0][threadIdx.x] = 0; h[1][threadIdx.x] = 0;
+    __syncthreads();
+    const int shift = 56 - 8 * pass;
+    const unsigned long long p0 = st[0], p1 = st[2];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(x[i]);
+        const unsigned d = (unsigned)(b >> shift) & 255u;
+        const bool m0 = pass == 0 || (b >> (shift + 8)) == (p0 >> (shift + 8));
+        const bool m1 = pass == 0 || (b >> (shift + 8)) == (p1 >> (shift + 8));
+        if (m0) atomicAdd(&h[0][d], 1u);
+        if (m1) atomicAdd(&h[1][d], 1u);
+    }
+    __syncthreads();
+    if (h[0][threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[0][threadIdx.x]);
+    if (h[1][threadIdx.x]) atomicAdd(&hist[256 + threadIdx.x], h[1][threadIdx.x]);
+}
+
+__global__ void rsel_init_kernel(unsigned long long* __restrict__ st, unsigned long long k0, unsigned long long k1,
+                                 unsigned* __restrict__ hist) {
+    if (threadIdx.x == 0) { st[0] = 0; st[1] = k0; st[2] = 0; st[3] = k1; }
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) hist[i] = 0;
+}
+
+__global__ void rsel_pick_kernel(unsigned long long* __restrict__ st, int pass, unsigned* __restrict__ hist) {
+    const int t = threadIdx.x;   // one thread per target
+    if (t < 2) {
+        const int shift = 56 - 8 * pass;
+        unsigned long long k = st[2 * t + 1], cum = 0;
+        int b = 0;
+        for (; b < 255; ++b) {
+            const unsigned long long c = hist[256 * t + b];
+            if (k < cum + c) break;
+            cum += c;
+        }
+        st[2 * t] |= (unsigned long long)b << shift;
+        st[2 * t + 1] = k - cum;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) hist[i] = 0;
+}
+
+// numpy's _lerp(a, b, t): a + (b - a) * t, and b - (b - a) * (1 - t) where t >= 0.5; the result replaces the plane's max
+__global__ void percentile_lerp_kernel(const unsigned long long* __restrict__ st, double gamma, unsigned long long* __restrict__ mm64) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double a = __longlong_as_double((long long)st[0]), b = __longlong_as_double((long long)st[2]);
+        const double d = b - a;
+        double r = a + d * gamma;
+        if (gamma >= 0.5) r = b - d * (1.0 - gamma);
+        mm64[1] = (unsigned long long)__double_as_longlong(r);
+    }
+}
+
 static unsigned blocks_for(size_t n) { return (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16); }
 
 hipError_t launch_gauss1d(const double* src, double* dst, int H, int W, int axis, int radius, const double* w_dev,
@@ -758,6 +821,24 @@ hipError_t launch_minmax_f64(const double* x, size_t n, unsigned long long* mm64
 hipError_t launch_zoom1(const double* src, int H, int W, int h, int w, const unsigned long long* clip, double* dst,
                         unsigned char* out_u8, hipStream_t stream) {
     hipLaunchKernelGGL(zoom1_kernel, dim3(blocks_for((size_t)h * w)), dim3(256), 0, stream, src, H, W, h, w, clip, dst, out_u8);
+    return hipGetLastError();
+}
+// mm64[1] <- np.percentile(x, q) for the n non-negative values of x; st: 4 x 8 bytes, hist: 512 x 4 bytes of device scratch
+hipError_t launch_percentile_f64(const double* x, size_t n, double q, unsigned long long* st, unsigned* hist,
+                                 unsigned long long* mm64, hipStream_t stream) {
+    // numpy: virtual index = (n - 1) * (q / 100), previous = floor, next = previous + 1 (clipped), gamma = virtual - previous
+    const double virt = (double)(n - 1) * (q / 100.0);
+    double prev = std::floor(virt);
+    if (prev < 0) prev = 0;
+    if (prev > (double)(n - 1)) prev = (double)(n - 1);
+    const unsigned long long k0 = (unsigned long long)prev, k1 = std::min<unsigned long long>(k0 + 1, n - 1);
+    const double gamma = virt - prev;
+    hipLaunchKernelGGL(rsel_init_kernel, dim3(1), dim3(256), 0, stream, st, k0, k1, hist);
+    for (int pass = 0; pass < 8; ++pass) {
+        hipLaunchKernelGGL(rsel_hist_kernel, dim3(blocks_for(n)), dim3(256), 0, stream, x, n, st, pass, hist);
+        hipLaunchKernelGGL(rsel_pick_kernel, dim3(1), dim3(256), 0, stream, st, pass, hist);
+    }
+    hipLaunchKernelGGL(percentile_lerp_kernel, dim3(1), dim3(64), 0, stream, st, gamma, mm64);
     return hipGetLastError();
 }
 hipError_t launch_rescale_f64(double* x, size_t n, const unsigned long long* mm64, hipStream_t stream) {

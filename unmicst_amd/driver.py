@@ -157,15 +157,16 @@ def run(tool: str, argv=None, script_dir: str = None) -> int:
             os.makedirs(qc_dir, exist_ok=True)
         suffix = str(first + 1) if spec.suffix_plus_one else str(first)
 
-        # fast path: with the default intensity range (--outlier -1) the whole pre/post-processing -- im2double, both resizes
-        # at --scalingFactor != 1, min/max + rescale, the double uint8 cast -- runs on the GPU next to the inference
-        # (umx_infer_image_raw / _raw_scaled): no float64 upload / float16 download.  A percentile (--outlier) goes through
-        # the host-side recipe.
-        fast = (args.outlier == -1 and all(r.dtype in (np.uint8, np.uint16) for r in raws)
+        # fast path: the whole pre/post-processing -- im2double, both resizes at --scalingFactor != 1, min/max (or the
+        # --outlier percentile, exact by radix selection) + rescale, the double uint8 cast -- runs on the GPU next to the
+        # inference (umx_infer_image_raw / _raw_scaled / _raw_outlier): no float64 upload / float16 download.
+        fast = (all(r.dtype in (np.uint8, np.uint16) for r in raws)
                 and len({(r.shape, r.dtype) for r in raws}) == 1 and not os.environ.get("UMX_NO_RAW_PATH"))
         if fast:
             stack_raw = np.stack(raws) if spec.n_inputs == 2 else raws[0]
-            if float(args.scalingFactor) == 1.0:
+            if args.outlier != -1 and spec.infer_rescaled:   # (a tool that feeds the un-rescaled plane ignores the limit)
+                u8_planes = UNet2D.singleImageInferenceRawOutlier(stack_raw, args.scalingFactor, args.outlier, "accumulate")
+            elif float(args.scalingFactor) == 1.0:
                 u8_planes = UNet2D.singleImageInferenceRaw(stack_raw, spec.infer_rescaled, "accumulate")
             else:   # both resizes (skimage defaults) run on the device too
                 u8_planes = UNet2D.singleImageInferenceRawScaled(stack_raw, args.scalingFactor, spec.infer_rescaled, "accumulate")

@@ -25,7 +25,7 @@ STITCH_FP16_COMPAT, STITCH_FP32 = 0, 1
 EXPORTS = [
     "umx_device_count", "umx_device_mem_info", "umx_create", "umx_create_opts", "umx_precision_of", "umx_destroy", "umx_last_error", "umx_set_stream", "umx_synchronize",
     "umx_forward_tiles", "umx_forward_tiles_dev", "umx_tile_grid", "umx_infer_image", "umx_infer_image_dev",
-    "umx_infer_image_raw", "umx_infer_image_raw_scaled", "umx_infer_image_raw_submit", "umx_infer_image_wait", "umx_tiff_lzw_decode",
+    "umx_infer_image_raw", "umx_infer_image_raw_scaled", "umx_infer_image_raw_outlier", "umx_infer_image_raw_submit", "umx_infer_image_wait", "umx_tiff_lzw_decode",
     "umx_tiff_packbits_decode", "umx_shard_unique_id", "umx_shard_init", "umx_shard_fini", "umx_shard_plan",
     "umx_infer_image_sharded_dev",
     "umx_band_tiles_dev", "umx_stitch_dev", "umx_profile_enable", "umx_profile_read", "umx_test_double_to_half",
@@ -122,6 +122,9 @@ def load(path: Optional[str] = None):
     L.umx_tile_grid.argtypes = [c_void_p, c_int, c_int, ip, ip, ip, ip]
     L.umx_infer_image.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_int, c_int, c_void_p]
     L.umx_infer_image_dev.argtypes = L.umx_infer_image.argtypes
+    L.umx_infer_image_raw_outlier.restype = c_int
+    L.umx_infer_image_raw_outlier.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_double, c_double,
+                                              c_int, c_void_p]
     L.umx_infer_image_raw_scaled.restype = c_int
     L.umx_infer_image_raw_scaled.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_int, c_double, c_double,
                                              c_int, c_void_p]
@@ -397,6 +400,23 @@ class Engine:
         self._check(self._L.umx_infer_image_raw_scaled(self._ctx, raw.ctypes.data, raw.dtype.itemsize * 8, C, H, W,
                                                        float(scaling), 1 if rescale else 0, float(mean), float(std), int(mode),
                                                        out.ctypes.data))
+        return out
+
+    def infer_image_raw_outlier(self, raw: np.ndarray, scaling: float, outlier: float, mean: float, std: float,
+                                mode: int = MODE_ACCUMULATE) -> np.ndarray:
+        """The drivers' recipe with --outlier on the device (any --scalingFactor): intensities rescaled to
+        (min, np.percentile(resized plane, outlier)) -> (0, 0.983); raw uint8/uint16 (H,W) or (C,H,W) -> uint8 [K,H,W]."""
+        raw = np.ascontiguousarray(raw)
+        if raw.dtype not in (np.uint8, np.uint16):
+            raise TypeError("raw planes must be uint8 or uint16")
+        if raw.ndim == 2:
+            raw = raw[None]
+        C, H, W = raw.shape
+        raw = raw.astype(raw.dtype.newbyteorder("="), copy=False)
+        out = np.empty((self.hp.nClasses, H, W), np.uint8)
+        self._check(self._L.umx_infer_image_raw_outlier(self._ctx, raw.ctypes.data, raw.dtype.itemsize * 8, C, H, W,
+                                                        float(scaling), float(outlier), float(mean), float(std), int(mode),
+                                                        out.ctypes.data))
         return out
 
     # -- device-pointer API (pointers are plain ints, e.g. torch.Tensor.data_ptr())

@@ -188,6 +188,21 @@ class UNet2D:
                                                          UNet2D.DatasetStDev, m))
 
     @staticmethod
+    def singleImageInferenceRawOutlier(raw, scaling, outlier, mode="accumulate"):
+        """Driver fast path with ``--outlier``: resize -> rescale to (min, percentile) -> inference -> uint8 -> resize back, all on
+        the device (reference UnMicst1-5.py:813-821,848-854; the percentile is numpy's, found by radix selection)."""
+        if UNet2D.Engine is None:
+            raise RuntimeError("call UNet2D.singleImageInferenceSetup first")
+        print("Inference...")
+        raw = np.asarray(raw)
+        if raw.ndim == 3 and raw.shape[0] != UNet2D.hparams.nChannels:
+            raise ValueError("image has %d planes, the model takes %d channels" % (raw.shape[0], UNet2D.hparams.nChannels))
+        m = _umx.MODE_ACCUMULATE if mode == "accumulate" else _umx.MODE_REPLACE
+        return UNet2D._with_range_fallback(
+            lambda: UNet2D.Engine.infer_image_raw_outlier(raw, float(scaling), float(outlier), UNet2D.DatasetMean,
+                                                          UNet2D.DatasetStDev, m))
+
+    @staticmethod
     def _pass_key(image, mode):
         a = np.asarray(image)
         flat = a.reshape(-1)
