@@ -57,6 +57,11 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
     // ---- workgroup -> (image group, spatial tile), N block, phase
     const int TWm = 1 << p.twm_log2, TH = 1 << p.th_log2;
     int bid = blockIdx.x;
+    if (p.xcd_order) {   // consecutive ids go round-robin over the 8 XCDs: give each XCD a contiguous run of tiles, so that
+                         // tiles that share halo lines meet in ONE L2
+        const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = xcd < r8 ? xcd * (q8 + 1) + idx : r8 * (q8 + 1) + (xcd - r8) * q8 + idx;
+    }
     const int tx_i = bid % p.tiles_x; bid /= p.tiles_x;
     const int ty_i = bid % p.tiles_y; bid /= p.tiles_y;
     const int img0 = bid * p.imgs;

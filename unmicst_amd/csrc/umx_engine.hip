@@ -977,6 +977,21 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     h.lo_off = bestSlots * h.slot_bytes;
     h.b_off = 2 * h.lo_off;
     h.wbuf_bytes = 64 + S * nt16 * 2048;
+    {   // XCD-aware tile order (default on; UMX_XCD_ORDER=0 off, or a comma list of layer-name prefixes to limit it)
+        h.xcd_order = 1;
+        if (const char* e = getenv("UMX_XCD_ORDER")) {
+            std::string spec(e);
+            h.xcd_order = (spec == "1" || spec == "all") ? 1 : 0;
+            size_t pos = 0;
+            while (pos < spec.size()) {
+                const size_t end = spec.find(',', pos);
+                const std::string tok = spec.substr(pos, end == std::string::npos ? std::string::npos : end - pos);
+                if (tok.size() > 1 && L.name.compare(0, tok.size(), tok) == 0) h.xcd_order = 1;
+                if (end == std::string::npos) break;
+                pos = end + 1;
+            }
+        }
+    }
     {   // de-phasing of the workgroups that share a CU (see conv_f16x3): UMX_STAGGER = "cycles" or "layer:cycles,..."
         h.stagger = 0;
         h.nres = std::max(1, std::min((fused || tall) ? 2 : (nt16 <= 3 && maxp == 4) ? 4 : (nt16 <= 3 || (nt16 <= 5 && maxp == 4)) ? 3 : 2, (160 * 1024) / std::max(1, lds_total(bestSlots, OC, S, plane_pair))));

@@ -98,6 +98,7 @@ struct HConvParams {
     int piece_bytes;               // PP*OC*16: LDS bytes one piece fills (the image stays dense: slot = pixel*OC + octet)
     int inv_oc_q16;                // 65536/OC + 1: lane / OC == (lane * inv_oc_q16) >> 16 for lane < 64
     int kmt;                       // M-tiles per wave of the plain kernel: 4 (4 waves per workgroup) or 2 (8 waves)
+    int xcd_order;                 // 1: workgroup ids are re-ordered so that each XCD (ids = x mod 8) walks a contiguous range of tiles
     int maxp;                      // halo pieces per wave and chunk the launched instantiation indexes: 4 or 12
     int stagger, first_gen, nres;  // stagger > 0: a workgroup of the launch's first generation (linear id < first_gen) sleeps
                                    // (hardware wave slot % nres) * stagger cycles before it starts, so that the nres
