@@ -542,7 +542,7 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
                 const int row = dpl ? (u & (R - 1)) : u / UR, cu = dpl ? u / R : u - (u / UR) * UR;
                 const int c0 = nblk * (NT * 16) + cu * 8;
                 if (row < R && cu < UR && c0 < p.Cds) {
-                    const int off = xo(row) * dPix + (c0 >> 3) * dOct;
+                    const int off = (int)(__umul24(xo(row), dPix) + __umul24(c0 >> 3, dOct));   // both factors < 2^24 (planner)
                     uint4 vh = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16);
                     uint4 vl = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16 + PLANE);
                     if (p.app_hi && c0 == p.app_c0) {   // appended channels (NHWC plans only)

@@ -1558,7 +1558,8 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
         for (const Launch& Lp : c->plan)
             if (Lp.dst == (int)i && Lp.nphase == 4 && !(Lp.o_mul == 2 && Lp.ngroups == 1 && (Lp.Cout + 15) / 16 <= 5 && Lp.H >= 8 && Lp.W >= 16))
                 phase_written = true;
-        B.planar = planar_mode != 0 && !(planar_mode == 2 && phase_written) && !B.as_f32 && B.S >= 16 && B.Cs > 8 && !b.fold_top_skip;
+        B.planar = planar_mode != 0 && !(planar_mode == 2 && phase_written) && !B.as_f32 && B.S >= 16 && B.Cs > 8 && !b.fold_top_skip &&
+                   (size_t)B.S * B.S * 16 < (1u << 24);   // (the kernels form octet offsets with 24-bit multiplies)
         // (hi, lo) binary16 planes with Cs channels take 4*Cs bytes per pixel
         const size_t bytes_per_tile = B.as_f32 ? B.floats_per_tile * sizeof(float) : (size_t)B.S * B.S * B.Cs * 4;
         void* d = nullptr;
