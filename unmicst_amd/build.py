@@ -12,9 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libumx.so")
-SOURCES = ["umx_kernels.hip", "umx_conv_f16.hip", "umx_conv_rw.hip", "umx_engine.hip", "umx_shard.hip", "umx_train_kernels.hip",
-           "umx_train.hip"]
-HEADERS = ["umx_kernels.h", os.path.join("..", "..", "include", "umx.h"), os.path.join("..", "..", "include", "umx_train.h")]
+SOURCES = ["umx_kernels.hip", "umx_conv_f16.hip", "umx_conv_first.hip", "umx_graph.hip", "umx_plan.hip", "umx_engine.hip", "umx_host.hip",
+           "umx_tiff.hip", "umx_shard.hip", "umx_train_kernels.hip", "umx_train.hip"]
+HEADERS = ["umx_kernels.h", "umx_internal.h", os.path.join("..", "..", "include", "umx.h"), os.path.join("..", "..", "include", "umx_train.h")]
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
          "-Wno-unused-value", "-Wno-unused-result"]

@@ -31,9 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
 // NPH = 1: one output phase per workgroup (plain convolutions; transposed convolutions one sub-pixel phase at a time,
-//          phase = blockIdx.z), KMT = 4 M-tiles per wave (256 pixels per workgroup: a 16 x 16 tile), or KMT = 8 for the
-//          layers of <= 3 N-tiles (512 pixels: 16 wide x 32 tall -- half the weight traffic, stage overhead and weight
-//          fragment reads per MFMA, at 2 instead of 4 resident workgroups per CU).
+//          phase = blockIdx.z), KMT = 4 M-tiles per wave (256 pixels per workgroup: a 16 x 16 tile).
 // NPH = 4: stride-2 transposed convolution with all four sub-pixel phases in one workgroup: the input halo is loaded
 //          once instead of four times, every stage carries the phase whose accumulators it feeds, KMT = 2 (128 input
 //          pixels -> 512 output pixels per workgroup), and the epilogue interleaves the phases so that whole output
@@ -42,7 +40,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // MAXP: halo pieces per wave and chunk the kernel keeps a pixel index for (4 or 12; the planner picks the smallest that holds
 //       its chunking -- 12 costs 8 vector registers, i.e. a wave per SIMD on the narrow kernels).
 constexpr int conv_f16x3_waves(int NT, int KMT, int NPH, int MAXP) {   // resident waves per SIMD the register budget is set for
-    return (NPH != 1 || KMT > 4) ? 2 : (NT <= 3 && MAXP == 4) ? 4 : (NT <= 3 || (NT <= 5 && MAXP == 4)) ? 3 : 2;
+    return NPH != 1 ? 2 : (NT <= 3 && MAXP == 4) ? 4 : (NT <= 3 || (NT <= 5 && MAXP == 4)) ? 3 : 2;
 }
 template <int NT, int KMT, int NPH, bool DBG = false, int MAXP = 4>
 __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) conv_f16x3(const HConvParams p) {
@@ -72,14 +70,6 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
     // blocks, [3] epilogue, [4] whole kernel
     long long t_in = 0, t_wait = 0, t_comp = 0, t_a = 0, t_b = 0, t_vm = 0, t_iss = 0;
     if (DBG && p.dbg) t_in = __builtin_amdgcn_s_memtime();
-    // ---- de-phasing.  Workgroups that share a CU start together, do identical work and stay in lockstep: they reach their
-    // MFMA blocks together (each gets half the matrix pipe) and their load / epilogue phases together (the pipe idles), so
-    // the phases add up instead of overlapping.  The first generation is therefore started at different times, by
-    // hardware wave slot; later generations inherit the offset (a workgroup starts when its predecessor in the slot ends).
-    if (p.stagger > 0 && (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) < p.first_gen) {
-        const unsigned slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) % (unsigned)p.nres;   // HW_ID.WAVE_ID
-        for (int c = (int)slot * p.stagger; c > 0; c -= 64 * 64) __builtin_amdgcn_s_sleep(64);
-    }
     // ---- per-lane A-fragment pixel offsets (bytes) of this wave's M-tiles
     int abase[KMT];
 #pragma unroll
@@ -508,17 +498,9 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
             if (row < R && cu < UR && c0 < p.Cds) {
                 const long e0 = elem_of(row);
                 if (e0 >= 0) {
-                    uint4 vh = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16);
-                    uint4 vl = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16 + PLANE);
+                    const uint4 vh = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16);
+                    const uint4 vl = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16 + PLANE);
                     const long e = e0 + (long)(c0 >> 3) * dOct;
-                    if (p.app_hi && c0 == p.app_c0) {   // appended channels (NHWC plans only; exact zeros so far: padded output channels)
-                        const long pix = e0 / p.Cds;
-                        const unsigned ah = *reinterpret_cast<const unsigned*>(p.app_hi + pix * p.app_Cs);
-                        const unsigned al = *reinterpret_cast<const unsigned*>(p.app_lo + pix * p.app_Cs);
-                        if (p.app_word == 1) { vh.y = ah; vl.y = al; }
-                        else if (p.app_word == 2) { vh.z = ah; vl.z = al; }
-                        else { vh.w = ah; vl.w = al; }
-                    }
                     *reinterpret_cast<uint4*>(p.dst_hi + e) = vh;
                     *reinterpret_cast<uint4*>(p.dst_lo + e) = vl;
                 }
@@ -543,16 +525,8 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
                 const int c0 = nblk * (NT * 16) + cu * 8;
                 if (row < R && cu < UR && c0 < p.Cds) {
                     const int off = (int)(__umul24(xo(row), dPix) + __umul24(c0 >> 3, dOct));   // both factors < 2^24 (planner)
-                    uint4 vh = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16);
-                    uint4 vl = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16 + PLANE);
-                    if (p.app_hi && c0 == p.app_c0) {   // appended channels (NHWC plans only)
-                        const long pix = seg_elem / p.Cds + xo(row);
-                        const unsigned ah = *reinterpret_cast<const unsigned*>(p.app_hi + pix * p.app_Cs);
-                        const unsigned al = *reinterpret_cast<const unsigned*>(p.app_lo + pix * p.app_Cs);
-                        if (p.app_word == 1) { vh.y = ah; vl.y = al; }
-                        else if (p.app_word == 2) { vh.z = ah; vl.z = al; }
-                        else { vh.w = ah; vl.w = al; }
-                    }
+                    const uint4 vh = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16);
+                    const uint4 vl = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16 + PLANE);
                     *reinterpret_cast<uint4*>(bh + off) = vh;
                     *reinterpret_cast<uint4*>(bl + off) = vl;
                 }
@@ -682,7 +656,7 @@ static hipError_t launch_h_k(const HConvParams& p, hipStream_t stream) {
 // instantiations: MAXP = 4 everywhere; MAXP = 12 in addition for <= 5 N-tiles (12 only for the fused kernels of <= 3)
 template <int NT, int KMT, int NPH>
 static hipError_t launch_h_nt(const HConvParams& p, hipStream_t stream) {
-    constexpr bool has4 = !(NPH == 4 && NT <= 3), has12 = NT <= 5 && !(NPH == 4 && NT > 3) && KMT <= 4;
+    constexpr bool has4 = !(NPH == 4 && NT <= 3), has12 = NT <= 5 && !(NPH == 4 && NT > 3);
     if (p.maxp != 4 && p.maxp != 12) return hipErrorInvalidValue;
     if constexpr (has12) {
         if (p.maxp == 12) return launch_h_k<NT, KMT, NPH, false, 12>(p, stream);
@@ -706,14 +680,6 @@ hipError_t launch_conv_f16(const HConvParams& p, hipStream_t stream) {
             case 3: return launch_h_nt<3, 2, 4>(p, stream);
             case 4: return launch_h_nt<4, 2, 4>(p, stream);
             case 5: return launch_h_nt<5, 2, 4>(p, stream);
-            default: return hipErrorInvalidValue;
-        }
-    }
-    if (p.kmt == 8) {
-        switch (p.NT) {
-            case 1: return launch_h_nt<1, 8, 1>(p, stream);
-            case 2: return launch_h_nt<2, 8, 1>(p, stream);
-            case 3: return launch_h_nt<3, 8, 1>(p, stream);
             default: return hipErrorInvalidValue;
         }
     }

@@ -1,0 +1,318 @@
+// Host pipeline of libumx: the entry points that take host arrays (reference seam UnMicst1-5.py:687-710 and the drivers'
+// pre/post-processing around it, :807-854), with uploads / downloads overlapped with the tile kernels.
+#include "umx_internal.h"
+
+using namespace umx;
+
+extern "C" {
+
+// ---- host entry points.  The reference hands host arrays across its seam (UnMicst1-5.py:687-710); here the slide goes up
+// and the probability stack comes down in row slabs on two copy streams while the tile kernels of the neighbouring slabs
+// run: slab s = patch rows [cut[s], cut[s+1]); its upload covers the image rows its tiles read that are not on the device
+// yet, its download the image rows no later patch row touches.  With pinned host buffers the transfers are true DMA and
+// all but the first upload and the last download ride under compute; with pageable buffers HIP stages them (still correct).
+// src_bits: 0 = float64 planes (what singleImageInference receives), 8 / 16 = raw integer planes (the driver's file
+// contents; im2double and, with `rescale`, rescale_intensity run on the device).  out_u8: the driver's uint8 planes
+// instead of the stitch result.  A rescale needs the plane's (min, max) before the first tile: the upload then runs
+// ahead of compute (min/max reduced slab by slab as the rows arrive) and only the download is hidden.
+static int host_wait(umx_ctx* ctx, int slot) {
+    if (slot < 0 || slot > 1) return fail(ctx, UMX_ERR_INVALID, "slot must be 0 or 1");
+    umx_ctx::HostSlot& hs = ctx->hs[slot];
+    if (!hs.busy) return UMX_OK;
+    hs.busy = false;
+    HIP_TRY(ctx, hipEventSynchronize(hs.done));
+    if (*hs.flag_host) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return check_range_flag(ctx);
+    }
+    return UMX_OK;
+}
+
+static int host_submit(umx_ctx* ctx, int slot, const void* src, int src_bits, int C_img, int H, int W, int rescale, double mean,
+                       double stdv, int mode, int stitch, int out_u8, void* out_host) {
+    if (slot < 0 || slot > 1) return fail(ctx, UMX_ERR_INVALID, "slot must be 0 or 1");
+    umx_ctx::HostSlot& hs = ctx->hs[slot];
+    if (hs.busy) return fail(ctx, UMX_ERR_INVALID, "slot %d still holds a submitted call: wait for it first", slot);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!hs.done) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&hs.done, hipEventDisableTiming));
+        HIP_TRY(ctx, hipHostMalloc((void**)&hs.flag_host, 64, hipHostMallocDefault));
+    }
+    const TileGeom g = geom_of(ctx->hp, H, W);
+    const size_t plane = (size_t)H * W, K = ctx->hp.nClasses;
+    const size_t in_b = src_bits ? (size_t)(src_bits / 8) : sizeof(double);
+    const size_t oel = stitch == UMX_STITCH_FP32 ? 4 : 2;
+    const size_t pm_b = K * plane * oel, u8_b = out_u8 ? K * plane : 0;
+    const size_t raw_off = (pm_b + u8_b + 255) & ~(size_t)255;
+    const size_t raw_b = src_bits ? plane * C_img * in_b : 0;
+    const size_t mm_off = (raw_off + raw_b + 255) & ~(size_t)255;
+    int rc;
+    if ((rc = grow(ctx, (void**)&hs.d_image, &hs.image_cap, plane * C_img * sizeof(double)))) return rc;
+    if ((rc = grow(ctx, &hs.d_out, &hs.out_cap, mm_off + 64 * (size_t)C_img))) return rc;
+    if ((rc = grow(ctx, (void**)&hs.d_probs, &hs.probs_cap, (size_t)g.npr * g.npc * g.P * g.P * K * sizeof(float)))) return rc;
+    unsigned char* const base = (unsigned char*)hs.d_out;
+    if (!ctx->up_stream) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->dn_stream, hipStreamNonBlocking));
+    }
+    // slabs = the launch groups of the tile loop (equal groups of <= max_batch tiles, exactly what umx_infer_image_dev
+    // runs), so that pipelining the transfers does not change a single kernel launch; UMX_HOST_SLABS=1: no overlap
+    const int T = g.npr * g.npc;
+    int S = std::max(1, (T + ctx->max_batch - 1) / ctx->max_batch);
+    if (const char* e = getenv("UMX_HOST_SLABS")) S = std::max(1, std::min(atoi(e), S));
+    while ((int)hs.events.size() < 2 * S + 1) {
+        hipEvent_t ev;
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hs.events.push_back(ev);
+    }
+    hipEvent_t* const ev_up = hs.events.data();
+    hipEvent_t* const ev_dn = hs.events.data() + S;
+    hipEvent_t ev_start = hs.events[2 * S];
+    (void)ev_start;   // (a slot's buffers are private to it and free again once host_wait has returned: no extra ordering)
+    std::vector<int> tcut(S + 1), cut(S + 1);   // tile cuts; cut[i] = patch rows COMPLETE after slab i-1 (cut[S] = npr)
+    for (int i = 0; i <= S; ++i) {
+        tcut[i] = (int)((long long)T * i / S);
+        cut[i] = tcut[i] / g.npc;
+    }
+    auto rows_needed = [&](int pr1) { return std::min(H, (pr1 - 1) * g.sub + g.P - g.margin); };
+    unsigned* const mm = (unsigned*)(base + mm_off);
+    unsigned char* const d_raw = base + raw_off;
+    auto upload = [&](int r0, int r1) -> int {   // image rows [r0, r1) of every plane
+        for (int c = 0; c < C_img && r1 > r0; ++c) {
+            const size_t off = ((size_t)c * H + r0) * W * in_b, n = (size_t)(r1 - r0) * W * in_b;
+            void* const dst = src_bits ? (void*)(d_raw + off) : (void*)((unsigned char*)hs.d_image + off);
+            HIP_TRY(ctx, hipMemcpyAsync(dst, (const unsigned char*)src + off, n, hipMemcpyHostToDevice, ctx->up_stream));
+        }
+        return UMX_OK;
+    };
+    auto convert = [&](int r0, int r1) -> int {   // raw rows -> float64 rows (im2double [+ rescale])
+        for (int c = 0; c < C_img && src_bits && r1 > r0; ++c) {
+            const size_t e0 = ((size_t)c * H + r0) * W;
+            HIP_TRY(ctx, launch_raw_convert(d_raw + e0 * in_b, src_bits, (size_t)(r1 - r0) * W, rescale, mm + 16 * c,
+                                            hs.d_image + e0, ctx->stream));
+        }
+        return UMX_OK;
+    };
+    int up_done = 0;
+    if (src_bits) {
+        for (int c = 0; c < C_img; ++c) HIP_TRY(ctx, launch_minmax_init(mm + 16 * c, ctx->stream));
+        if (rescale) {   // whole planes first: min / max per plane, reduced as the slabs arrive
+            for (int s = 0; s < S; ++s) {
+                const int r1 = s == S - 1 ? H : rows_needed((tcut[s + 1] - 1) / g.npc + 1);
+                if (r1 <= up_done) continue;
+                if ((rc = upload(up_done, r1))) return rc;
+                HIP_TRY(ctx, hipEventRecord(ev_up[s], ctx->up_stream));
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ev_up[s], 0));
+                for (int c = 0; c < C_img && r1 > up_done; ++c)
+                    HIP_TRY(ctx, launch_minmax(d_raw + ((size_t)c * H + up_done) * W * in_b, src_bits, (size_t)(r1 - up_done) * W,
+                                               mm + 16 * c, ctx->stream));
+                up_done = r1;
+            }
+            if ((rc = convert(0, H))) return rc;
+        }
+    }
+    int y_done = 0;
+    for (int s = 0; s < S; ++s) {
+        // rows the tiles of this slab read: up to the last patch row it touches
+        const int r1 = s == S - 1 ? H : rows_needed((tcut[s + 1] - 1) / g.npc + 1);
+        if (r1 > up_done) {
+            if ((rc = upload(up_done, r1))) return rc;
+            HIP_TRY(ctx, hipEventRecord(ev_up[s], ctx->up_stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ev_up[s], 0));
+            if ((rc = convert(up_done, r1))) return rc;
+            up_done = r1;
+        }
+        if (tcut[s + 1] > tcut[s]) {
+            float* const pr = hs.d_probs + (size_t)tcut[s] * g.P * g.P * K;
+            if ((rc = tiles_range(ctx, hs.d_image, C_img, g, 0, H, mean, stdv, tcut[s], tcut[s + 1], pr))) return rc;
+        }
+        // image rows no later tile touches: below the first incomplete patch row
+        const int y1 = s == S - 1 ? H : std::max(y_done, std::min(H, cut[s + 1] * g.sub - g.margin));
+        if (y1 > y_done && cut[s + 1] > 0) {
+            // the stitch writes a compact slab [K][rows][W]; slabs sit one after the other in the device buffer
+            const size_t rows = (size_t)(y1 - y_done), slab_e = K * (size_t)y_done * W;
+            unsigned char* const d_slab = base + slab_e * oel;
+            if ((rc = umx_stitch_dev(ctx, hs.d_probs, 0, cut[s + 1], H, W, mode, stitch, y_done, y1, d_slab))) return rc;
+            if (out_u8) HIP_TRY(ctx, launch_half_to_u8(d_slab, K * rows * W, base + pm_b + slab_e, ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ev_dn[s], ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->dn_stream, ev_dn[s], 0));
+            const size_t el = out_u8 ? 1 : oel;
+            const unsigned char* const dsrc = out_u8 ? base + pm_b + slab_e : d_slab;
+            for (size_t k = 0; k < K; ++k)
+                HIP_TRY(ctx, hipMemcpyAsync((unsigned char*)out_host + (k * plane + (size_t)y_done * W) * el,
+                                            dsrc + k * rows * W * el, rows * W * el, hipMemcpyDeviceToHost, ctx->dn_stream));
+            y_done = y1;
+        }
+    }
+    // the range flag of the split-precision path rides down behind the last planes; `done` then says the call is complete
+    // (every upload precedes a kernel that precedes a download on the download stream)
+    if (ctx->d_flag) {
+        hipEvent_t ev_f = hs.events[2 * S];
+        HIP_TRY(ctx, hipEventRecord(ev_f, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->dn_stream, ev_f, 0));
+        HIP_TRY(ctx, hipMemcpyAsync(hs.flag_host, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->dn_stream));
+    } else {
+        *hs.flag_host = 0;
+    }
+    HIP_TRY(ctx, hipEventRecord(hs.done, ctx->dn_stream));
+    hs.busy = true;
+    return UMX_OK;
+}
+
+static int infer_host(umx_ctx* ctx, const void* src, int src_bits, int C_img, int H, int W, int rescale, double mean,
+                      double stdv, int mode, int stitch, int out_u8, void* out_host) {
+    int rc = host_submit(ctx, 0, src, src_bits, C_img, H, W, rescale, mean, stdv, mode, stitch, out_u8, out_host);
+    if (rc) return rc;
+    return host_wait(ctx, 0);
+}
+
+
+
+int umx_infer_image(umx_ctx* ctx, const double* image_host, int C_img, int H, int W, double mean, double stdv, int mode,
+                    int stitch, void* out_host) {
+    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    if (!image_host || !out_host || H < 1 || W < 1 || C_img < 1) return fail(ctx, UMX_ERR_INVALID, "bad image/out/H/W");
+    if (C_img != 1 && C_img != ctx->hp.nChannels)
+        return fail(ctx, UMX_ERR_INVALID, "image has %d channels, model wants 1 or %d", C_img, ctx->hp.nChannels);
+    if (!(stdv != 0.0)) return fail(ctx, UMX_ERR_INVALID, "std must be non-zero");
+    if (mode != UMX_MODE_ACCUMULATE && mode != UMX_MODE_REPLACE) return fail(ctx, UMX_ERR_INVALID, "bad mode %d", mode);
+    if (stitch != UMX_STITCH_FP16_COMPAT && stitch != UMX_STITCH_FP32) return fail(ctx, UMX_ERR_INVALID, "bad stitch %d", stitch);
+    return infer_host(ctx, image_host, 0, C_img, H, W, 0, mean, stdv, mode, stitch, 0, out_host);
+}
+
+int umx_infer_image_raw(umx_ctx* ctx, const void* raw_host, int bits, int C_img, int H, int W, int rescale, double mean,
+                        double stdv, int mode, uint8_t* out_host) {
+    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    if (!raw_host || !out_host || H < 1 || W < 1 || C_img < 1) return fail(ctx, UMX_ERR_INVALID, "bad image/out/H/W");
+    if (bits != 8 && bits != 16) return fail(ctx, UMX_ERR_INVALID, "raw planes must be uint8 or uint16 (bits = %d)", bits);
+    if (C_img != 1 && C_img != ctx->hp.nChannels)
+        return fail(ctx, UMX_ERR_INVALID, "image has %d channels, model wants 1 or %d", C_img, ctx->hp.nChannels);
+    if (!(stdv != 0.0)) return fail(ctx, UMX_ERR_INVALID, "std must be non-zero");
+    if (mode != UMX_MODE_ACCUMULATE && mode != UMX_MODE_REPLACE) return fail(ctx, UMX_ERR_INVALID, "bad mode %d", mode);
+    return infer_host(ctx, raw_host, bits, C_img, H, W, rescale, mean, stdv, mode, UMX_STITCH_FP16_COMPAT, 1, out_host);
+}
+
+// ---- the drivers' whole recipe at --scalingFactor != 1 on the device (reference UnMicst1-5.py:807-821,845-854):
+// raw planes -> im2double -> resize to (int(H*sf), int(W*sf)) -> [rescale_intensity((min, max) -> (0, 0.983))] -> inference
+// -> np.uint8(255 * pm) -> resize back to (H, W) -> np.uint8(255 * .).  One resize = skimage.transform.resize's defaults
+// (umx_kernels.hip).  Synchronous; the planes are small next to the tile work, so nothing is pipelined here.
+static int resize_plane(umx_ctx* ctx, const double* src, int H, int W, int h, int w, double* tmpA, double* tmpB, double* wdev,
+                        unsigned long long* mm64, double* dst, unsigned char* dst_u8) {
+    const double* cur = src;
+    const double fy = (double)H / h, fx = (double)W / w;
+    const double sig[2] = {std::max(0.0, (fy - 1.0) / 2.0), std::max(0.0, (fx - 1.0) / 2.0)};
+    if (h < H || w < W) {   // anti-aliasing Gaussian, axis by axis (scipy.ndimage.gaussian_filter: axis 0 first)
+        double* bufs[2] = {tmpA, tmpB};
+        int which = 0;
+        for (int axis = 0; axis < 2; ++axis) {
+            if (!(sig[axis] > 1e-15)) continue;   // scipy skips axes with sigma <= 1e-15
+            const int radius = (int)(4.0 * sig[axis] + 0.5);
+            std::vector<double> wts((size_t)radius + 1);
+            double sum = 0.0;
+            std::vector<double> full(2 * (size_t)radius + 1);
+            for (int x = -radius; x <= radius; ++x) full[x + radius] = std::exp(-0.5 / (sig[axis] * sig[axis]) * (double)x * (double)x);
+            for (double v : full) sum += v;
+            for (int j = 0; j <= radius; ++j) wts[j] = full[radius + j] / sum;
+            if (radius + 1 > 4096) return fail(ctx, UMX_ERR_INVALID, "scaling factor too small for the resize kernel");
+            HIP_TRY(ctx, hipMemcpyAsync(wdev + axis * 4096, wts.data(), wts.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // (wts is a stack-lifetime host buffer)
+            HIP_TRY(ctx, launch_gauss1d(cur, bufs[which], H, W, axis, radius, wdev + axis * 4096, ctx->stream));
+            cur = bufs[which];
+            which ^= 1;
+        }
+    }
+    HIP_TRY(ctx, launch_minmax_f64(cur, (size_t)H * W, mm64, ctx->stream));   // resize clips to the (filtered) input's range
+    HIP_TRY(ctx, launch_zoom1(cur, H, W, h, w, mm64, dst, dst_u8, ctx->stream));
+    return UMX_OK;
+}
+
+// outlier < 0: rescale (if set) to the plane's (min, max); outlier in [0, 100]: to (min, np.percentile(plane, outlier))
+static int infer_raw_scaled_impl(umx_ctx* ctx, const void* raw_host, int bits, int C_img, int H, int W, double scaling, int rescale,
+                                 double outlier, double mean, double stdv, int mode, uint8_t* out_host) {
+    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    if (!raw_host || !out_host || H < 1 || W < 1 || C_img < 1) return fail(ctx, UMX_ERR_INVALID, "bad image/out/H/W");
+    if (bits != 8 && bits != 16) return fail(ctx, UMX_ERR_INVALID, "raw planes must be uint8 or uint16 (bits = %d)", bits);
+    if (C_img != 1 && C_img != ctx->hp.nChannels)
+        return fail(ctx, UMX_ERR_INVALID, "image has %d channels, model wants 1 or %d", C_img, ctx->hp.nChannels);
+    if (!(stdv != 0.0)) return fail(ctx, UMX_ERR_INVALID, "std must be non-zero");
+    if (!(scaling > 0.0)) return fail(ctx, UMX_ERR_INVALID, "scaling factor must be positive");
+    const int h = (int)((double)H * scaling), w = (int)((double)W * scaling);   // int(float(I.shape[0]) * float(sf))
+    if (h < 1 || w < 1) return fail(ctx, UMX_ERR_INVALID, "scaled image is empty");
+    const bool same = h == H && w == W;   // resize(I, I.shape) leaves im2double(I): the pipelined path does all but the percentile
+    if (same && outlier < 0) return umx_infer_image_raw(ctx, raw_host, bits, C_img, H, W, rescale, mean, stdv, mode, out_host);
+    if (mode != UMX_MODE_ACCUMULATE && mode != UMX_MODE_REPLACE) return fail(ctx, UMX_ERR_INVALID, "bad mode %d", mode);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t big = (size_t)std::max(H, h) * std::max(W, w), plane = (size_t)H * W, sp = (size_t)h * w, K = ctx->hp.nClasses;
+    const size_t in_b = bits / 8;
+    // scratch: [raw upload | 3 float64 work planes of the larger size | scaled input planes | fp16 result | u8 out | weights | mm]
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_raw = take(plane * C_img * in_b), o_a = take(big * 8), o_b = take(big * 8), o_c = take(big * 8);
+    const size_t o_in = take(sp * C_img * 8), o_pm = take(K * sp * 2), o_u8 = take(K * plane), o_w = take(2 * 4096 * 8), o_mm = take(256);
+    const size_t o_sel = take(64 + 512 * 4);   // radix-selection state + histograms of the percentile
+    int rc;
+    umx_ctx::HostSlot& hs = ctx->hs[0];
+    if (hs.busy) return fail(ctx, UMX_ERR_INVALID, "slot 0 still holds a submitted call: wait for it first");
+    if ((rc = grow(ctx, &hs.d_out, &hs.out_cap, off))) return rc;
+    unsigned char* const base = (unsigned char*)hs.d_out;
+    double *A = (double*)(base + o_a), *B = (double*)(base + o_b), *Cw = (double*)(base + o_c), *din = (double*)(base + o_in);
+    double* const wdev = (double*)(base + o_w);
+    unsigned long long* const mm64 = (unsigned long long*)(base + o_mm);
+    unsigned* const mm32 = (unsigned*)(base + o_mm + 64);
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_raw, raw_host, plane * C_img * in_b, hipMemcpyHostToDevice, ctx->stream));
+    for (int c = 0; c < C_img; ++c) {
+        HIP_TRY(ctx, launch_minmax_init(mm32, ctx->stream));
+        HIP_TRY(ctx, launch_raw_convert(base + o_raw + (size_t)c * plane * in_b, bits, plane, 0, mm32, A, ctx->stream));   // im2double
+        if (same) HIP_TRY(ctx, hipMemcpyAsync(din + (size_t)c * sp, A, sp * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        else if ((rc = resize_plane(ctx, A, H, W, h, w, B, Cw, wdev, mm64, din + (size_t)c * sp, nullptr))) return rc;
+        if (rescale) {   // rescale_intensity(I, (min, max | percentile), (0, 0.983)) of the RESIZED plane (UnMicst1-5.py:817-821)
+            HIP_TRY(ctx, launch_minmax_f64(din + (size_t)c * sp, sp, mm64, ctx->stream));
+            if (outlier >= 0)
+                HIP_TRY(ctx, launch_percentile_f64(din + (size_t)c * sp, sp, outlier, (unsigned long long*)(base + o_sel),
+                                                   (unsigned*)(base + o_sel + 64), mm64, ctx->stream));
+            HIP_TRY(ctx, launch_rescale_f64(din + (size_t)c * sp, sp, mm64, ctx->stream));
+        }
+    }
+    if ((rc = umx_infer_image_dev(ctx, din, C_img, h, w, mean, stdv, mode, UMX_STITCH_FP16_COMPAT, base + o_pm))) return rc;
+    for (size_t k = 0; k < K; ++k) {
+        if (same) {   // resize of a uint8 plane to its own shape and back through np.uint8(255 * .): the plane itself
+            HIP_TRY(ctx, launch_half_to_u8(base + o_pm + k * sp * 2, sp, base + o_u8 + k * plane, ctx->stream));
+            continue;
+        }
+        HIP_TRY(ctx, launch_half_to_u8_f64(base + o_pm + k * sp * 2, sp, A, ctx->stream));   // np.uint8(255 * pm) as float u8/255
+        if ((rc = resize_plane(ctx, A, h, w, H, W, B, Cw, wdev, mm64, nullptr, base + o_u8 + k * plane))) return rc;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(out_host, base + o_u8, K * plane, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return check_range_flag(ctx);
+}
+
+int umx_infer_image_raw_scaled(umx_ctx* ctx, const void* raw_host, int bits, int C_img, int H, int W, double scaling, int rescale,
+                               double mean, double stdv, int mode, uint8_t* out_host) {
+    return infer_raw_scaled_impl(ctx, raw_host, bits, C_img, H, W, scaling, rescale, -1.0, mean, stdv, mode, out_host);
+}
+
+int umx_infer_image_raw_outlier(umx_ctx* ctx, const void* raw_host, int bits, int C_img, int H, int W, double scaling, double outlier,
+                                double mean, double stdv, int mode, uint8_t* out_host) {
+    if (!(outlier >= 0.0 && outlier <= 100.0)) return fail(ctx, UMX_ERR_INVALID, "outlier percentile must be in [0, 100]");
+    return infer_raw_scaled_impl(ctx, raw_host, bits, C_img, H, W, scaling, 1, outlier, mean, stdv, mode, out_host);
+}
+
+int umx_infer_image_raw_submit(umx_ctx* ctx, int slot, const void* raw_host, int bits, int C_img, int H, int W, int rescale,
+                               double mean, double stdv, int mode, uint8_t* out_host) {
+    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    if (!raw_host || !out_host || H < 1 || W < 1 || C_img < 1) return fail(ctx, UMX_ERR_INVALID, "bad image/out/H/W");
+    if (bits != 8 && bits != 16) return fail(ctx, UMX_ERR_INVALID, "raw planes must be uint8 or uint16 (bits = %d)", bits);
+    if (C_img != 1 && C_img != ctx->hp.nChannels)
+        return fail(ctx, UMX_ERR_INVALID, "image has %d channels, model wants 1 or %d", C_img, ctx->hp.nChannels);
+    if (!(stdv != 0.0)) return fail(ctx, UMX_ERR_INVALID, "std must be non-zero");
+    if (mode != UMX_MODE_ACCUMULATE && mode != UMX_MODE_REPLACE) return fail(ctx, UMX_ERR_INVALID, "bad mode %d", mode);
+    return host_submit(ctx, slot, raw_host, bits, C_img, H, W, rescale, mean, stdv, mode, UMX_STITCH_FP16_COMPAT, 1, out_host);
+}
+
+int umx_infer_image_wait(umx_ctx* ctx, int slot) {
+    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    return host_wait(ctx, slot);
+}
+
+}  // extern "C"

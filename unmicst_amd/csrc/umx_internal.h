@@ -1,0 +1,237 @@
+// Internal host-side interface of libumx (gfx950 only): the graph / plan / context structures shared by the graph builder
+// (umx_graph.hip), the split-precision planner (umx_plan.hip), the engine and C ABI (umx_engine.hip) and the host pipeline
+// (umx_host.hip).  Nothing here is part of the C ABI (include/umx.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/umx.h"
+#include "umx_kernels.h"
+
+
+namespace umx {
+
+struct HostTensor {
+    const float* p;
+    int d0, d1, d2, d3;  // [kh,kw,a,b]
+    float at(int i, int j, int a, int b) const { return p[(((size_t)i * d1 + j) * d2 + a) * d3 + b]; }
+};
+
+struct BN {
+    const float *g, *b, *m, *v;
+};
+
+struct Group {           // one operand group of a launch, host description
+    int src;             // buffer id
+    int C;               // channels
+    std::vector<std::pair<int, int>> taps[4];  // per phase: (dy, dx) input offsets
+    std::vector<float> packed[4];              // per phase: [ntaps][Cp][Np]
+};
+
+struct Launch {
+    std::string name;
+    bool head = false;
+    int ngroups = 0;
+    Group g[2];
+    int nphase = 1, o_mul = 1;
+    int oy_off[4] = {0, 0, 0, 0}, ox_off[4] = {0, 0, 0, 0};
+    int H = 0, W = 0, Cout = 0;
+    int dst = -1, outH = 0, outW = 0, pool = 0, act = 0;
+    std::vector<float> pre_s, pre_b, post_s, post_b;  // size Cout or empty
+    // head only
+    std::vector<float> head_w;  // [C][K]
+    int head_C = 0, head_K = 0;
+    // derived
+    int nt = 1, Np = 16, hpix = 2;
+    double flops = 0.0;       // algorithmic FLOPs per tile (per image of the batch)
+    double exec_flops = 0.0;  // executed incl. channel/N padding
+    double bytes = 0.0;       // compulsory HBM bytes per tile: sources + destination (weights excluded)
+    // device
+    ConvParams cp;
+    // split-precision plan (UMX_PREC_F16X3)
+    HConvParams hcp;
+    FirstParams first;        // dense-K plan of the first down-sampling layer (use_first; umx_conv_first.hip)
+    bool use_first = false;
+    int nt16 = 1;             // N-tiles per workgroup of the split-precision kernel
+    int wshift = 0;           // weights are stored times 2^wshift
+    int n_ksteps = 0;         // K-slots of 32 executed per output tile, all phases (for the executed-FLOP figure)
+    float* d_head_w = nullptr;
+    float *d_pre_s = nullptr, *d_pre_b = nullptr, *d_post_s = nullptr, *d_post_b = nullptr;
+};
+
+struct Buffer {
+    size_t floats_per_tile = 0;
+    int S = 0, C = 0;        // spatial size and real channels of the tensor
+    int Cs = 0;              // stored channels of the (hi, lo) binary16 form
+    bool as_f32 = true;      // fp32 NHWC (f32 path, and the head's input in the f16 path) or (hi, lo) binary16 planes
+    bool planar = false;     // (hi, lo) planes stored per image as [octet][pixel][8] instead of NHWC (tensors of >= 16 x 16 pixels)
+    float* d = nullptr;
+};
+
+struct ProfSite {
+    std::string name, kernel;
+    int64_t launches = 0;
+    double total_ms = 0.0, flops = 0.0, bytes = 0.0, exec = 0.0;
+};
+
+struct PendingEvent {
+    int site;
+    hipEvent_t a, b;
+};
+
+}  // namespace umx
+
+struct umx_ctx {
+    using Launch = umx::Launch;
+    using Buffer = umx::Buffer;
+    using ProfSite = umx::ProfSite;
+    using PendingEvent = umx::PendingEvent;
+    umx_hparams hp;
+    int device = 0;
+    int max_batch = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::vector<Launch> plan;
+    std::vector<Buffer> bufs;   // bufs[0] = input tiles
+    // Second "lane": the tile batches of one band alternate between two activation-buffer sets on two streams, so that
+    // the kernels of batch i+1 fill the CUs the tail of batch i's current layer leaves idle and MFMA-bound layers of one
+    // batch share a CU with the load-bound full-resolution layers of the other.
+    std::vector<Buffer> bufs2;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    float* d_tiles32_2 = nullptr;
+    int nlanes = 1, lane = 0;
+    int ncu = 256;
+    // host entry points: uploads / downloads on their own streams, slab by slab, under the tile kernels
+    hipStream_t up_stream = nullptr, dn_stream = nullptr;
+    struct HostSlot {   // device buffers + events of one in-flight host call (two slots: slide i+1 uploads while slide i computes)
+        double* d_image = nullptr;  size_t image_cap = 0;
+        float* d_probs = nullptr;   size_t probs_cap = 0;
+        void* d_out = nullptr;      size_t out_cap = 0;
+        std::vector<hipEvent_t> events;
+        hipEvent_t done = nullptr;
+        int* flag_host = nullptr;   // pinned copy of the range flag, read back behind the slot's last download
+        bool busy = false;
+    } hs[2];
+    std::vector<void*> allocs;
+    std::string err;
+    // whole-image scratch (grown on demand)
+    double* d_image = nullptr;  size_t image_cap = 0;
+    float* d_probs = nullptr;   size_t probs_cap = 0;
+    void* d_out = nullptr;      size_t out_cap = 0;
+    float* d_io_tiles = nullptr; size_t io_tiles_cap = 0;
+    float* d_io_probs = nullptr; size_t io_probs_cap = 0;
+    // profiling
+    bool prof = false;
+    std::vector<ProfSite> sites;
+    std::vector<PendingEvent> pending;
+    std::vector<hipEvent_t> free_events;
+    int site_gather = -1, site_stitch = -1, site_split = -1;
+    // precision
+    int precision = UMX_PREC_F16X3;
+    int act_shift = 0;          // activations are stored times 2^act_shift in the (hi, lo) binary16 form
+    float* d_tiles32 = nullptr; // fp32 staging of gathered tiles before the split (f16 path)
+    int* d_flag = nullptr;      // binary16 range overflow flag
+    uint4* d_zeros = nullptr;
+    bool head_fused = false;
+    Launch split_launch;
+};
+
+namespace umx {
+
+extern thread_local std::string g_err;
+
+inline std::vector<Buffer>& cur_bufs(umx_ctx* ctx) { return ctx->lane ? ctx->bufs2 : ctx->bufs; }
+inline hipStream_t run_stream(umx_ctx* ctx) { return ctx->lane ? ctx->stream2 : ctx->stream; }
+
+int fail(umx_ctx* ctx, int code, const char* fmt, ...);
+
+#define HIP_TRY(ctx, expr)                                                                                  \
+    do {                                                                                                    \
+        hipError_t e__ = (expr);                                                                            \
+        if (e__ != hipSuccess)                                                                              \
+            return fail(ctx, e__ == hipErrorOutOfMemory ? UMX_ERR_OOM : UMX_ERR_HIP, "%s failed: %s", #expr, \
+                        hipGetErrorString(e__));                                                            \
+    } while (0)
+
+
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// ---- umx_graph.hip: hyper-parameters -> launch list (reference UnMicst1-5.py:55-237, UnMicst.py:51-187)
+int check_hp(const umx_hparams* hp, std::string* why);
+std::vector<int> widths(const umx_hparams& hp);
+size_t blob_floats_needed(const umx_hparams& hp);
+// builds the launch list and the activation-buffer list (per-tile floats, (spatial size, channels)); blob may be NULL
+// (describe only); *pos = floats of the blob consumed
+int build_graph(const umx_hparams& hp, const float* blob, std::vector<Launch>* plan, std::vector<size_t>* buf_floats,
+                std::vector<std::pair<int, int>>* buf_geom, size_t* pos);
+bool conv_geometry(Launch& L, std::string* why);
+
+// ---- umx_plan.hip: split-precision plan of one launch
+int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch* head, std::string* why);
+// dense-K plan of the first down-sampling layer, for a launch plan_f16 has just planned (sets L.use_first when it applies)
+int plan_first(umx_ctx* ctx, Launch& L, int act_shift, std::string* why);
+
+// ---- umx_engine.hip
+int dev_alloc(umx_ctx* ctx, void** out, size_t bytes);
+int upload(umx_ctx* ctx, const std::vector<float>& h, float** out);
+template <typename T>
+int upload_raw(umx_ctx* ctx, const std::vector<T>& h, T** out) {
+    *out = nullptr;
+    if (h.empty()) return UMX_OK;
+    void* d = nullptr;
+    int rc = dev_alloc(ctx, &d, h.size() * sizeof(T));
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (T*)d;
+    return UMX_OK;
+}
+
+int grow(umx_ctx* ctx, void** buf, size_t* cap, size_t bytes);
+int site_of(umx_ctx* ctx, const std::string& name, const std::string& kernel);
+int prof_fold(umx_ctx* ctx);
+struct ProfScope {
+    umx_ctx* ctx;
+    int site;
+    hipEvent_t a = nullptr, b = nullptr;
+    bool on;
+    ProfScope(umx_ctx* c, int s, double flops, double bytes, double exec = 0.0) : ctx(c), site(s), on(c->prof && s >= 0) {
+        if (!on) return;
+        auto get = [&](hipEvent_t* e) {
+            if (!ctx->free_events.empty()) { *e = ctx->free_events.back(); ctx->free_events.pop_back(); }
+            else if (hipEventCreate(e) != hipSuccess) *e = nullptr;
+        };
+        get(&a);
+        get(&b);
+        if (!a || !b) { on = false; return; }
+        ctx->sites[site].launches += 1;
+        ctx->sites[site].flops += flops;
+        ctx->sites[site].bytes += bytes;
+        ctx->sites[site].exec += exec;
+        hipEventRecord(a, run_stream(ctx));
+    }
+    ~ProfScope() {
+        if (!on) return;
+        hipEventRecord(b, run_stream(ctx));
+        ctx->pending.push_back({site, a, b});
+    }
+};
+
+inline _Float16* hi_of(const Buffer& b) { return reinterpret_cast<_Float16*>(b.d); }
+inline _Float16* lo_of(const Buffer& b, int n) { return reinterpret_cast<_Float16*>(b.d) + (size_t)n * b.S * b.S * b.Cs; }
+
+int check_range_flag(umx_ctx* ctx);   // call with the stream idle
+TileGeom geom_of(const umx_hparams& hp, int H, int W);
+// tiles [t0, t1) of the slide (row-major tile index) -> probs_dev (tile t0 first): gather + normalise + UNet
+int tiles_range(umx_ctx* ctx, const double* image_dev, int C_img, const TileGeom& g, int band_row0, int band_rows,
+                double mean, double stdv, int t0, int t1, float* probs_dev);
+
+}  // namespace umx

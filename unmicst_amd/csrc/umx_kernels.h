@@ -97,12 +97,9 @@ struct HConvParams {
     int PP, nact, ninst;           // halo chunk = ninst LDS-DMA pieces of PP = 64/OC pixels x OC octets (nact = PP*OC lanes)
     int piece_bytes;               // PP*OC*16: LDS bytes one piece fills (the image stays dense: slot = pixel*OC + octet)
     int inv_oc_q16;                // 65536/OC + 1: lane / OC == (lane * inv_oc_q16) >> 16 for lane < 64
-    int kmt;                       // M-tiles per wave of the plain kernel: 4 (4 waves per workgroup) or 2 (8 waves)
+    int kmt;                       // M-tiles per wave: 4 (plain kernel) or 2 (fused transposed convolution)
     int xcd_order;                 // 1: workgroup ids are re-ordered so that each XCD (ids = x mod 8) walks a contiguous range of tiles
     int maxp;                      // halo pieces per wave and chunk the launched instantiation indexes: 4 or 12
-    int stagger, first_gen, nres;  // stagger > 0: a workgroup of the launch's first generation (linear id < first_gen) sleeps
-                                   // (hardware wave slot % nres) * stagger cycles before it starts, so that the nres
-                                   // workgroups sharing a CU do not run their matrix phases in lockstep
     int stg_off;                   // LDS byte offset of the epilogue's transpose staging (clear of weight buffer 1: the
                                    // epilogue constants sit there while the staged rows are written)
     int lo_off, b_off, lds_bytes;  // LDS byte offsets: lo planes, weight buffers; total dynamic LDS
@@ -115,9 +112,6 @@ struct HConvParams {
     const uint4* zeros;          // >= 16 bytes of zeros in global memory (source for out-of-image halo slots)
     _Float16* dst_hi;
     _Float16* dst_lo;
-    const _Float16* app_hi;      // non-NULL: after the epilogue, word `app_word` (2 channels) of the stored octet that starts
-    const _Float16* app_lo;      // at channel app_c0 is replaced by channels 0..1 of this tensor ([..,app_Cs], same pixel
-    int app_Cs, app_c0, app_word;   // grid as the destination): the raw-input skip rides in the spare channels
     float* dst_f32;              // non-NULL: write fp32 NHWC [..,Cout] instead of the (hi, lo) pair
     float* probs;                // head_K > 0: fused 1x1 conv + BN affine + softmax head, probabilities NHWC [..,head_K]
     int head_K;                  // (needs nblocks == 1: every channel of a pixel in one workgroup)
@@ -135,42 +129,43 @@ struct HConvParams {
 
 hipError_t launch_conv_f16(const HConvParams& p, hipStream_t stream);
 
-// ---- register-resident-weight variant for the narrow full-resolution layers (umx_conv_rw.hip): persistent workgroups,
-// the layer's whole packed weight set in VGPRs, only input halos move (LDS-DMA, double-buffered per 16x16-pixel tile)
-struct RwParams {
-    const _Float16* src_hi[2];   // NHWC binary16 [B,H,W,Cs], hi and lo planes, per operand group
-    const _Float16* src_lo[2];
-    int Cs[2], noct[2], goct[2]; // stored channels; octets loaded; first octet column of the group in the LDS image
-    int ngroups;
-    int B, H, W;                 // H, W multiples of 16 (tile = 16 x 16 output pixels)
-    int hh, hw, nhalo, ymin, xmin;
-    float inv_hw;
-    int OCT, pix_bytes;          // octet columns per halo pixel of the LDS image (all groups side by side), OCT*16
-    int PP, nact, ninst, piece_bytes, inv_oct_q16;   // LDS-DMA pieces of PP = 64/OCT pixels
-    int plane_bytes;             // hi image of one tile buffer (== offset of its lo image); a buffer is 2*plane_bytes
-    int ec_off, ec_units, lds_bytes;
-    int tx_log2, ty_log2, ntiles;   // tiles per image row / column (powers of two), B*tiles
-    int nk;                      // k-steps (the kernel's NK)
-    const unsigned short* kmap;  // [nk][4]: 16-byte slot of the (tap, octet) pair inside a tile buffer's hi image
-    const uint4* w;              // [nk][NT][hi|lo][64 lanes] x 16 B: MFMA A-fragments
-    const uint4* econst;         // as HConvParams::econst (one N-block)
-    int act, head_K;
-    int post_affine;             // 1: a second affine follows the activation (legacy graph: BN after ReLU)
-    float* probs;                // fused 1x1 head + BN + softmax output, NHWC [B,H,W,head_K]
-    const uint4* head_frag;      // the 1x1 head as MFMA A-fragments: [ceil(NT/2) k-steps][hi|lo][64 lanes] x 16 B (rows = classes)
-    float head_unscale;          // 2^-hs: the head weights are stored times 2^hs
-    int* overflow_flag;          // set when an activation feeding the head leaves binary16's range
-};
-bool conv_rw_supported(int NT, int NK);
-hipError_t launch_conv_rw(const RwParams& p, int NT, int ncu, hipStream_t stream);
-hipError_t launch_split_f32(const float* x, size_t npix, int C, int Cs, float scale, _Float16* hi, _Float16* lo,
-                            hipStream_t stream);
-
+// ---- first down-sampling layer, umx_conv_first.hip: the K extent of the layer (taps x input channels: 9 x 2 = 18 for the duo
+// models, 9 for solo, 25 for the legacy 5 x 5 graph) packed DENSELY into 1-2 MFMA k-steps instead of one octet (8 channel
+// slots, 1-2 of them real) per tap; weights live in registers, a workgroup owns a 16 x (16..64)-pixel region of one tile
 struct TileGeom {
     int H, W;            // full image size
     int P, margin, sub;  // patch size, margin, sub-patch
     int npr, npc;        // patch rows / cols
 };
+
+struct FirstParams {
+    const _Float16* src_hi;   // the input tiles as (hi, lo) binary16 NHWC planes with 8 stored channels [B,P,P,8] ...
+    const _Float16* src_lo;
+    const double* image;      // ... or (non-NULL) the float64 slide band itself: PI2D.getPatch + normalise fused into the load
+    int C_img, band_row0, band_rows, tile0;
+    TileGeom g;
+    double mean, stdv;
+    float in_scale;           // 2^(activation shift)
+    int B, P, Ci;
+    int ks, ntaps;            // ks x ks taps, SAME padding
+    int NT, CW, NKS;          // N-tiles of 16 output channels; channel slots per tap (1, 2, 4); k-steps (K = ntaps * CW <= 32 * NKS)
+    int rw_log2;              // region = 16 rows x 2^rw_log2 columns of the tile per workgroup
+    int hh, hw;               // halo of a region (pixels)
+    float inv_hw;
+    int lds_bytes;
+    const uint4* w;           // MFMA A-fragments [NKS][NT][hi | lo][64 lanes] x 16 B, rows = output channels
+    const float* econst;      // [pre_s | pre_b | post_s | post_b] x NT*16 (HConvParams::econst of the same layer)
+    int act, post_affine;
+    _Float16* dst_hi;         // pooled output, (hi, lo) planes, NHWC or octet-planar
+    _Float16* dst_lo;
+    int Cds, dst_planar, outS;
+    int* overflow_flag;
+};
+bool conv_first_supported(int NT, int CW, int NKS);
+hipError_t launch_conv_first(const FirstParams& p, hipStream_t stream);
+
+hipError_t launch_split_f32(const float* x, size_t npix, int C, int Cs, float scale, _Float16* hi, _Float16* lo,
+                            hipStream_t stream);
 
 hipError_t launch_gather_split(const double* image, int C_img, int band_row0, int band_rows, const TileGeom& g, int Cn,
                                double mean, double stdv, int tile0, int ntiles, float scale, _Float16* hi, _Float16* lo,

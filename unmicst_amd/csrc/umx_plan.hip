@@ -1,0 +1,454 @@
+// Split-precision planner of libumx: chunking of the input octets, k-step table, stage table and packed weight images of
+// one convolution launch for conv_f16x3 (layout documented in umx_conv_f16.hip).  Host code only.
+#include "umx_internal.h"
+
+namespace umx {
+
+// ---- split-precision plan of one conv launch: chunking of the input octets, k-step table, stage table, weight images
+// (layout documented in umx_conv_f16.hip).  Reads the fp32 packing [tap][Cp][Np] produced by the Builder.
+int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch* head, std::string* why) {
+    const ConvParams& g = L.cp;   // tile geometry shared with the fp32 kernel
+    HConvParams& h = L.hcp;
+    memset(&h, 0, sizeof h);
+    const int t16 = (L.Cout + 15) / 16;
+    // stride-2 transposed convolution with few output channels: all four sub-pixel phases in one workgroup (the input
+    // halo is read once instead of four times; 4 accumulator sets limit it to 5 N-tiles and 128 input pixels)
+    const bool fused = L.nphase == 4 && L.o_mul == 2 && L.ngroups == 1 && !out_f32 && t16 <= 5 && L.H >= 8 && L.W >= 16 &&
+                       !getenv("UMX_NO_FUSED_CONVT");
+    h.fused_phases = fused ? 1 : 0;
+    if (fused) {
+        const int THg = 1 << g.th_log2, TWg = 1 << g.twm_log2;   // >= 8 and == 16 under the conditions above
+        h.twm_log2 = 4; h.th_log2 = 3; h.nimg_m = 1; h.imgs = 1;
+        h.hh = 8 + (g.hh - THg); h.hw = 16 + (g.hw - TWg);
+        h.tiles_y = L.H / 8; h.tiles_x = L.W / 16;
+    } else {
+        h.twm_log2 = g.twm_log2; h.th_log2 = g.th_log2; h.nimg_m = g.nimg_m; h.imgs = g.imgs;
+        h.hh = g.hh; h.hw = g.hw; h.tiles_y = g.tiles_y; h.tiles_x = g.tiles_x;
+    }
+    h.imgplane = h.hh * h.hw; h.nhalo = h.imgs * h.imgplane;
+    h.ymin = g.ymin; h.xmin = g.xmin;
+    h.nphase = L.nphase; h.o_mul = L.o_mul;
+    h.H = L.H; h.W = L.W; h.Cout = L.Cout; h.Cds = round_up(L.Cout, 8);
+    int nt16 = 1, Np16 = 16;
+    {   // N-tiles per workgroup: minimise padded N, prefer wide workgroups (fewer re-reads of the input halo)
+        int best_pad = 1 << 30;
+        for (int c = 1; c <= (fused ? 5 : kMaxNT16); ++c) {
+            const int padded = round_up(t16, c);
+            if (padded < best_pad || (padded == best_pad && c > nt16)) { nt16 = c; best_pad = padded; }
+        }
+        Np16 = best_pad * 16;
+    }
+    L.nt16 = nt16;
+    h.NT = nt16; h.nblocks = Np16 / (16 * nt16);
+    h.outH = L.outH; h.outW = L.outW; h.pool = L.pool; h.act = L.act;
+    if (h.nhalo > kHaloChunks * 64) { *why = "halo too large for the split-precision kernel"; return UMX_ERR_INVALID; }
+    h.plane_slots = round_up(h.nhalo, 16);
+    const int plane_pair = h.plane_slots * 16 * 2;   // hi + lo bytes of one octet plane
+
+    // weight shift: largest |w| lands in [2^13, 2^14) so that the lo parts stay in binary16's normal range
+    float maxabs = 0.f;
+    for (int ph = 0; ph < L.nphase; ++ph)
+        for (int gi = 0; gi < L.ngroups; ++gi)
+            for (float v : L.g[gi].packed[ph]) maxabs = std::max(maxabs, std::fabs(v));
+    L.wshift = 0;
+    if (maxabs > 0.f && std::isfinite(maxabs)) {
+        int e;
+        std::frexp(maxabs, &e);           // maxabs = m * 2^e, m in [0.5, 1)
+        L.wshift = std::max(-24, std::min(30, 14 - e));
+    }
+    const float wscale = std::ldexp(1.f, L.wshift);
+
+    // ---- chunking.  A chunk = up to OC octets of one operand group, resident in LDS while its (tap, octet) pairs are
+    // consumed 4 per k-step; a stage = up to S k-steps = one weight block.  Consecutive chunks alternate between two
+    // halo slots (even chunks at plane 0, odd chunks behind them) so that chunk c+1 loads while chunk c computes.
+    // Per-phase kernels walk their own chunk list (groups with taps in that phase); the fused kernel walks one list
+    // and, inside each chunk, the phases one after the other.
+    int noct[2] = {0, 0};
+    for (int gi = 0; gi < L.ngroups; ++gi) noct[gi] = round_up(L.g[gi].C, 8) / 8;
+    struct Chunk { int gi, o0, o1; };
+    auto chunks_for = [&](int OC, int ph /* -1: every group */) {
+        std::vector<Chunk> out;
+        for (int gi = 0; gi < L.ngroups; ++gi) {
+            if (ph >= 0 && L.g[gi].taps[ph].empty()) continue;
+            const int nchunk = (noct[gi] + OC - 1) / OC;
+            for (int c = 0; c < nchunk; ++c) out.push_back({gi, c * noct[gi] / nchunk, (c + 1) * noct[gi] / nchunk});
+        }
+        return out;
+    };
+    const int nlists = fused ? 1 : L.nphase;   // independent stage lists (= kernel phases)
+    auto phases_of = [&](int list) { return fused ? std::make_pair(0, L.nphase) : std::make_pair(list, list + 1); };
+    // Search attempts, in order of preference: (pieces per wave and chunk the kernel instantiation indexes, LDS budget per
+    // workgroup).  80 KiB = 2 workgroups per CU; narrow layers (few accumulators -> few VGPRs) first try the budgets that let
+    // 4 (<= 3 N-tiles, 128 VGPRs) or 3 workgroups per CU cover each other, and the 4-piece instantiation (8 VGPRs fewer).
+    struct Attempt { int maxp, cap, max_chunks; };
+    std::vector<Attempt> attempts;
+    {
+        const int narrow = 53 * 1024;   // 3 workgroups per CU
+        const int narrow_nt = 5;        // the kernels of <= 5 N-tiles fit 3 waves per SIMD
+        const int nt3 = 40 * 1024;      // 4 workgroups per CU (the <= 3-tile kernels are built for 128 VGPRs)
+        if (fused) attempts = {{nt16 <= 3 ? 12 : 4, kMaxLdsPerWG, 1 << 30}};   // (the fused kernels exist in one piece count each)
+        else {
+            for (int maxp : {4, 12}) {
+                if (maxp == 12 && nt16 > 5) break;
+                // (4-5 N-tiles: the third workgroup per CU pays only while the smaller chunks stay few -- ld1.conv, 6 chunks:
+                // -12 %; lu1.conv, 24 chunks: +1 %)
+                const int few = nt16 <= 3 ? 1 << 30 : 8;
+                if (nt16 <= 3 && maxp == 4) attempts.push_back({maxp, nt3, 1 << 30});
+                if (nt16 <= narrow_nt) attempts.push_back({maxp, narrow, few});
+                attempts.push_back({maxp, kMaxLdsPerWG, 1 << 30});
+            }
+        }
+    }
+    const int stage_rows = fused ? 32 : 16;
+    const int nwaves = kWaves;
+    h.kmt = fused ? 2 : kMT;
+    const int epi_bytes = nwaves * 2 * stage_rows * (nt16 * 32 + 16);   // epilogue transpose staging
+    // dynamic LDS of a plan: halo slots (hi + lo) | weight buffer 0 | weight buffer 1 | the staging area, unless it fits below
+    // buffer 1 (the epilogue constants sit in buffer 1 while the staged rows are written: the kernel orders the buffers so)
+    auto lds_total = [&](int nslots, int oc, int ss, int plane_pair_bytes) {
+        const int below = nslots * oc * plane_pair_bytes, wb = 64 + ss * nt16 * 2048;
+        return below + 2 * wb + (epi_bytes <= below + wb ? 0 : epi_bytes);
+    };
+
+    // One stage list (= one kernel phase, or the whole fused transposed convolution) for a given (OC, S, slot base E):
+    // (tap, octet) pairs of every chunk -> k-steps of 4 -> stages of <= S k-steps.  Pairs left over when a chunk's
+    // pair count is not a multiple of 4 are carried into the first k-step of the next chunk instead of being padded:
+    // the previous chunk's halo slot is still resident then (its reload is issued at the start of the next chunk's LAST
+    // stage, so the next chunk must have >= 2 stages).  Not across the phases of the fused kernel (other accumulators).
+    struct Pair { int gi, ph, tap, oct, slot, k; };   // slot: halo slot (0/1) of the chunk; k: octet inside the chunk
+    const bool carry_ok = !fused && !getenv("UMX_NO_KSTEP_CARRY");
+    auto npairs_of = [&](const Chunk& k, int ph) { return (int)L.g[k.gi].taps[ph].size() * (k.o1 - k.o0); };
+    auto plan_list = [&](int OC, int S, int list, std::vector<HStage>* stages_out,
+                         std::vector<std::vector<Pair>>* steps_out, int* nchunks) {
+        const auto pr = phases_of(list);
+        const auto ch = chunks_for(OC, fused ? -1 : list);
+        if (nchunks) *nchunks = (int)ch.size();
+        int nsteps = 0;
+        std::vector<Pair> carry;
+        for (size_t c = 0; c < ch.size(); ++c) {
+            const int gi = ch[c].gi, o0 = ch[c].o0, o1 = ch[c].o1;
+            const int slot = (int)(c & 1);   // consecutive chunks alternate between the two halo slots
+            bool first = true;   // the chunk's first stage carries its halo load
+            for (int ph = pr.first; ph < pr.second; ++ph) {
+                const int nt = (int)L.g[gi].taps[ph].size();
+                if (!nt) continue;
+                std::vector<Pair> pairs = carry;
+                carry.clear();
+                for (int t = 0; t < nt; ++t)
+                    for (int o = o0; o < o1; ++o) pairs.push_back({gi, ph, t, o, slot, o - o0});
+                const int rem = (int)pairs.size() % 4;
+                if (rem && carry_ok && c + 1 < ch.size() && (int)pairs.size() >= 4) {
+                    // stages the next chunk will have if it takes the remainder (it pads or carries on in turn)
+                    const int next_k = (rem + npairs_of(ch[c + 1], ph) + (c + 2 < ch.size() ? 0 : 3)) / 4;
+                    if ((next_k + S - 1) / S >= 2) {
+                        carry.assign(pairs.end() - rem, pairs.end());
+                        pairs.resize(pairs.size() - rem);
+                    }
+                }
+                while (pairs.size() % 4) pairs.push_back({gi, ph, -1, o0, slot, 0});   // zero-weight filler on a loaded slot
+                const int nk_chunk = (int)pairs.size() / 4;
+                nsteps += nk_chunk;
+                for (int k = 0; k < nk_chunk; k += S) {
+                    HStage st;
+                    memset(&st, 0, sizeof st);
+                    st.group = first ? (short)gi : (short)-1;
+                    first = false;
+                    st.oct0 = (short)o0;
+                    st.noct = (short)(o1 - o0);
+                    st.plane0 = (short)slot;
+                    st.phase = (short)ph;
+                    st.nk = (short)std::min(S, nk_chunk - k);
+                    if (steps_out)
+                        for (int j = 0; j < st.nk; ++j)
+                            steps_out->push_back(std::vector<Pair>(pairs.begin() + (k + j) * 4, pairs.begin() + (k + j) * 4 + 4));
+                    if (stages_out) stages_out->push_back(st);
+                }
+            }
+        }
+        return nsteps;
+    };
+
+    // (OC, S) search.  OC = octets per staged pixel (pixel pitch OC*16 B in the LDS image).  Odd OC maps 16 consecutive pixels
+    // at one octet to 16 distinct 16-byte bank groups (conflict-free fragment reads); even OC costs 2- to 4-way conflicts
+    // on those reads, which the kernels tolerate (LDS reads are not their limit) -- a mild penalty only.
+    int bestOC = 0, bestS = 0, bestSlots = 1, maxp = 4;
+    double bestCost = 1e30;
+    for (size_t at = 0; at < attempts.size() && !bestOC; ++at) {
+    maxp = attempts[at].maxp;
+    const int lds_cap = attempts[at].cap;
+    for (int OC = 1; OC <= 9; ++OC) {
+        int nslots = 1;
+        double sectors = 0;   // 64-byte memory requests of the halo loads of one workgroup
+        for (int list = 0; list < nlists; ++list) {
+            const auto ch = chunks_for(OC, fused ? -1 : list);
+            if (ch.size() >= 2) nslots = 2;
+            for (const auto& c : ch) sectors += 2.0 * h.nhalo * ((c.o1 - c.o0 + 3) / 4);
+        }
+        // the kernel keeps one pixel index per (wave, piece of a chunk) in registers
+        if (((h.nhalo + 64 / OC - 1) / (64 / OC) + nwaves - 1) / nwaves > maxp) continue;
+        for (int S = 1; S <= kStageK; ++S) {
+            const int lds = lds_total(nslots, OC, S, plane_pair);
+            if (lds > lds_cap) continue;
+            int ksteps = 0, nchunks = 0;
+            for (int list = 0; list < nlists; ++list) {
+                int nc = 0;
+                ksteps += plan_list(OC, S, list, nullptr, nullptr, &nc);
+                nchunks += nc;
+            }
+            // executed k-steps (exact) with a barrier/latency charge per stage, a charge per halo chunk load (measured
+            // ~0.35 k-steps on the deep layers) and per 64-byte halo request (halo reloads measured at 8-22 % of a layer)
+            const double cost = (ksteps * (1.0 + 0.30 / S) + 0.35 * nchunks + sectors / 1500.0) * ((OC & 1) ? 1.0 : 1.03);
+            if (nchunks > attempts[at].max_chunks) continue;
+            if (cost < bestCost) { bestCost = cost; bestOC = OC; bestS = S; bestSlots = nslots; }
+        }
+    }
+    }
+    if (!bestOC) { *why = "LDS footprint too large for the split-precision kernel"; return UMX_ERR_INVALID; }
+    if (const char* e = getenv("UMX_PLAN_OVERRIDE")) {   // tuning aid: "layer:OC:S[,layer:OC:S...]" forces a layer's (OC, S)
+        std::string spec(e);
+        size_t pos = 0;
+        while (pos < spec.size()) {
+            const size_t end = spec.find(',', pos);
+            const std::string item = spec.substr(pos, end == std::string::npos ? std::string::npos : end - pos);
+            char nm[64];
+            int oc = 0, ss = 0, mp = 0;
+            const int nf = sscanf(item.c_str(), "%63[^:]:%d:%d:%d", nm, &oc, &ss, &mp);
+            if (nf >= 3 && L.name == nm && oc >= 1 && oc <= 9 && ss >= 1 && ss <= kStageK) {
+                if (nf == 4 && (mp == 4 || (mp == 12 && nt16 <= 5)) && !fused) maxp = mp;
+                int nslots = 1;
+                for (int list = 0; list < nlists; ++list)
+                    if (chunks_for(oc, fused ? -1 : list).size() >= 2) nslots = 2;
+                const int lds = lds_total(nslots, oc, ss, plane_pair);
+                const bool pieces_ok = ((h.nhalo + 64 / oc - 1) / (64 / oc) + nwaves - 1) / nwaves <= maxp;
+                if (lds <= kMaxLdsPerWG && pieces_ok) { bestOC = oc; bestS = ss; bestSlots = nslots; }
+                else fprintf(stderr, "[umx plan] override %s ignored (LDS %d B)\n", item.c_str(), lds);
+            }
+            if (end == std::string::npos) break;
+            pos = end + 1;
+        }
+    }
+    const int OC = bestOC, S = bestS;
+    h.OC = OC;
+    h.inv_OC = 1.f / (float)OC;
+    h.PP = 64 / OC;
+    h.maxp = maxp;
+    h.nact = h.PP * OC;
+    h.ninst = (h.nhalo + h.PP - 1) / h.PP;
+    h.piece_bytes = h.nact * 16;
+    h.inv_oc_q16 = 65536 / OC + 1;
+    h.pix_bytes = OC * 16;
+    h.slot_bytes = h.plane_slots * OC * 16;
+    h.lo_off = bestSlots * h.slot_bytes;
+    h.b_off = 2 * h.lo_off;
+    h.wbuf_bytes = 64 + S * nt16 * 2048;
+    {   // XCD-aware tile order (default on; UMX_XCD_ORDER=0 off, or a comma list of layer-name prefixes to limit it)
+        h.xcd_order = 1;
+        if (const char* e = getenv("UMX_XCD_ORDER")) {
+            std::string spec(e);
+            h.xcd_order = (spec == "1" || spec == "all") ? 1 : 0;
+            size_t pos = 0;
+            while (pos < spec.size()) {
+                const size_t end = spec.find(',', pos);
+                const std::string tok = spec.substr(pos, end == std::string::npos ? std::string::npos : end - pos);
+                if (tok.size() > 1 && L.name.compare(0, tok.size(), tok) == 0) h.xcd_order = 1;
+                if (end == std::string::npos) break;
+                pos = end + 1;
+            }
+        }
+    }
+    // epilogue transpose staging: below weight buffer 1 when it fits there (the constants sit in buffer 1), else above it
+    h.stg_off = epi_bytes <= h.b_off + h.wbuf_bytes ? 0 : h.b_off + 2 * h.wbuf_bytes;
+    h.lds_bytes = std::max(h.b_off + 2 * h.wbuf_bytes, h.stg_off + epi_bytes);
+    if (h.lds_bytes > kMaxLdsPerWG) { *why = "epilogue staging exceeds the LDS budget"; return UMX_ERR_INVALID; }
+
+    std::vector<HStage> stages;
+    std::vector<std::vector<_Float16>> wimg(nlists);   // per stage list: [nblk][stage blocks] halves
+    L.n_ksteps = 0;
+    for (int list = 0; list < nlists; ++list) {
+        h.ph[list].oy_off = L.oy_off[list];
+        h.ph[list].ox_off = L.ox_off[list];
+        h.ph[list].stage0 = (int)stages.size();
+        std::vector<std::vector<Pair>> steps;   // k-steps of this list, each 4 pairs (padded ones have tap = -1)
+        plan_list(OC, S, list, &stages, &steps, nullptr);
+        h.ph[list].nstages = (int)stages.size() - h.ph[list].stage0;
+        L.n_ksteps += (int)steps.size();
+        // weight slab of one N-block: per stage a block = 64-byte header (k-map) + nk * NT * (hi, lo) images
+        size_t per_blk = 0;   // halves
+        for (int si = h.ph[list].stage0; si < (int)stages.size(); ++si) {
+            stages[si].woff = (int)(per_blk / 8);
+            per_blk += 32 + (size_t)stages[si].nk * nt16 * 2 * 512;
+        }
+        h.ph[list].wblk_stride = (int)(per_blk / 8);
+        std::vector<_Float16>& W = wimg[list];
+        W.assign(per_blk * h.nblocks, (_Float16)0.f);
+        for (int nb = 0; nb < h.nblocks; ++nb) {
+            size_t ks = 0;
+            for (int si = h.ph[list].stage0; si < (int)stages.size(); ++si) {
+                const size_t blk = nb * per_blk + (size_t)stages[si].woff * 8;
+                unsigned short* const hdr = reinterpret_cast<unsigned short*>(&W[blk]);
+                for (int j = 0; j < stages[si].nk; ++j, ++ks) {
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const Pair& pr2 = steps[ks][qq];
+                        const auto& tp = L.g[pr2.gi].taps[pr2.ph][pr2.tap < 0 ? 0 : pr2.tap];
+                        // 16-byte LDS slot of (halo pixel at this tap, octet k) in the pixel-major image of halo slot `slot`
+                        const int slot = pr2.slot * (h.plane_slots * OC) + ((tp.first - g.ymin) * h.hw + (tp.second - g.xmin)) * OC + pr2.k;
+                        if (slot < 0 || slot >= bestSlots * h.plane_slots * OC || slot > 65535) {
+                            *why = "internal: k-map slot out of range";
+                            return UMX_ERR_INVALID;
+                        }
+                        hdr[j * 4 + qq] = (unsigned short)slot;
+                    }
+                    for (int n = 0; n < nt16; ++n)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const Pair& pr2 = steps[ks][lane >> 4];
+                            if (pr2.tap < 0) continue;
+                            const Group& G = L.g[pr2.gi];
+                            const int Cp = round_up(G.C, 4);
+                            const int co = nb * nt16 * 16 + n * 16 + (lane & 15);
+                            const size_t base = blk + 32 + (((size_t)j * nt16 + n) * 2) * 512 + (size_t)lane * 8;
+                            for (int e = 0; e < 8; ++e) {
+                                const int c = pr2.oct * 8 + e;
+                                if (c >= G.C || co >= L.Cout) continue;
+                                const float v = G.packed[pr2.ph][((size_t)pr2.tap * Cp + c) * L.Np + co] * wscale;
+                                const _Float16 hi = (_Float16)v;
+                                W[base + e] = hi;
+                                W[base + 512 + e] = (_Float16)(v - (float)hi);
+                            }
+                        }
+                }
+            }
+        }
+    }
+
+    // epilogue constants per N-block: pre_s absorbs 2^-(weight shift + input activation shift), post_* the output's
+    // 2^(activation shift); padded channels get pre_s = post_s = 0 so that they store exact zeros
+    {
+        const float unshift = std::ldexp(1.f, -(L.wshift + act_shift));
+        const float oscale = out_f32 ? 1.f : std::ldexp(1.f, act_shift);
+        const int nb16 = nt16 * 16;
+        // a fused softmax head needs every channel of a pixel in one workgroup; it replaces the fp32 store of this layer
+        const bool fuse_head = head && out_f32 && h.nblocks == 1 && head->head_K <= 4 && !fused && !getenv("UMX_NO_FUSED_HEAD");
+        h.head_K = fuse_head ? head->head_K : 0;
+        const size_t per_blk = fuse_head ? (size_t)(4 + h.head_K) * nb16 + 16 : (size_t)4 * nb16;
+        std::vector<float> ec((size_t)h.nblocks * per_blk, 0.f);
+        for (int nb = 0; nb < h.nblocks; ++nb)
+            for (int i = 0; i < nb16; ++i) {
+                const int c = nb * nb16 + i;
+                if (c >= L.Cout) continue;
+                float* e = &ec[(size_t)nb * per_blk];
+                e[0 * nb16 + i] = (L.pre_s.empty() ? 1.f : L.pre_s[c]) * unshift;
+                e[1 * nb16 + i] = L.pre_b.empty() ? 0.f : L.pre_b[c];
+                e[2 * nb16 + i] = (L.post_s.empty() ? 1.f : L.post_s[c]) * oscale;
+                e[3 * nb16 + i] = (L.post_b.empty() ? 0.f : L.post_b[c]) * oscale;
+                for (int k = 0; k < h.head_K; ++k) e[(4 + k) * nb16 + i] = head->head_w[(size_t)c * head->head_K + k];
+            }
+        if (fuse_head) {
+            float* e = &ec[(size_t)(4 + h.head_K) * nb16];
+            for (int k = 0; k < h.head_K; ++k) {
+                e[k] = head->pre_s.empty() ? 1.f : head->pre_s[k];
+                e[8 + k] = head->pre_b.empty() ? 0.f : head->pre_b[k];
+            }
+        }
+        h.post_affine = 0;
+        for (int nb = 0; nb < h.nblocks; ++nb)
+            for (int i = 0; i < nb16; ++i) {
+                if (nb * nb16 + i >= L.Cout) continue;
+                const float* e = &ec[(size_t)nb * per_blk];
+                if (e[2 * nb16 + i] != 1.f || e[3 * nb16 + i] != 0.f) h.post_affine = 1;
+            }
+        float* d = nullptr;
+        int rc2 = upload(ctx, ec, &d);
+        if (rc2) return rc2;
+        h.econst = reinterpret_cast<const uint4*>(d);
+    }
+    if (getenv("UMX_DEBUG_PLAN"))
+        fprintf(stderr, "[umx plan] %-12s %sNT %d x %d blocks, OC %d x %d halo slot(s), S %d, LDS %d B, k-steps %d, wshift %d\n",
+                L.name.c_str(), fused ? "fused-phase " : "", nt16, h.nblocks, OC, bestSlots, S, h.lds_bytes, L.n_ksteps,
+                L.wshift);
+    h.inv_imgplane = 1.f / (float)h.imgplane;
+    h.inv_hw = 1.f / (float)h.hw;
+    int rc;
+    HStage* d_st = nullptr;
+    {
+        HStage dummy;   // the kernel reads stages[stage0] before looking at nstages
+        memset(&dummy, 0, sizeof dummy);
+        dummy.group = -1;
+        stages.push_back(dummy);
+    }
+    if ((rc = upload_raw(ctx, stages, &d_st))) return rc;
+    h.stages = d_st;
+    for (int list = 0; list < nlists; ++list) {
+        _Float16* d = nullptr;
+        if ((rc = upload_raw(ctx, wimg[list], &d))) return rc;
+        h.ph[list].w = reinterpret_cast<const uint4*>(d);
+    }
+    L.exec_flops = 2.0 * 3.0 * (double)L.n_ksteps * 32.0 * Np16 * L.H * L.W;   // MFMA work incl. split and padding
+    return UMX_OK;
+}
+
+// ---- dense-K plan of the first down-sampling layer (umx_conv_first.hip).  Applies to a pooled single-source convolution of
+// the input tiles (buffer 0) with <= 4 input channels and <= 80 output channels on tiles of >= 16 x 16 pixels whose taps
+// x channel slots fit two k-steps; everything else stays on conv_f16x3.  Reuses plan_f16's weight shift and epilogue
+// constants, so the two kernels differ only in the summation order inside the (now single) k-step.
+int plan_first(umx_ctx* ctx, Launch& L, int act_shift, std::string* why) {
+    (void)why;
+    L.use_first = false;
+    if (getenv("UMX_NO_FIRST")) return UMX_OK;   // A/B aid: the layer stays on conv_f16x3
+    const HConvParams& h = L.hcp;
+    if (L.ngroups != 1 || L.g[0].src != 0 || L.nphase != 1 || !L.pool || h.head_K > 0 || h.nblocks != 1) return UMX_OK;
+    const int Ci = L.g[0].C, P = L.H;
+    if (Ci < 1 || Ci > 4 || P < 16 || L.W != P || (P & (P - 1))) return UMX_OK;
+    const auto& taps = L.g[0].taps[0];
+    const int ntaps = (int)taps.size();
+    int ks = 1;
+    while (ks * ks < ntaps) ks += 2;
+    if (ks * ks != ntaps) return UMX_OK;
+    for (int t = 0; t < ntaps; ++t)
+        if (taps[t].first != t / ks - (ks - 1) / 2 || taps[t].second != t % ks - (ks - 1) / 2) return UMX_OK;
+    const int CW = Ci == 1 ? 1 : Ci == 2 ? 2 : 4, NKS = (ntaps * CW + 31) / 32, NT = h.NT;
+    if (!conv_first_supported(NT, CW, NKS)) return UMX_OK;
+    if (L.g[0].packed[0].empty()) return UMX_OK;
+    FirstParams& f = L.first;
+    memset(&f, 0, sizeof f);
+    f.P = P; f.Ci = Ci; f.ks = ks; f.ntaps = ntaps;
+    f.NT = NT; f.CW = CW; f.NKS = NKS;
+    f.rw_log2 = P >= 64 ? 6 : P >= 32 ? 5 : 4;
+    f.hh = 16 + ks - 1;
+    f.hw = (1 << f.rw_log2) + ks - 1;
+    f.inv_hw = 1.f / (float)f.hw;
+    f.lds_bytes = ((f.hh * f.hw * 4 * CW + 15) & ~15) + 4 * NT * 16 * (int)sizeof(float);
+    f.in_scale = std::ldexp(1.f, act_shift);
+    f.act = L.act;
+    f.post_affine = h.post_affine;
+    f.econst = reinterpret_cast<const float*>(h.econst);
+    f.Cds = h.Cds;
+    f.outS = P / 2;
+    // MFMA A-fragments: lane (q = lane >> 4, row = lane & 15) holds weight[channel n*16 + row][k = 32 s + 8 q + e], e = 0..7,
+    // k = tap * CW + c
+    const float wscale = std::ldexp(1.f, L.wshift);
+    const int Cp = round_up(Ci, 4);
+    std::vector<_Float16> W((size_t)NKS * NT * 2 * 512, (_Float16)0.f);
+    for (int s = 0; s < NKS; ++s)
+        for (int n = 0; n < NT; ++n)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int kk = 32 * s + 8 * (lane >> 4) + e, t = kk / CW, c = kk % CW, co = n * 16 + (lane & 15);
+                    if (t >= ntaps || c >= Ci || co >= L.Cout) continue;
+                    const float v = L.g[0].packed[0][((size_t)t * Cp + c) * L.Np + co] * wscale;
+                    const _Float16 hi = (_Float16)v;
+                    const size_t base = (((size_t)s * NT + n) * 2) * 512 + (size_t)lane * 8 + e;
+                    W[base] = hi;
+                    W[base + 512] = (_Float16)(v - (float)hi);
+                }
+    _Float16* d = nullptr;
+    int rc = upload_raw(ctx, W, &d);
+    if (rc) return rc;
+    f.w = reinterpret_cast<const uint4*>(d);
+    L.use_first = true;
+    if (getenv("UMX_DEBUG_PLAN"))
+        fprintf(stderr, "[umx plan] %-12s dense-K first layer: NT %d, %d channel slot(s) x %d taps = %d k-step(s), region 16 x %d, LDS %d B\n",
+                L.name.c_str(), NT, CW, ntaps, NKS, 1 << f.rw_log2, f.lds_bytes);
+    return UMX_OK;
+}
+
+}  // namespace umx
