@@ -26,6 +26,15 @@ namespace umx {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+template <int I> struct IC { static constexpr int value = I; };
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {   // compile-time loop: the body sees its index as a constant expression
+    if constexpr (B < E) {
+        f(IC<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
 #define UMX_GLDS16(gptr, lptr)                                                                        \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),           \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
@@ -383,69 +392,84 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
     if constexpr (NPH == 1) {
         if (p.head_K > 0) {
             // fused top layer (reference UnMicst1-5.py:212-222,236-237 / UnMicst.py:167-171,186): 1x1 conv over this pixel's
-            // channels -- 4*NT of them in this lane, the rest in the lanes li+16, li+32, li+48 -- BN affine, softmax
+            // channels, BN affine, softmax -- the 1x1 conv ON THE MATRIX CORES: the lane's 4 channels of N-tiles (2s, 2s+1)
+            // are exactly the 8 k-elements lane group q feeds at head k-step s, so the activations go from the accumulators
+            // into B-fragments without leaving the lane (as (hi, lo) binary16 pairs, the same 3-product arithmetic as the
+            // convolutions).  The head's A-fragment has the classes in rows 0..3; shifted down by 4 m rows (DPP row_shr, zeros
+            // shifted in) it puts M-tile m's logits into lane group m, so ONE accumulator collects the four M-tiles of a wave
+            // and every lane ends with all classes of one pixel: no cross-lane reduction, one softmax per lane.
             const int K = p.head_K;
-            const float* const hsb = ec + (4 + K) * (NT * 16);   // [scale x 8 | bias x 8]
-            // sum over the 4 lane groups holding one pixel's channels (lanes li, li+16, li+32, li+48).  ds_bpermute based:
-            // v_permlane16/32_swap would avoid the LDS crossbar, but on ROCm 7.2 the builtin's second result came back
-            // equal to the first when both operands are the same value (probed on MI355X), so it is not used.
-            auto sum4 = [](float x) {
-                x += __shfl_xor(x, 16);
-                return x + __shfl_xor(x, 32);
-            };
-            float mine[4] = {0.f, 0.f, 0.f, 0.f};   // logits of the pixel this lane finishes: pixel li of M-tile q
+            constexpr int NS2 = (NT + 1) / 2;
+            const float* const hsb = ec + (4 + K) * (NT * 16);   // [scale x 8 | bias x 8] (the scale carries the 2^-hs of the packed head weights)
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 Hh[NS2], Hl[NS2];
 #pragma unroll
-            for (int m = 0; m < KMT; ++m) {
+            for (int s2 = 0; s2 < NS2; ++s2) {
+                Hh[s2] = *reinterpret_cast<const u32x4*>(p.head_frag + (s2 * 2 + 0) * 64 + lane);
+                Hl[s2] = *reinterpret_cast<const u32x4*>(p.head_frag + (s2 * 2 + 1) * 64 + lane);
+            }
+            f32x4 lg = (f32x4){0.f, 0.f, 0.f, 0.f};
+            static_for<0, KMT>([&](auto MC) {
+                constexpr int m = decltype(MC)::value;
                 float res[NT][4];
-                arith(accs[0][m], res, kNoTrack);
-                float lg[4] = {0.f, 0.f, 0.f, 0.f};
+                arith(accs[0][m], res, kTrack);   // (range tracked: the head's operands are binary16 pairs)
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
+                for (int s2 = 0; s2 < NS2; ++s2) {
+                    h8 bh, bl;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (k < K) {
-                            const float4 w = ec4[(4 + k) * (NT * 4) + n * 4 + q];
-                            lg[k] += res[n][0] * w.x + res[n][1] * w.y + res[n][2] * w.z + res[n][3] * w.w;
-                        }
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (k < K) {
-                        const float t = sum4(lg[k]);
-                        if ((m & 3) == q) mine[k] = t;
+                    for (int j = 0; j < 8; ++j) {
+                        const int nt = 2 * s2 + (j >> 2);
+                        const float t = nt < NT ? res[nt < NT ? nt : 0][j & 3] : 0.f;
+                        bh[j] = (_Float16)t;
+                        bl[j] = (_Float16)(t - (float)bh[j]);
                     }
-                if ((m & 3) == 3 || m == KMT - 1) {   // every lane group finishes one of the last (up to) 4 M-tiles
+                    u32x4 ah = Hh[s2], al = Hl[s2];
+                    if constexpr ((m & 3) != 0) {
+                        constexpr int ctrl = 0x110 + 4 * (m & 3);   // row_shr:4m, bound_ctrl: rows shifted in are zero
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            ah[d] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ah[d], ctrl, 0xF, 0xF, true);
+                            al[d] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)al[d], ctrl, 0xF, 0xF, true);
+                        }
+                    }
+                    const h8 wh = __builtin_bit_cast(h8, ah), wl = __builtin_bit_cast(h8, al);
+                    lg = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl, lg, 0, 0, 0);
+                    lg = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh, lg, 0, 0, 0);
+                    lg = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh, lg, 0, 0, 0);
+                }
+                if ((m & 3) == 3 || m == KMT - 1) {   // lane group q holds the logits of pixel li of M-tile (m & ~3) + q
                     const int mq = (m & ~3) + q;
                     const int t = wave * KMT + mq;
                     const int ig = t >> p.th_log2, ty = t & (TH - 1);
                     const int img = img0 + ig * p.nimg_m + (li >> p.twm_log2);
                     if (mq < KMT && img < p.B) {
-                        float mx = -INFINITY;
+                        float e[4], mx = -INFINITY;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (k < K) {
-                                mine[k] = mine[k] * hsb[k] + hsb[8 + k];
-                                mx = fmaxf(mx, mine[k]);
-                            }
+                        for (int k = 0; k < 4; ++k) {
+                            e[k] = k < K ? lg[k] * hsb[k] + hsb[8 + k] : -INFINITY;
+                            mx = fmaxf(mx, e[k]);
+                        }
                         float sum = 0.f;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (k < K) {
-                                mine[k] = expf(mine[k] - mx);
-                                sum += mine[k];
-                            }
-                        const float inv = 1.f / sum;
+                        for (int k = 0; k < 4; ++k) {
+                            e[k] = __expf(e[k] - mx);
+                            sum += e[k];
+                        }
+                        const float inv = __builtin_amdgcn_rcpf(sum);
                         float* const d = p.probs + ((long)(img * p.outH + y0 + ty) * p.outW + x0 + (li & (TWm - 1))) * K;
                         if (K == 3) {   // one 12-byte store per pixel instead of three 4-byte ones
                             struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
-                            *reinterpret_cast<F3*>(d) = F3{mine[0] * inv, mine[1] * inv, mine[2] * inv};
+                            *reinterpret_cast<F3*>(d) = F3{e[0] * inv, e[1] * inv, e[2] * inv};
                         } else {
 #pragma unroll
                             for (int k = 0; k < 4; ++k)
-                                if (k < K) d[k] = mine[k] * inv;
+                                if (k < K) d[k] = e[k] * inv;
                         }
                     }
+                    lg = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
-            }
+            });
+            if (vmax >= 0x476a6000u) atomicOr(p.overflow_flag, 1);   // binary16 range exceeded in front of the head
             return;
         }
         if (p.dst_f32) {   // (the planner never pairs fp32 output with the fused transposed convolution)

@@ -115,6 +115,7 @@ struct HConvParams {
     float* dst_f32;              // non-NULL: write fp32 NHWC [..,Cout] instead of the (hi, lo) pair
     float* probs;                // head_K > 0: fused 1x1 conv + BN affine + softmax head, probabilities NHWC [..,head_K]
     int head_K;                  // (needs nblocks == 1: every channel of a pixel in one workgroup)
+    const uint4* head_frag;      // the 1x1 head as MFMA A-fragments: [ceil(NT/2) k-steps][hi | lo][64 lanes] x 16 B, rows = classes
     int outH, outW, pool;
     const uint4* econst;         // epilogue constants per N-block: [pre_s | pre_b | post_s | post_b] x NT*16 floats
                                  // (+ with a fused head: head_K rows of NT*16 head weights, then [scale | bias] x 8);

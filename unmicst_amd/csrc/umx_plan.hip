@@ -343,11 +343,43 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                 for (int k = 0; k < h.head_K; ++k) e[(4 + k) * nb16 + i] = head->head_w[(size_t)c * head->head_K + k];
             }
         if (fuse_head) {
+            // The 1x1 head runs on the matrix cores (conv_f16x3's fused-head epilogue): its weights as MFMA A-fragments, rows =
+            // classes, scaled by 2^hs so that their lo parts stay normal binary16 numbers; the head's BN scale absorbs 2^-hs.
+            // k order of head k-step s2: lane group q, element j <-> channel (2 s2 + (j >> 2)) * 16 + 4 q + (j & 3) -- the four
+            // accumulator values of N-tiles 2 s2 and 2 s2 + 1 a lane holds, so activations never leave their lane.
+            float hmax = 0.f;
+            for (float v : head->head_w) hmax = std::max(hmax, std::fabs(v));
+            int hs = 0;
+            if (hmax > 0.f && std::isfinite(hmax)) {
+                int e2;
+                std::frexp(hmax, &e2);
+                hs = std::max(-24, std::min(30, 14 - e2));
+            }
+            const float hscale = std::ldexp(1.f, hs);
             float* e = &ec[(size_t)(4 + h.head_K) * nb16];
             for (int k = 0; k < h.head_K; ++k) {
-                e[k] = head->pre_s.empty() ? 1.f : head->pre_s[k];
+                e[k] = (head->pre_s.empty() ? 1.f : head->pre_s[k]) * std::ldexp(1.f, -hs);
                 e[8 + k] = head->pre_b.empty() ? 0.f : head->pre_b[k];
             }
+            const int ns2 = (nt16 + 1) / 2;
+            std::vector<_Float16> HF((size_t)ns2 * 2 * 512, (_Float16)0.f);
+            for (int s2 = 0; s2 < ns2; ++s2)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int row = lane & 15, qq = lane >> 4;
+                    if (row >= h.head_K) continue;
+                    for (int j = 0; j < 8; ++j) {
+                        const int nt = 2 * s2 + (j >> 2), c = nt * 16 + 4 * qq + (j & 3);
+                        if (nt >= nt16 || c >= L.Cout) continue;
+                        const float v = head->head_w[(size_t)c * head->head_K + row] * hscale;
+                        const _Float16 hi = (_Float16)v;
+                        HF[((size_t)s2 * 2) * 512 + (size_t)lane * 8 + j] = hi;
+                        HF[((size_t)s2 * 2 + 1) * 512 + (size_t)lane * 8 + j] = (_Float16)(v - (float)hi);
+                    }
+                }
+            _Float16* dh = nullptr;
+            int rc3 = upload_raw(ctx, HF, &dh);
+            if (rc3) return rc3;
+            h.head_frag = reinterpret_cast<const uint4*>(dh);
         }
         h.post_affine = 0;
         for (int nb = 0; nb < h.nblocks; ++nb)
