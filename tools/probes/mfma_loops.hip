@@ -1,0 +1,199 @@
+// Bare-loop probes (gfx950, MI355X), LDS-fed operands, random binary16 data, fp32 accumulate:
+//   shape A/B   v_mfma_f32_16x16x32_f16 vs v_mfma_f32_32x32x16_f16 at the SAME 64 x 64 output tile per wave and the same
+//               ds_read_b128 traffic per K = 32 (cdna_hip_programming.md section 5.4 rule 28 / MI355X_MICROARCH.md DVFS item 7)
+//   loop shapes the inner loop of conv_f16x3<9, 4, 1> (4 pixel tiles x 9 channel tiles, 3 split-precision products: 26 fragment
+//               reads per 108 MFMAs) against the inner loop a Winograd F(2x2, 3x3) kernel would run with the output transform
+//               in-lane (16 positions x 1 patch tile x 2 channel tiles: 96 fragment reads per 96 MFMAs)
+// Each variant: grid = 256 CUs x WGS workgroups of 256 threads, ITERS loop trips, timed with HIP events over REPS launches
+// after a 2 s warm-up; in-kernel clock = d(s_memtime) / d(s_memrealtime) * 100 MHz of block 0.
+// build: hipcc -O3 --offload-arch=gfx950 tools/probes/mfma_loops.hip -o /tmp/mfma_loops
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int LDS_HALVES = 32 * 1024;   // 64 KB of operands
+
+__device__ __forceinline__ void fill_lds(_Float16* lds, const _Float16* src) {
+    for (int i = threadIdx.x; i < LDS_HALVES / 8; i += blockDim.x)
+        reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(src)[i + blockIdx.x % 7 * 64];
+    __syncthreads();
+}
+struct Stamp { long long c0, r0; };
+__device__ __forceinline__ Stamp stamp() { return {(long long)__builtin_amdgcn_s_memtime(), (long long)__builtin_amdgcn_s_memrealtime()}; }
+
+// ---- 16x16x32: 4 x 4 tiles per wave
+__global__ void __launch_bounds__(256) k_16(const _Float16* src, float* out, long long* clk, int iters) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    fill_lds(lds, src);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 acc[4][4];
+    for (int m = 0; m < 4; ++m) for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0, 0, 0, 0};
+    const Stamp s0 = stamp();
+    for (int it = 0; it < iters; ++it) {
+        const _Float16* base = lds + ((it * 8 + wave * 2) & 31) * 512 + lane * 8;   // walks the buffer, 1 KiB per fragment
+        h8 a[4], b[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const h8*>(base + m * 512);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const h8*>(base + (4 + n) * 512);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+    const Stamp s1 = stamp();
+    float s = 0;
+    for (int m = 0; m < 4; ++m) for (int n = 0; n < 4; ++n) s += acc[m][n][0] + acc[m][n][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = s1.c0 - s0.c0; clk[1] = s1.r0 - s0.r0; }
+}
+// ---- 32x32x16: 2 x 2 tiles per wave, two K = 16 sub-steps per trip
+__global__ void __launch_bounds__(256) k_32(const _Float16* src, float* out, long long* clk, int iters) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    fill_lds(lds, src);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x16 acc[2][2];
+    for (int m = 0; m < 2; ++m) for (int n = 0; n < 2; ++n) for (int r = 0; r < 16; ++r) acc[m][n][r] = 0;
+    const Stamp s0 = stamp();
+    for (int it = 0; it < iters; ++it) {
+        const _Float16* base = lds + ((it * 8 + wave * 2) & 31) * 512 + lane * 8;
+        h8 a[2][2], b[2][2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                a[k][m] = *reinterpret_cast<const h8*>(base + (k * 2 + m) * 512);
+                b[k][m] = *reinterpret_cast<const h8*>(base + (4 + k * 2 + m) * 512);
+            }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[k][m], b[k][n], acc[m][n], 0, 0, 0);
+    }
+    const Stamp s1 = stamp();
+    float s = 0;
+    for (int m = 0; m < 2; ++m) for (int n = 0; n < 2; ++n) s += acc[m][n][0] + acc[m][n][15];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = s1.c0 - s0.c0; clk[1] = s1.r0 - s0.r0; }
+}
+// ---- conv_f16x3<9, 4, 1>-shaped trip: 4 pixel tiles (hi, lo) x 9 channel tiles (hi, lo), 3 products each
+__global__ void __launch_bounds__(256, 2) k_conv9(const _Float16* src, float* out, long long* clk, int iters) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    fill_lds(lds, src);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 acc[4][9];
+    for (int m = 0; m < 4; ++m) for (int n = 0; n < 9; ++n) acc[m][n] = (f32x4){0, 0, 0, 0};
+    const Stamp s0 = stamp();
+    for (int it = 0; it < iters; ++it) {
+        const _Float16* base = lds + ((it * 26 + wave * 8) & 31) * 512 + lane * 8;
+        h8 ah[4], al[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            ah[m] = *reinterpret_cast<const h8*>(base + (2 * m) * 512);
+            al[m] = *reinterpret_cast<const h8*>(base + (2 * m + 1) * 512);
+        }
+#pragma unroll
+        for (int n = 0; n < 9; ++n) {
+            __builtin_amdgcn_iglp_opt(0);
+            const h8 bh = *reinterpret_cast<const h8*>(base + (8 + 2 * n) * 512);
+            const h8 bl = *reinterpret_cast<const h8*>(base + (9 + 2 * n) * 512);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                f32x4 c = acc[m][n];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[m], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[m], c, 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[m], c, 0, 0, 0);
+            }
+        }
+    }
+    const Stamp s1 = stamp();
+    float s = 0;
+    for (int m = 0; m < 4; ++m) for (int n = 0; n < 9; ++n) s += acc[m][n][0] + acc[m][n][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = s1.c0 - s0.c0; clk[1] = s1.r0 - s0.r0; }
+}
+// ---- Winograd F(2x2, 3x3)-shaped trip: 16 positions x (1 patch tile (hi, lo) x 2 channel tiles (hi, lo)), 3 products each
+__global__ void __launch_bounds__(256, 2) k_wino(const _Float16* src, float* out, long long* clk, int iters) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    fill_lds(lds, src);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 acc[16][2];
+    for (int p = 0; p < 16; ++p) for (int n = 0; n < 2; ++n) acc[p][n] = (f32x4){0, 0, 0, 0};
+    const Stamp s0 = stamp();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            __builtin_amdgcn_iglp_opt(0);
+            const _Float16* bp = lds + ((it * 6 + wave * 8 + p * 6) & 31) * 512 + lane * 8;
+            const h8 vh = *reinterpret_cast<const h8*>(bp), vl = *reinterpret_cast<const h8*>(bp + 512);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const h8 uh = *reinterpret_cast<const h8*>(bp + (2 + 2 * n) * 512);
+                const h8 ul = *reinterpret_cast<const h8*>(bp + (3 + 2 * n) * 512);
+                f32x4 c = acc[p][n];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh, vl, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ul, vh, c, 0, 0, 0);
+                acc[p][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh, vh, c, 0, 0, 0);
+            }
+        }
+    }
+    const Stamp s1 = stamp();
+    float s = 0;
+    for (int p = 0; p < 16; ++p) for (int n = 0; n < 2; ++n) s += acc[p][n][0] + acc[p][n][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = s1.c0 - s0.c0; clk[1] = s1.r0 - s0.r0; }
+}
+
+template <typename K>
+static void run(const char* name, K kern, int wgs_per_cu, int iters, double mfma_per_trip_per_wave, double flop_per_mfma,
+                const _Float16* src, float* out, long long* clk) {
+    const int grid = 256 * wgs_per_cu;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_HALVES * 2);
+    // warm-up ~2 s so that the clock the chip holds under this load has settled
+    hipEventRecord(e0);
+    float ms = 0;
+    int warm = 0;
+    do {
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_HALVES * 2, 0, src, out, clk, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+        warm += 20;
+    } while (ms < 2000.f);
+    const int reps = 50;
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_HALVES * 2, 0, src, out, clk, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    long long c[2];
+    hipMemcpy(c, clk, sizeof c, hipMemcpyDeviceToHost);
+    const double mfmas = (double)grid * 4 * iters * mfma_per_trip_per_wave;
+    const double tflops = mfmas * flop_per_mfma * reps / (ms * 1e-3) / 1e12;
+    const double cyc_per_mfma = (double)c[0] / ((double)iters * mfma_per_trip_per_wave);
+    printf("%-28s %d WG/CU  %8.3f ms/launch  %8.1f TFLOP/s issued  wave cycles per MFMA %6.2f  in-kernel clock %.2f GHz\n", name,
+           wgs_per_cu, ms / reps, tflops, cyc_per_mfma, (double)c[0] / (double)c[1] * 0.1);
+}
+
+int main() {
+    std::vector<_Float16> h(LDS_HALVES + 8 * 512);
+    srand(1234);
+    for (auto& v : h) v = (_Float16)((rand() / (float)RAND_MAX) * 2.f - 1.f);
+    _Float16* src; float* out; long long* clk;
+    hipMalloc(&src, h.size() * 2); hipMalloc(&out, 1024 * 256 * 4); hipMalloc(&clk, 64);
+    hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    const int iters = 4000;
+    for (int wgs = 1; wgs <= 2; ++wgs) {
+        run("mfma 16x16x32, 64x64 tile", k_16, wgs, iters, 16, 2.0 * 16 * 16 * 32, src, out, clk);
+        run("mfma 32x32x16, 64x64 tile", k_32, wgs, iters, 8, 2.0 * 32 * 32 * 16, src, out, clk);
+    }
+    for (int wgs = 1; wgs <= 2; ++wgs) {
+        run("conv_f16x3<9,4,1>-shaped", k_conv9, wgs, iters / 4, 108, 2.0 * 16 * 16 * 32, src, out, clk);
+        run("winograd F(2x2,3x3)-shaped", k_wino, wgs, iters / 4, 96, 2.0 * 16 * 16 * 32, src, out, clk);
+    }
+    return 0;
+}

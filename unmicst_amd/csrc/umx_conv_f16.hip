@@ -332,17 +332,8 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
     const float4* const ec4 = reinterpret_cast<const float4*>(ec);
 
     // fp32 output: direct 16-byte stores (64 contiguous bytes per pixel and N-tile).
-    // (hi, lo) output: through a per-wave LDS transpose -- each lane drops its 4 channels (8 bytes) into a [pixel][channel]
-    // row image, then the wave stores whole rows, 16 bytes per lane, consecutive lanes consecutive addresses (pixels
-    // that are neighbours in x are contiguous in NHWC): full-line writes instead of 8-byte fragments.  The staging area
-    // (p.stg_off, chosen by the planner) stays clear of weight buffer 1, so the constants stay readable and every wave
-    // runs arithmetic -> transpose -> stores one M-tile at a time on its own: accumulators die as they are consumed.
-    constexpr int ROWS = NPH == 4 ? 32 : 16;   // staged pixel rows per flush
-    constexpr int PITCH = NT * 32 + 16;   // bytes per staged pixel row of one plane
-    constexpr int PLANE = ROWS * PITCH;
-    constexpr int UR = NT * 2;            // 16-byte units per staged row
-    unsigned char* const stg = smem + p.stg_off + wave * (2 * PLANE);
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    // (hi, lo) output: straight from registers in 16-byte units (below); no LDS staging, every wave runs arithmetic ->
+    // exchange -> stores on its own and accumulators die as they are consumed.
 
     // One M-tile of one phase: (acc * pre_s + pre_b) -> activation -> [* post_s + post_b].  Nothing in the per-value code may
     // branch: hipcc does not unswitch loops on p.act / p.post_affine, it tests them per value (5 VALU + 3 SALU + 4 branches
@@ -501,163 +492,157 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
         }
     }
 
-    // Destination addressing, in binary16 elements from the plane's start: image * dImg + pixel * dPix + octet * dOct --
-    // NHWC: (Cds, 8); octet-planar (per image [octet][pixel][8]): (8, outH*outW*8).  In the planar form a wave's lanes walk
-    // pixels first (16 consecutive pixels of one octet = 256 contiguous bytes), in NHWC octets first (one pixel's channels).
+    // ---- (hi, lo) output.  A lane holds 4 consecutive channels (8 bytes per plane) of one pixel; the unit of both
+    // destination layouts is (pixel, octet) = 16 bytes: element offset image * dImg + pixel * dPix + octet * dOct with
+    // (dPix, dOct) = (Cds, 8) for NHWC and (8, outH*outW*8) for octet-planar ([octet][pixel][8] per image).
+    // v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of another.  Fed with two result
+    // sets A and B of the SAME N-tile (two sets of pixels), it leaves lane group q with all 8 channels of octet
+    // 2n + (q >> 1) -- of A's pixel for q even, of B's pixel for q odd: every lane stores one 16-byte unit per plane and
+    // N-tile, 16 consecutive pixels of an octet per lane row (256 contiguous bytes in the planar form), with no LDS
+    // transpose, no staging area and no waits in between.
     const bool dpl = p.dst_planar != 0;
-    const long dImg = (long)p.Cds * p.outH * p.outW;
+    const int dImg = p.Cds * p.outH * p.outW;
     const int dPix = dpl ? 8 : p.Cds;
     const int dOct = dpl ? p.outH * p.outW * 8 : 8;
-    // staged rows [0, R) -> global; elem_of(row) gives the element offset of the row's pixel (octet 0) or -1
-    auto flush = [&](auto RC, auto elem_of) {
-        constexpr int R = decltype(RC)::value;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        int ln = lane;
-        asm volatile("" : "+v"(ln));   // the unit addressing is computed here, not hoisted across the epilogue arithmetic
-#pragma unroll
-        for (int k = 0; k < (ROWS * UR + 63) / 64; ++k) {
-            const int u = ln + 64 * k;
-            const int row = dpl ? (u & (R - 1)) : u / UR, cu = dpl ? u / R : u - (u / UR) * UR;
-            const int c0 = nblk * (NT * 16) + cu * 8;
-            if (row < R && cu < UR && c0 < p.Cds) {
-                const long e0 = elem_of(row);
-                if (e0 >= 0) {
-                    const uint4 vh = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16);
-                    const uint4 vl = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16 + PLANE);
-                    const long e = e0 + (long)(c0 >> 3) * dOct;
-                    *reinterpret_cast<uint4*>(p.dst_hi + e) = vh;
-                    *reinterpret_cast<uint4*>(p.dst_lo + e) = vl;
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staged rows are in registers before the next tile overwrites
+    const int noct = p.Cds >> 3;
+    const int oct_q = q >> 1;            // octet (of the N-tile's two) this lane stores
+    const bool setB = (q & 1) != 0;      // ... and whose pixel: set A (q even) or set B (q odd)
+    // wave-uniform bases: this workgroup's first image; a lane adds a 32-bit byte offset (the planner keeps a tile's images
+    // and every (pixel, octet) offset inside one image far below 2^31)
+    unsigned char* const bhi = reinterpret_cast<unsigned char*>(p.dst_hi + (size_t)img0 * dImg);
+    unsigned char* const blo = reinterpret_cast<unsigned char*>(p.dst_lo + (size_t)img0 * dImg);
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    auto pack_split = [](float v0, float v1, unsigned& hw, unsigned& lw) {
+        h2 h, l;
+        h[0] = (_Float16)v0; h[1] = (_Float16)v1;
+        l[0] = (_Float16)(v0 - (float)h[0]); l[1] = (_Float16)(v1 - (float)h[1]);
+        hw = __builtin_bit_cast(unsigned, h);
+        lw = __builtin_bit_cast(unsigned, l);
     };
-    // the same for tiles whose staged rows are the pixels of ONE image row segment (tile width 16: every full-resolution
-    // layer): the segment's address is wave-uniform (scalar), a lane only adds a 32-bit element offset
-    auto flush_row = [&](auto RC, long seg_elem /* element offset of the segment's first pixel, or -1 */, auto xo) {
-        constexpr int R = decltype(RC)::value;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (seg_elem >= 0) {
-            _Float16* const bh = p.dst_hi + seg_elem;
-            _Float16* const bl = p.dst_lo + seg_elem;
-            int ln = lane;
-            asm volatile("" : "+v"(ln));   // (as in flush)
-#pragma unroll
-            for (int k = 0; k < (ROWS * UR + 63) / 64; ++k) {
-                const int u = ln + 64 * k;
-                const int row = dpl ? (u & (R - 1)) : u / UR, cu = dpl ? u / R : u - (u / UR) * UR;
-                const int c0 = nblk * (NT * 16) + cu * 8;
-                if (row < R && cu < UR && c0 < p.Cds) {
-                    const int off = (int)(__umul24(xo(row), dPix) + __umul24(c0 >> 3, dOct));   // both factors < 2^24 (planner)
-                    const uint4 vh = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16);
-                    const uint4 vl = *reinterpret_cast<const uint4*>(stg + row * PITCH + cu * 16 + PLANE);
-                    *reinterpret_cast<uint4*>(bh + off) = vh;
-                    *reinterpret_cast<uint4*>(bl + off) = vl;
-                }
-            }
+    // One value: (acc * pre_s + pre_b) -> activation -> [* post_s + post_b], range-tracked (as arith_v above, one N-tile at a
+    // time so that the results of an N-tile leave for memory before the next one is touched: a whole M-tile pair of
+    // results live at once spilled 69 registers in the 9-tile kernel)
+    struct EC { float ps[4], pb[4], qs[4], qb[4]; };
+    auto load_ec = [&](int n, auto POST) {
+        EC e;
+        const float4 ps = ec4[0 * NT * 4 + n * 4 + q], pb = ec4[1 * NT * 4 + n * 4 + q];
+        e.ps[0] = ps.x; e.ps[1] = ps.y; e.ps[2] = ps.z; e.ps[3] = ps.w;
+        e.pb[0] = pb.x; e.pb[1] = pb.y; e.pb[2] = pb.z; e.pb[3] = pb.w;
+        if constexpr (decltype(POST)::value) {
+            const float4 qs = ec4[2 * NT * 4 + n * 4 + q], qb = ec4[3 * NT * 4 + n * 4 + q];
+            e.qs[0] = qs.x; e.qs[1] = qs.y; e.qs[2] = qs.z; e.qs[3] = qs.w;
+            e.qb[0] = qb.x; e.qb[1] = qb.y; e.qb[2] = qb.z; e.qb[3] = qb.w;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        return e;
     };
-    auto elem_at = [&](int img, int y, int x) -> long { return (long)img * dImg + ((long)y * p.outW + x) * dPix; };
-    constexpr std::integral_constant<int, 8> kR8{};
-    constexpr std::integral_constant<int, 16> kR16{};
-    constexpr std::integral_constant<int, 32> kR32{};
-#define UMX_PUT(row, A) /* this lane's 4 channels of every N-tile of result row A -> staged row */ \
-    _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                        \
-        h4 hi, lo;                                                                                           \
-        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                      \
-            hi[r] = (_Float16)(A)[n][r];                                                                     \
-            lo[r] = (_Float16)((A)[n][r] - (float)hi[r]);                                                    \
-        }                                                                                                    \
-        unsigned char* const d = stg + (row) * PITCH + (n * 16 + 4 * q) * 2;                                 \
-        *reinterpret_cast<h4*>(d) = hi;                                                                      \
-        *reinterpret_cast<h4*>(d + PLANE) = lo;                                                              \
-    }
+    auto act1 = [&](float a, const EC& e, int r, auto POST) {
+        float v = a * e.ps[r] + e.pb[r];
+        v = __builtin_amdgcn_fmed3f(v, v * slope, INFINITY);
+        if constexpr (decltype(POST)::value) v = v * e.qs[r] + e.qb[r];
+        return v;
+    };
+    // this lane's 16-byte unit of N-tile n after the exchange of sets (a, b) -> both planes
+    auto store_unit = [&](int n, const float (&a)[4], const float (&b)[4], int off, bool ok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            vmax = max(vmax, max(__float_as_uint(a[r]) & 0x7fffffffu, __float_as_uint(b[r]) & 0x7fffffffu));
+        unsigned ah0, ah1, al0, al1, bh0, bh1, bl0, bl1;
+        pack_split(a[0], a[1], ah0, al0);
+        pack_split(a[2], a[3], ah1, al1);
+        pack_split(b[0], b[1], bh0, bl0);
+        pack_split(b[2], b[3], bh1, bl1);
+        // (every lane takes part in the exchange: never under a divergent branch)
+        const auto h0 = __builtin_amdgcn_permlane16_swap(ah0, bh0, false, false);
+        const auto h1 = __builtin_amdgcn_permlane16_swap(ah1, bh1, false, false);
+        const auto l0 = __builtin_amdgcn_permlane16_swap(al0, bl0, false, false);
+        const auto l1 = __builtin_amdgcn_permlane16_swap(al1, bl1, false, false);
+        const int oct = (nblk * NT + n) * 2 + oct_q;
+        if (ok && oct < noct) {
+            const unsigned o = (unsigned)(off + oct * dOct) * 2u;
+            *reinterpret_cast<uint4*>(bhi + o) = make_uint4(h0[0], h1[0], h0[1], h1[1]);
+            *reinterpret_cast<uint4*>(blo + o) = make_uint4(l0[0], l1[0], l0[1], l1[1]);
+        }
+    };
+    // accumulator sets A, B (two sets of pixels) -> stores; `off`: element offset of THIS lane's pixel (set A's for q even,
+    // set B's for q odd) relative to image img0, octet 0; `ok`: the lane's pixel exists
+    auto emit_t = [&](const f32x4 (&A)[NT], const f32x4 (&B)[NT], int off, bool ok, auto POST) {
+        if constexpr (decltype(POST)::value) asm volatile("; epilogue stores, second affine");
+        else asm volatile("; epilogue stores");
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const EC e = load_ec(n, POST);
+            float a[4], b[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = act1(A[n][r], e, r, POST); b[r] = act1(B[n][r], e, r, POST); }
+            store_unit(n, a, b, off, ok);
+            __builtin_amdgcn_sched_barrier(0);   // one N-tile at a time
+        }
+    };
+    auto emit = [&](const f32x4 (&A)[NT], const f32x4 (&B)[NT], int off, bool ok) {
+        if (p.post_affine) emit_t(A, B, off, ok, std::true_type{});
+        else emit_t(A, B, off, ok, std::false_type{});
+    };
+    // the same with a fused 2 x 2 max-pool: set A = the pooled row of M-tiles (R0, R1), set B of (R2, R3); rows are vertical
+    // neighbours, pixels li, li^1 horizontal ones; both lanes of a pixel pair hold the pooled value, the even one stores it
+    auto emit_pool_t = [&](const f32x4 (&R0)[NT], const f32x4 (&R1)[NT], const f32x4 (&R2)[NT], const f32x4 (&R3)[NT], int off,
+                           bool ok, auto POST) {
+        if constexpr (decltype(POST)::value) asm volatile("; pooled epilogue stores, second affine");
+        else asm volatile("; pooled epilogue stores");
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const EC e = load_ec(n, POST);
+            float a[4], b[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float va = fmaxf(act1(R0[n][r], e, r, POST), act1(R1[n][r], e, r, POST));
+                const float vb = fmaxf(act1(R2[n][r], e, r, POST), act1(R3[n][r], e, r, POST));
+                const float sa = __builtin_bit_cast(
+                    float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, va), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false));
+                const float sb = __builtin_bit_cast(
+                    float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, vb), 0xB1, 0xF, 0xF, false));
+                a[r] = fmaxf(va, sa);
+                b[r] = fmaxf(vb, sb);
+            }
+            store_unit(n, a, b, off, ok);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // element offset (relative to image img0) of the image M-tile t's column i belongs to, and the tile-relative (y, x) of
+    // that pixel; -1: no such image
+    auto pix_off = [&](int t, int i, int& y_tile, int& x_tile) {
+        const int ig = t >> p.th_log2;
+        y_tile = y0 + (t & (TH - 1));
+        x_tile = x0 + (i & (TWm - 1));
+        const int irel = ig * p.nimg_m + (i >> p.twm_log2);
+        return img0 + irel < p.B ? irel * dImg : -1;
+    };
     if constexpr (NPH == 4) {
-        // output row 2y+pu of M-tile row y: its 32 pixels 2x+pv come from phases (pu,0) and (pu,1), interleaved here
+        // output row 2y+pu of M-tile row y: its 32 pixels 2x+pv come from phases (pu, 0) = set A and (pu, 1) = set B
 #pragma unroll
         for (int m = 0; m < KMT; ++m) {
-            const int t = wave * KMT + m;
-            const int ig = t >> p.th_log2, ty = t & (TH - 1);
+            int yt, xt;
+            const int ib = pix_off(wave * KMT + m, li, yt, xt);
 #pragma unroll
-            for (int pu = 0; pu < 2; ++pu) {
-                {
-                    float r0[NT][4];
-                    arith(accs[pu * 2 + 0][m], r0, kTrack);
-                    UMX_PUT(2 * li, r0)
-                }
-                {
-                    float r1[NT][4];
-                    arith(accs[pu * 2 + 1][m], r1, kTrack);
-                    UMX_PUT(2 * li + 1, r1)
-                }
-                if (p.nimg_m == 1) {   // 32 consecutive output pixels of one row
-                    const int img = img0 + ig;
-                    flush_row(kR32, img < p.B ? elem_at(img, (y0 + ty) * 2 + pu, x0 * 2) : -1, [](int row) { return row; });
-                    continue;
-                }
-                flush(kR32, [&](int row) -> long {
-                    const int i = row >> 1;
-                    const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
-                    if (img >= p.B) return -1;
-                    return elem_at(img, (y0 + ty) * 2 + pu, (x0 + (i & (TWm - 1))) * 2 + (row & 1));
-                });
-            }
+            for (int pu = 0; pu < 2; ++pu)
+                emit(accs[pu * 2 + 0][m], accs[pu * 2 + 1][m], ib + ((yt * 2 + pu) * p.outW + xt * 2 + (setB ? 1 : 0)) * dPix, ib >= 0);
         }
     } else if (p.pool) {
+        static_assert(NPH == 4 || KMT == 4, "the pooled epilogue pairs the two pooled rows of a wave");
+        int yt, xt;
+        const int ib = pix_off(wave * KMT + (setB ? 2 : 0), li, yt, xt);
+        const int off = ib + ((yt >> 1) * p.outW + (xt >> 1)) * dPix;
+        const bool ok = ib >= 0 && (li & 1) == 0;
+        if (p.post_affine) emit_pool_t(accs[0][0], accs[0][1], accs[0][2], accs[0][3], off, ok, std::true_type{});
+        else emit_pool_t(accs[0][0], accs[0][1], accs[0][2], accs[0][3], off, ok, std::false_type{});
+    } else {
+        // sets A, B = M-tiles m, m+1 (every o_mul-th pixel for a per-phase transposed convolution)
+        static_assert((KMT & 1) == 0, "M-tiles are stored in pairs");
+        const int om = p.o_mul;
 #pragma unroll
         for (int m = 0; m < KMT; m += 2) {
-            const int t = wave * KMT + m;
-            const int ig = t >> p.th_log2, ty = t & (TH - 1);
-            float r0[NT][4], r1[NT][4];
-            arith(accs[0][m], r0, kTrack);
-            arith(accs[0][m + 1], r1, kTrack);
-            // rows m, m+1 are vertical neighbours; pixels li, li^1 horizontal neighbours
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float a = fmaxf(r0[n][r], r1[n][r]);
-                    const float b = __builtin_bit_cast(
-                        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1 /* quad_perm [1,0,3,2] */, 0xF,
-                                                           0xF, false));
-                    r0[n][r] = fmaxf(a, b);   // both lanes of the pair hold the pooled value; the even one stores
-                }
-            if ((li & 1) == 0) { UMX_PUT(li >> 1, r0) }   // pooled pixel j = li/2 of the 8 this M-tile pair produces
-            if (p.nimg_m == 1) {   // 8 consecutive pooled pixels of one row
-                const int img = img0 + ig;
-                flush_row(kR8, img < p.B ? elem_at(img, (y0 + ty) >> 1, x0 >> 1) : -1, [](int row) { return row; });
-                continue;
-            }
-            flush(kR8, [&](int j) -> long {
-                const int i = 2 * j;
-                const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
-                if (img >= p.B) return -1;
-                return elem_at(img, (y0 + ty) >> 1, (x0 + (i & (TWm - 1))) >> 1);
-            });
-        }
-    } else {
-#pragma unroll
-        for (int m = 0; m < KMT; ++m) {
-            const int t = wave * KMT + m;
-            const int ig = t >> p.th_log2, ty = t & (TH - 1);
-            {
-                float r0[NT][4];
-                arith(accs[0][m], r0, kTrack);
-                UMX_PUT(li, r0)
-            }
-            if (p.nimg_m == 1) {   // 16 pixels of one row (every o_mul-th pixel for a per-phase transposed convolution)
-                const int img = img0 + ig;
-                const int om = p.o_mul;
-                flush_row(kR16, img < p.B ? elem_at(img, (y0 + ty) * om + ph.oy_off, x0 * om + ph.ox_off) : -1,
-                          [om](int row) { return row * om; });
-                continue;
-            }
-            flush(kR16, [&](int i) -> long {
-                const int img = img0 + ig * p.nimg_m + (i >> p.twm_log2);
-                if (img >= p.B) return -1;
-                return elem_at(img, (y0 + ty) * p.o_mul + ph.oy_off, (x0 + (i & (TWm - 1))) * p.o_mul + ph.ox_off);
-            });
+            int yt, xt;
+            const int ib = pix_off(wave * KMT + m + (setB ? 1 : 0), li, yt, xt);
+            emit(accs[0][m], accs[0][m + 1], ib + ((yt * om + ph.oy_off) * p.outW + xt * om + ph.ox_off) * dPix, ib >= 0);
         }
     }
     if (vmax >= 0x476a6000u) atomicOr(p.overflow_flag, 1);   // |v| >= 60000, infinity or NaN: binary16 range exceeded, the host reports it

@@ -124,7 +124,7 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
         // diagnostic: UMX_DEBUG_STAMPS=<layer name> prints the mean s_memtime segments of that layer's workgroups
         static const char* dbg_layer = getenv("UMX_DEBUG_STAMPS");
         if (dbg_layer && L.name == dbg_layer) {
-            const size_t nwg = (size_t)((ns + p.imgs - 1) / p.imgs) * p.tiles_y * p.tiles_x * p.nblocks * p.nphase;
+            const size_t nwg = (size_t)((ns + p.imgs - 1) / p.imgs) * p.tiles_y * p.tiles_x * p.nblocks * (p.fused_phases ? 1 : p.nphase);
             long long* d = nullptr;
             HIP_TRY(ctx, hipMalloc((void**)&d, nwg * 7 * sizeof(long long)));
             p.dbg = d;

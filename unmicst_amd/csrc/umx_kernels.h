@@ -100,8 +100,6 @@ struct HConvParams {
     int kmt;                       // M-tiles per wave: 4 (plain kernel) or 2 (fused transposed convolution)
     int xcd_order;                 // 1: workgroup ids are re-ordered so that each XCD (ids = x mod 8) walks a contiguous range of tiles
     int maxp;                      // halo pieces per wave and chunk the launched instantiation indexes: 4 or 12
-    int stg_off;                   // LDS byte offset of the epilogue's transpose staging (clear of weight buffer 1: the
-                                   // epilogue constants sit there while the staged rows are written)
     int lo_off, b_off, lds_bytes;  // LDS byte offsets: lo planes, weight buffers; total dynamic LDS
     int wbuf_bytes;                // one weight buffer (there are two): 64 + S * NT * 2048
     int ymin, xmin, tiles_y, tiles_x;

@@ -99,15 +99,11 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
             }
         }
     }
-    const int stage_rows = fused ? 32 : 16;
     const int nwaves = kWaves;
     h.kmt = fused ? 2 : kMT;
-    const int epi_bytes = nwaves * 2 * stage_rows * (nt16 * 32 + 16);   // epilogue transpose staging
-    // dynamic LDS of a plan: halo slots (hi + lo) | weight buffer 0 | weight buffer 1 | the staging area, unless it fits below
-    // buffer 1 (the epilogue constants sit in buffer 1 while the staged rows are written: the kernel orders the buffers so)
+    // dynamic LDS of a plan: halo slots (hi + lo) | weight buffer 0 | weight buffer 1 (the epilogue stores from registers)
     auto lds_total = [&](int nslots, int oc, int ss, int plane_pair_bytes) {
-        const int below = nslots * oc * plane_pair_bytes, wb = 64 + ss * nt16 * 2048;
-        return below + 2 * wb + (epi_bytes <= below + wb ? 0 : epi_bytes);
+        return nslots * oc * plane_pair_bytes + 2 * (64 + ss * nt16 * 2048);
     };
 
     // One stage list (= one kernel phase, or the whole fused transposed convolution) for a given (OC, S, slot base E):
@@ -256,10 +252,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
             }
         }
     }
-    // epilogue transpose staging: below weight buffer 1 when it fits there (the constants sit in buffer 1), else above it
-    h.stg_off = epi_bytes <= h.b_off + h.wbuf_bytes ? 0 : h.b_off + 2 * h.wbuf_bytes;
-    h.lds_bytes = std::max(h.b_off + 2 * h.wbuf_bytes, h.stg_off + epi_bytes);
-    if (h.lds_bytes > kMaxLdsPerWG) { *why = "epilogue staging exceeds the LDS budget"; return UMX_ERR_INVALID; }
+    h.lds_bytes = h.b_off + 2 * h.wbuf_bytes;
 
     std::vector<HStage> stages;
     std::vector<std::vector<_Float16>> wimg(nlists);   // per stage list: [nblk][stage blocks] halves
