@@ -665,14 +665,19 @@ static hipError_t launch_h_k(const HConvParams& p, hipStream_t stream) {
 // instantiations: MAXP = 4 everywhere; MAXP = 12 in addition for <= 5 N-tiles (12 only for the fused kernels of <= 3)
 template <int NT, int KMT, int NPH>
 static hipError_t launch_h_nt(const HConvParams& p, hipStream_t stream) {
-    constexpr bool has4 = !(NPH == 4 && NT <= 3), has12 = NT <= 5 && !(NPH == 4 && NT > 3);
+    constexpr bool has4 = true, has12 = NT <= 5 && !(NPH == 4 && NT > 3);
     if (p.maxp != 4 && p.maxp != 12) return hipErrorInvalidValue;
     if constexpr (has12) {
-        if (p.maxp == 12) return launch_h_k<NT, KMT, NPH, false, 12>(p, stream);
+        if (p.maxp == 12) {
+            if constexpr (NT == 3 && NPH == 4) {   // (stamped twin of the top transposed convolution)
+                if (p.dbg) return launch_h_k<NT, KMT, NPH, true, 12>(p, stream);
+            }
+            return launch_h_k<NT, KMT, NPH, false, 12>(p, stream);
+        }
     }
     if constexpr (has4) {
         if (p.maxp == 4) {
-            if constexpr (NT == 3 || NT == 5 || NT == 9) {   // the stamped twins exist for the tile counts the bench graphs use
+            if constexpr ((NT == 3 || NT == 5 || NT == 9) && !(NPH == 4 && NT == 3)) {   // the stamped twins exist for the tile counts the bench graphs use
                 if (p.dbg) return launch_h_k<NT, KMT, NPH, true, 4>(p, stream);
             }
             return launch_h_k<NT, KMT, NPH, false, 4>(p, stream);
