@@ -57,7 +57,7 @@ def parse_args(argv=None):
                     help="conv arithmetic: exact fp32 MFMA, or 3 binary16 MFMA products per fp32 product (default)")
     ap.add_argument("--band-rows", type=int, default=0, help="override rows per GPU")
     ap.add_argument("--cols", type=int, default=0, help="override slide width")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-baseline legs (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=45.0, help="budget of the CPU-baseline legs (0 = skip)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-layer table to stderr")
     ap.add_argument("--slabs", type=int, default=2, help="N>1 path: row slabs per band (stitch + async all-gather each)")
     ap.add_argument("--force-sharded", action="store_true",
@@ -108,13 +108,16 @@ def pmc_traffic(kernel, precision, batch):
     this configuration is committed."""
     import csv
     path = None
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         cand = os.path.join(ROOT, "profiles", rnd, "final_%s_b%d_by_layer_pmc.csv" % (precision, batch))
         if os.path.exists(cand):
             path = cand
             break
     if path is None:
         return None
+    commit = None          # the commit the counters were captured at (sidecar written when the CSV was copied into profiles/)
+    if os.path.exists(path + ".commit"):
+        commit = open(path + ".commit").read().strip()
     calls = rd = wr = us = 0.0
     with open(path, newline="") as f:
         for r in csv.DictReader(f):
@@ -128,7 +131,7 @@ def pmc_traffic(kernel, precision, batch):
         return None
     return {"bytes_per_launch": round((rd + wr) / calls), "read": round(rd / calls), "write": round(wr / calls),
             "avg_launch_us_profiled": round(us / calls, 2), "launches_profiled": int(calls),
-            "source": os.path.relpath(path, ROOT)}
+            "source": os.path.relpath(path, ROOT), "captured_at_commit": commit}
 
 
 def roofline_of(prof, elapsed_s, eng, batch):
@@ -180,6 +183,38 @@ def print_breakdown(prof):
                                                       p["flops"] / s / 1e12, p["bytes"] / s / 1e9), file=sys.stderr)
 
 
+def ranks_block(dist, torch, hp, H, W, rank, agree, dev=None):
+    """What the communicator saw, for the N > 1 line: world size from the process group, every rank's band of patch rows and
+    tile count, the bytes each rank contributes to / receives from the all-gather per step, and whether the host path equalled
+    the resident path on EVERY rank.  Works over any backend (the dry launch uses gloo, no GPU)."""
+    from unmicst_amd import sharding
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    sub = hp.imSize - 2 * hp.margin
+    npr, npc = -(-H // sub), -(-W // sub)
+    pa, pb = sharding.band_partition(npr, world)[rank]
+    mine = [int(pa), int(pb), int((pb - pa) * npc)]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        agree_all = None
+        if agree is not None:
+            flags = [None] * world
+            dist.all_gather_object(flags, bool(agree))
+            agree_all = all(flags)
+    else:
+        gathered, agree_all = [mine], agree
+    K = hp.nClasses
+    owned = [sharding.owned_rows(a, b, npr, sub, hp.margin, H) for a, b, _ in gathered]
+    return {"world_size_from_communicator": int(world), "backend": dist.get_backend() if world > 1 else None,
+            "patch_rows": int(npr), "patch_cols": int(npc),
+            "per_rank": [{"rank": i, "patch_row0": g[0], "patch_row1": g[1], "tiles": g[2], "owned_image_rows": [int(o[0]), int(o[1])]}
+                         for i, (g, o) in enumerate(zip(gathered, owned))],
+            "tiles_total": int(sum(g[2] for g in gathered)),
+            "allgather_bytes_per_step": {"contributed_per_rank": [int(K * max(o[1] - o[0], 0) * W * 2) for o in owned],
+                                         "received_per_rank": int(K * H * W * 2)},
+            "host_path_equals_resident_path_all_ranks": agree_all}
+
+
 def main():
     args = parse_args()
     world_env = os.environ.get("WORLD_SIZE")
@@ -194,6 +229,19 @@ def main():
     if args.dry_launch:
         sys.stdout.write("bench.py dry launch: rank %d of %d (local rank %d)\n" % (rank, world, local_rank))   # one write
         sys.stdout.flush()
+        if world > 1:      # the "ranks" block of the JSON line, filled from a (gloo) communicator: no GPU is touched
+            import torch.distributed as dist
+            from unmicst_amd import model
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(args.master_port))
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            key, C_img, band_rows, W = WORKLOADS[args.workload]
+            hp = model.KNOWN_HP[key]
+            H = (args.band_rows or band_rows) * (8 if args.scaling == "strong" else world)
+            block = ranks_block(dist, None, hp, H, args.cols or W, rank, None)
+            if rank == 0:
+                print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks": block}))
+            dist.destroy_process_group()
         return
 
     import numpy as np
@@ -347,8 +395,26 @@ def main():
         return dt, prof, res
 
     host_elapsed = host_prof = None
+    host_sync = None
     if not args.resident_only:
         host_elapsed, host_prof, res_h = timed(step_host)
+        if not sharded:
+            # what ONE per-file driver call achieves: a synchronous umx_infer_image_raw with the drivers' intensity rescale
+            # (the whole upload and its min/max pass precede the first tile), one slide at a time
+            sync_out = torch.empty((K, H, W), dtype=torch.uint8).pin_memory()
+
+            def step_sync():
+                eng._check(eng._L.umx_infer_image_raw(eng._ctx, host_u16.data_ptr(), 16, C_img, H, W, 1, float(mean), float(std),
+                                                      umx.MODE_ACCUMULATE, sync_out.data_ptr()))
+            ns = max(3, min(args.steps, 10))
+            step_sync()
+            t0 = time.perf_counter()
+            for _ in range(ns):
+                step_sync()
+            dts = time.perf_counter() - t0
+            host_sync = {"value": round(tiles_total * ns / dts, 2), "unit": "tiles/s", "ms_per_call": round(1e3 * dts / ns, 3),
+                         "calls": ns, "note": "synchronous umx_infer_image_raw(rescale=1), one slide at a time: the per-file "
+                                              "driver's call (`value` above streams two slides through submit / wait)"}
     res_elapsed, res_prof, res_r = timed(step_resident)
     # the two paths must agree: uint8 planes of the host path == np.uint8(255 * fp16 planes) of the resident path
     with torch.cuda.stream(work):
@@ -365,6 +431,7 @@ def main():
             agree = None if host_elapsed is None else bool(torch.equal(res_h, res_r))
             checksum = float(res_r.float().mean().item())
     elapsed, prof = (host_elapsed, host_prof) if host_elapsed is not None else (res_elapsed, res_prof)
+    ranks = ranks_block(dist if sharded else None, torch, hp, H, W, rank, agree)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -400,6 +467,7 @@ def main():
             "resident": {"value": round(tiles_total * args.steps / res_elapsed, 2), "unit": "tiles/s",
                          "ms_per_step": round(1e3 * res_elapsed / args.steps, 3),
                          "note": "same slide already in HBM as float64, result left in HBM (no H2D / D2H): kernel-only"},
+            "host_sync": host_sync, "ranks": ranks,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
@@ -491,70 +559,133 @@ def cpu_baseline_train(hp, blob, data, labels, weights, budget_s):
                       "optimiser update), %.1f s" % (n, dt)}
 
 
+def host_cpu_info():
+    """What the host offers this process: logical CPUs, the affinity mask and the cgroup CPU quota (a GPU box shows every
+    host core but may grant only a share of them)."""
+    info = {"logical": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+            "cgroup_quota_cores": None}
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    info["cgroup_quota_cores"] = round(float(txt[0]) / float(txt[1]), 2)
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    info["cgroup_quota_cores"] = round(q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()), 2)
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return info
+
+
 def cpu_baseline(hp, blob, band_f64, mean, std, budget_s):
     """The reference's CPU path restated (TensorFlow is not installable here: SURVEY.md section 8c), timed on the host
     cores of the GPU box on a bounded sample of the same slide.  Two figures:
-      value / best_effort   the UNet as torch-CPU float32 on every host core (oracle/train_oracle.py's restatement of the
-                            v2 graph; the C oracle for the legacy graph), tiles batched at the hp's batch size, ONE pass
-                            that yields all classes, PI2D gather + normalise in numpy;
+      value / best_effort   the UNet as torch-CPU float32 (oracle/train_oracle.py's restatement of the v2 graph; the C
+                            oracle for the legacy graph), ONE pass that yields all classes, PI2D gather + normalise in numpy,
+                            at the BEST of a sweep over thread count x batch size x memory format (every setting tried is
+                            listed in `sweep`), on a sample of >= 64 tiles;
       reference_faithful    the reference's own loop shape: the Python PI2D tile loop with per-tile patchOutput, run once
-                            PER CLASS (UnMicst1-5.py:697-707,845-848) on the same torch-CPU forward -- a "tile" still
-                            counts once, so this is ~nClasses x slower by construction."""
+                            PER CLASS (UnMicst1-5.py:697-707,845-848) on the same forward at the same settings -- a "tile"
+                            still counts once, so this is ~nClasses x slower by construction."""
     import numpy as np
     import torch
     from oracle import oracle, pi2d_oracle
     P, m = hp.imSize, hp.margin
     sub = P - 2 * m
-    B = max(1, int(getattr(hp, "batchSize", 0) or 8))
+    hpB = max(1, int(getattr(hp, "batchSize", 0) or 8))
+    host = host_cpu_info()
+    cap = int(host["affinity"] or host["logical"] or 1)
+    quota = host["cgroup_quota_cores"]
+    cands = {8, 16, 32, 64, cap}
+    if quota:
+        cands |= {max(1, int(quota // 2)), max(1, int(round(quota))), max(1, int(2 * quota))}
+    threads = sorted(t for t in cands if 1 <= t <= cap)
     if hp.graph:
         from oracle import train_oracle as to
         T = to.split_blob(hp, np.asarray(blob, dtype=np.float64))
         Pm = {k: torch.tensor(v, dtype=torch.float32) for k, v in T.items()}
         opts = to.TrainOptions()
 
-        def forward(x):
+        def forward(x, fmt="channels_last"):
             with torch.no_grad():
-                return to.forward(hp, Pm, torch.from_numpy(np.ascontiguousarray(x)), opts, 0, training=False)[0].numpy()
-        cores, what = torch.get_num_threads(), "torch CPU float32 (oracle/train_oracle.py)"
+                t = torch.from_numpy(np.ascontiguousarray(x))                       # NHWC: the oracle's NCHW view of it is channels_last
+                if fmt == "contiguous":
+                    t = t.permute(0, 3, 1, 2).contiguous().permute(0, 2, 3, 1)      # ... or a contiguous NCHW tensor
+                return to.forward(hp, Pm, t, opts, 0, training=False)[0].numpy()
+        set_threads, what, formats = torch.set_num_threads, "torch CPU float32 (oracle/train_oracle.py)", ("channels_last", "contiguous")
     else:
-        def forward(x):
+        def forward(x, fmt=None):
             return oracle.forward(hp, blob, x)
-        cores, what = oracle.num_threads(), "oracle/unet_oracle.c (OpenMP, double accumulate)"
+        set_threads, what, formats = oracle.set_num_threads, "oracle/unet_oracle.c (OpenMP, double accumulate)", (None,)
     rows = min(band_f64.shape[1], 2 * sub + 2 * m)
-    cols = min(band_f64.shape[2], 8 * sub + 2 * m)
+    cols = min(band_f64.shape[2], 40 * sub + 2 * m)
     crop = band_f64[:, :rows, :cols].cpu().numpy()
     if hp.nChannels == 1:
         crop = crop[0]
     pi = pi2d_oracle.PI2DOracle(crop, P, m, "accumulate")
-    forward(pi2d_oracle.normalised_batch(pi, 0, 1, hp.nChannels, mean, std, False))          # untimed: thread pool, caches
-    t = time.perf_counter()
-    forward(pi2d_oracle.normalised_batch(pi, 0, min(B, pi.num_patches), hp.nChannels, mean, std, False))
-    per_tile = max((time.perf_counter() - t) / min(B, pi.num_patches), 1e-4)
-    # ---- best effort: one batched pass, all classes
-    n = int(max(1, min(pi.num_patches, 0.5 * budget_s / per_tile)))
+
+    def batch_of(t0, nb):
+        return pi2d_oracle.normalised_batch(pi, t0, nb, hp.nChannels, mean, std, False)
+    # ---- sweep (within half the budget): thread counts at the hp's batch size first, then batch size and memory format at the
+    # best thread count; every setting = one untimed batch (shape-specific primitive caches) + one timed batch
+    order = sorted(threads, key=lambda t: abs(t - (quota or min(cap, 32))))
+    sweep, t_sweep = [], time.perf_counter()
+    best = None
+
+    def probe(nt, B, fmt):
+        nonlocal best
+        B = min(B, pi.num_patches)
+        if any(e["threads"] == nt and e["batch"] == B and e["format"] == fmt for e in sweep):
+            return
+        if best is not None and time.perf_counter() - t_sweep > 0.5 * budget_s:
+            return
+        set_threads(nt)
+        x = batch_of(0, B)
+        forward(x, fmt)
+        t = time.perf_counter()
+        forward(x, fmt)
+        rate = B / max(time.perf_counter() - t, 1e-6)
+        sweep.append({"threads": nt, "batch": B, "format": fmt, "tiles_per_s": round(rate, 3)})
+        if best is None or rate > best[0]:
+            best = (rate, nt, B, fmt)
+    for nt in order:
+        probe(nt, hpB, formats[0])
+    for B in (8, 32):
+        for fmt in formats:
+            probe(best[1], B, fmt)
+    _, nt, B, fmt = best
+    set_threads(nt)
+    # ---- best effort at the best setting: >= 64 tiles (or every tile of the crop), one batched pass, all classes
+    n = int(min(pi.num_patches, max(64, 0.25 * budget_s * best[0])))
     t = time.perf_counter()
     done = 0
     while done < n:
         nb = min(B, n - done)
-        forward(pi2d_oracle.normalised_batch(pi, done, nb, hp.nChannels, mean, std, False))
+        forward(batch_of(done, nb), fmt)
         done += nb
     dt = time.perf_counter() - t
     # ---- reference-faithful: the whole loop once per class on a crop of nf tiles
-    nf = int(max(1, min(pi.num_patches, 0.5 * budget_s / per_tile / hp.nClasses)))
+    per_tile = dt / n
+    nf = int(max(1, min(pi.num_patches, 0.25 * budget_s / per_tile / hp.nClasses)))
     fr = max(1, min(2, nf // max(1, min(8, nf))))                # patch rows of the crop
     fc = max(1, min(nf // fr, 8))
     crop2 = crop[..., :fr * sub + 2 * m, :fc * sub + 2 * m]
     t = time.perf_counter()
     for k in range(hp.nClasses):
-        pi2d_oracle.single_image_inference(crop2, forward, P, hp.nChannels, mean, std, "accumulate", k, B)
+        pi2d_oracle.single_image_inference(crop2, lambda x: forward(x, fmt), P, hp.nChannels, mean, std, "accumulate", k, B)
     dtf = time.perf_counter() - t
     nft = pi2d_oracle.PI2DOracle(crop2, P, m, "accumulate").num_patches
-    return {"value": round(n / dt, 3), "unit": "tiles/s", "cores": cores, "kind": "port",
-            "sample": "best effort: first %d tiles of the same slide, batch %d, one pass for all classes (PI2D gather + "
-                      "normalise in numpy, UNet forward %s), %.1f s" % (n, B, what, dt),
-            "reference_faithful": {"value": round(nft / dtf, 3), "unit": "tiles/s", "cores": cores,
+    return {"value": round(n / dt, 3), "unit": "tiles/s", "cores": nt, "kind": "port",
+            "sample": "best effort: first %d tiles of the same slide at the best of %d swept settings (%d threads, batch %d, %s), one "
+                      "pass for all classes (PI2D gather + normalise in numpy, UNet forward %s), %.1f s" % (
+                          n, len(sweep), nt, B, fmt or "NHWC", what, dt),
+            "host": host, "sweep": sweep,
+            "reference_faithful": {"value": round(nft / dtf, 3), "unit": "tiles/s", "cores": nt,
                                    "sample": "the reference's loop on a %d-tile crop: Python PI2D tile loop with float16 "
-                                             "patchOutput, one full pass per class (%d passes), same forward, %.1f s" % (
+                                             "patchOutput, one full pass per class (%d passes), same forward and settings, %.1f s" % (
                                                  nft, hp.nClasses, dtf)}}
 
 

@@ -231,6 +231,13 @@ UMX_API int umx_profile_read(umx_ctx* ctx, umx_prof_entry* entries, int max_entr
  * used by the fp16-compat stitch, and the library's view of a model (layer count, packed weight bytes, FLOPs). */
 UMX_API void umx_test_double_to_half(const double* in, uint16_t* out, size_t n);
 UMX_API int umx_describe(const umx_hparams* hp, int* n_launches, double* flops_per_tile, double* executed_flops_per_tile);
+/* The library's wiring of a model as JSON text (host only): activation buffers (spatial size, channels), the launch list in
+ * execution order -- per launch its operand groups (source buffer, channels, filter taps: concat order = group order), output
+ * buffer, fused max-pool, activation, where the BatchNorm affine sits, stride-2 transposed convolution -- and the constants the
+ * kernels use (BatchNorm epsilon, LeakyReLU slope).  What a reviewer compares with the graph the reference builds
+ * (UnMicst1-5.py:55-237; the op graph it saves: models/<name>/model.ckpt.meta).  Writes at most cap bytes (NUL-terminated) and
+ * returns in *needed the bytes the whole text takes; UMX_ERR_INVALID if cap is too small. */
+UMX_API int umx_describe_graph(const umx_hparams* hp, char* json, size_t cap, size_t* needed);
 UMX_API const char* umx_version(void);
 
 #ifdef __cplusplus

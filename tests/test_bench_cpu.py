@@ -24,6 +24,22 @@ def test_bench_gpus_2_launches_two_ranks():
     import re
     seen = sorted(re.findall(r"bench\.py dry launch: rank (\d) of 2 \(local rank (\d)\)", r.stdout))   # (lines may interleave)
     assert seen == [("0", "0"), ("1", "1")], r.stdout[-500:]
+    # the "ranks" block of the N > 1 line, filled from the communicator the two ranks formed (gloo here, RCCL on the GPUs)
+    import json
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-800:]
+    blk = json.loads(lines[0])["ranks"]
+    assert blk["world_size_from_communicator"] == 2 and blk["backend"] == "gloo"
+    # default workload, weak scaling: 2 bands of 2048 rows x 16384 columns of 192-pixel sub-patches
+    assert blk["patch_rows"] == 22 and blk["patch_cols"] == 86
+    per = blk["per_rank"]
+    assert [p["rank"] for p in per] == [0, 1]
+    assert per[0]["patch_row0"] == 0 and per[0]["patch_row1"] == per[1]["patch_row0"] and per[1]["patch_row1"] == 22
+    assert sum(p["tiles"] for p in per) == blk["tiles_total"] == 22 * 86
+    assert per[0]["owned_image_rows"][0] == 0 and per[0]["owned_image_rows"][1] == per[1]["owned_image_rows"][0]
+    assert per[1]["owned_image_rows"][1] == 4096
+    ag = blk["allgather_bytes_per_step"]
+    assert sum(ag["contributed_per_rank"]) == ag["received_per_rank"] == 3 * 4096 * 16384 * 2
 
 
 def test_bench_rejects_a_world_that_does_not_match_gpus():

@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
     // not written back into the accumulator tuples (a 4-vector rebuilt by inserts gets a fresh register tuple).
     unsigned vmax = 0u;   // max |v| of this lane as a bit pattern (orders NaN and infinity above every finite value): one
                           // compare against binary16's range at the end
-    const float slope = p.act == ACT_RELU ? 0.f : p.act == ACT_LEAKY ? 0.2f : 1.f;
+    const float slope = p.act == ACT_RELU ? 0.f : p.act == ACT_LEAKY ? kLeakySlope : 1.f;
     auto arith_v = [&](const f32x4 (&A)[NT], float (&out)[NT][4], auto POST, auto TRACK) {
         constexpr bool post = decltype(POST)::value, track = decltype(TRACK)::value;
         // (different first instructions: otherwise the common head of the two copies is hoisted above the branch in one batch)

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256, 2) conv_first(const FirstParams p) {
     const int dOct = p.dst_planar ? outS * outS * 8 : 8;
     _Float16* const ohi = p.dst_hi + (size_t)img * outS * outS * p.Cds;
     _Float16* const olo = p.dst_lo + (size_t)img * outS * outS * p.Cds;
-    const float slope = p.act == ACT_RELU ? 0.f : p.act == ACT_LEAKY ? 0.2f : 1.f;
+    const float slope = p.act == ACT_RELU ? 0.f : p.act == ACT_LEAKY ? kLeakySlope : 1.f;
     const float4* const ec4 = reinterpret_cast<const float4*>(ecl);
     const bool odd = (li & 1) != 0;
     unsigned vmax = 0u;   // max |v| of this lane as a bit pattern (orders NaN and infinity above every finite value)

@@ -104,6 +104,7 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
     }
     HConvParams p = L.hcp;
     p.B = ns;
+    p.overflow_flag = ctx->d_flag + ctx->flag_word;
     for (int gi = 0; gi < L.ngroups; ++gi) {
         const Buffer& sb = cur_bufs(ctx)[L.g[gi].src];
         p.src_hi[gi] = hi_at(sb);
@@ -339,6 +340,49 @@ int umx_describe(const umx_hparams* hp, int* n_launches, double* flops_per_tile,
     if (n_launches) *n_launches = (int)plan.size();
     if (flops_per_tile) *flops_per_tile = f;
     if (executed_flops_per_tile) *executed_flops_per_tile = e;
+    return UMX_OK;
+}
+
+int umx_describe_graph(const umx_hparams* hp, char* json, size_t cap, size_t* needed) {
+    std::string why;
+    int rc = check_hp(hp, &why);
+    if (rc) return fail(nullptr, rc, "%s", why.c_str());
+    std::vector<Launch> plan;
+    std::vector<std::pair<int, int>> geom;
+    build_graph(*hp, nullptr, &plan, nullptr, &geom, nullptr);
+    std::string o = "{";
+    char b[256];
+    snprintf(b, sizeof b, "\"bn_epsilon\": %.9g, \"leaky_slope\": %.9g, \"buffers\": [", kBnEpsilon, (double)kLeakySlope);
+    o += b;
+    for (size_t i = 0; i < geom.size(); ++i) {
+        snprintf(b, sizeof b, "%s{\"id\": %zu, \"size\": %d, \"channels\": %d}", i ? ", " : "", i, geom[i].first, geom[i].second);
+        o += b;
+    }
+    o += "], \"launches\": [";
+    for (size_t li = 0; li < plan.size(); ++li) {
+        const Launch& L = plan[li];
+        static const char* acts[] = {"none", "relu", "leaky_relu"};
+        static const char* bns[] = {"none", "before_activation", "after_activation"};
+        snprintf(b, sizeof b, "%s{\"name\": \"%s\", \"kind\": \"%s\", \"size\": %d, \"out_channels\": %d, \"dst\": %d, "
+                              "\"max_pool\": %d, \"activation\": \"%s\", \"batch_norm\": \"%s\", \"stride\": %d, "
+                              "\"summed_shortcut_ks\": %d, \"groups\": [",
+                 li ? ", " : "", L.name.c_str(), L.head ? "head_softmax" : L.o_mul == 2 ? "conv_transpose" : "conv", L.H,
+                 L.head ? L.head_K : L.Cout, L.dst, L.pool ? 2 : 0, L.head ? "softmax" : acts[L.act], bns[L.bn], L.o_mul, L.summed_shortcut);
+        o += b;
+        for (int gi = 0; gi < L.ngroups; ++gi) {
+            size_t ntaps = 0;
+            for (int ph = 0; ph < (L.head ? 0 : L.nphase); ++ph) ntaps += L.g[gi].taps[ph].size();
+            int ks = 1;
+            while ((size_t)ks * ks < ntaps) ++ks;
+            snprintf(b, sizeof b, "%s{\"src\": %d, \"channels\": %d, \"ks\": %d}", gi ? ", " : "", L.g[gi].src, L.g[gi].C, L.head ? 1 : ks);
+            o += b;
+        }
+        o += "]}";
+    }
+    o += "]}";
+    if (needed) *needed = o.size() + 1;
+    if (!json || cap < o.size() + 1) return json ? fail(nullptr, UMX_ERR_INVALID, "umx_describe_graph: %zu bytes needed", o.size() + 1) : UMX_OK;
+    memcpy(json, o.c_str(), o.size() + 1);
     return UMX_OK;
 }
 

@@ -61,7 +61,7 @@ void fold_bn(const BN& bn, int C, std::vector<float>* s, std::vector<float>* b) 
     s->resize(C);
     b->resize(C);
     for (int c = 0; c < C; ++c) {
-        const double sc = (double)bn.g[c] / std::sqrt((double)bn.v[c] + 0.001);
+        const double sc = (double)bn.g[c] / std::sqrt((double)bn.v[c] + kBnEpsilon);
         (*s)[c] = (float)sc;
         (*b)[c] = (float)((double)bn.b[c] - (double)bn.m[c] * sc);
     }
@@ -199,6 +199,7 @@ struct Builder {
             ds[i + 1] = new_buf(S / 2, Co);
             auto epilogue = [&](Launch& Lh) {
                 // v2: leaky(BN(sum)) (UnMicst1-5.py:114);  legacy: BN(relu(sum)) (UnMicst.py:99); then 2x2 max-pool
+                Lh.bn = v2 ? 1 : 2;
                 if (!blob) return;
                 if (v2) fold_bn(bn, Co, &Lh.pre_s, &Lh.pre_b);
                 else fold_bn(bn, Co, &Lh.post_s, &Lh.post_b);
@@ -207,6 +208,7 @@ struct Builder {
                 snprintf(nm, sizeof nm, "ld%d.conv", i);
                 Launch Lh = make(nm, S, Co, ds[i + 1], 1, act);
                 add_conv_group(Lh, ds[i], w1, 0, Ci, &wsc);
+                Lh.summed_shortcut = kss;
                 epilogue(Lh);
                 finish(Lh);
             } else {
@@ -239,6 +241,7 @@ struct Builder {
             add_conv_group(Lb, ds[L], w, 0, Ci);
             if (v2) {
                 BN bn = take_bn(Co);
+                Lb.bn = 1;
                 if (blob) fold_bn(bn, Co, &Lb.pre_s, &Lb.pre_b);
             }
             finish(Lb);
@@ -262,6 +265,7 @@ struct Builder {
             Launch Lc = make(nm, S2, Cup, cv, 0, act);
             add_conv_group(Lc, ds[idx], w2, 0, Cskip);   // concat3([dsX[index], us]): skip channels first
             add_conv_group(Lc, us, w2, Cskip, Cup);
+            if (v2) Lc.bn = 1;
             if (v2 && blob) fold_bn(bn, Cup, &Lc.pre_s, &Lc.pre_b);
             finish(Lc);
             int other = nx > 0 ? new_buf(S2, Cup) : -1;
@@ -293,6 +297,7 @@ struct Builder {
             if (blob) Lh.head_w.assign(w, w + (size_t)n[1] * hp.nClasses);
             if (v2) {
                 BN bn = take_bn(hp.nClasses);
+                Lh.bn = 1;
                 if (blob) fold_bn(bn, hp.nClasses, &Lh.pre_s, &Lh.pre_b);
             }
             Lh.flops = Lh.exec_flops = 2.0 * S * S * n[1] * hp.nClasses;

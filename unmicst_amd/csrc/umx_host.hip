@@ -21,19 +21,15 @@ static int host_wait(umx_ctx* ctx, int slot) {
     if (!hs.busy) return UMX_OK;
     hs.busy = false;
     HIP_TRY(ctx, hipEventSynchronize(hs.done));
-    if (*hs.flag_host) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        return check_range_flag(ctx);
-    }
+    if (*hs.flag_host)   // this slot's own flag word, cleared by the next submit on the slot in stream order
+        return fail(ctx, UMX_ERR_RANGE, "an activation left the binary16 range of the split-precision path; "
+                                        "create the context with UMX_PREC_F32 (or UMX_PRECISION=f32)");
     return UMX_OK;
 }
 
-static int host_submit(umx_ctx* ctx, int slot, const void* src, int src_bits, int C_img, int H, int W, int rescale, double mean,
-                       double stdv, int mode, int stitch, int out_u8, void* out_host) {
-    if (slot < 0 || slot > 1) return fail(ctx, UMX_ERR_INVALID, "slot must be 0 or 1");
+static int host_submit_impl(umx_ctx* ctx, int slot, bool sync_call, const void* src, int src_bits, int C_img, int H, int W, int rescale,
+                            double mean, double stdv, int mode, int stitch, int out_u8, void* out_host) {
     umx_ctx::HostSlot& hs = ctx->hs[slot];
-    if (hs.busy) return fail(ctx, UMX_ERR_INVALID, "slot %d still holds a submitted call: wait for it first", slot);
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!hs.done) {
         HIP_TRY(ctx, hipEventCreateWithFlags(&hs.done, hipEventDisableTiming));
         HIP_TRY(ctx, hipHostMalloc((void**)&hs.flag_host, 64, hipHostMallocDefault));
@@ -60,6 +56,15 @@ static int host_submit(umx_ctx* ctx, int slot, const void* src, int src_bits, in
     const int T = g.npr * g.npc;
     int S = std::max(1, (T + ctx->max_batch - 1) / ctx->max_batch);
     if (const char* e = getenv("UMX_HOST_SLABS")) S = std::max(1, std::min(atoi(e), S));
+    // A synchronous call on a slide of one launch group has nothing to overlap: its upload, kernels and download go down ONE
+    // stream in order, without the copy streams and the events that hand slabs from one stream to the next (a 1024 x 1024
+    // slide is a 1 - 3 ms call).  Submitted calls keep the copy streams: slide i+1's upload rides under slide i's kernels.
+    const bool single = S == 1 && sync_call;
+    const hipStream_t up_s = single ? ctx->stream : ctx->up_stream, dn_s = single ? ctx->stream : ctx->dn_stream;
+    // this call's range flag: its own word, cleared in stream order in front of its kernels
+    const int fw = 16 * (slot + 1);
+    if (ctx->d_flag) HIP_TRY(ctx, hipMemsetAsync(ctx->d_flag + fw, 0, sizeof(int), ctx->stream));
+    ctx->flag_word = fw;
     while ((int)hs.events.size() < 2 * S + 1) {
         hipEvent_t ev;
         HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -81,7 +86,7 @@ static int host_submit(umx_ctx* ctx, int slot, const void* src, int src_bits, in
         for (int c = 0; c < C_img && r1 > r0; ++c) {
             const size_t off = ((size_t)c * H + r0) * W * in_b, n = (size_t)(r1 - r0) * W * in_b;
             void* const dst = src_bits ? (void*)(d_raw + off) : (void*)((unsigned char*)hs.d_image + off);
-            HIP_TRY(ctx, hipMemcpyAsync(dst, (const unsigned char*)src + off, n, hipMemcpyHostToDevice, ctx->up_stream));
+            HIP_TRY(ctx, hipMemcpyAsync(dst, (const unsigned char*)src + off, n, hipMemcpyHostToDevice, up_s));
         }
         return UMX_OK;
     };
@@ -101,8 +106,10 @@ static int host_submit(umx_ctx* ctx, int slot, const void* src, int src_bits, in
                 const int r1 = s == S - 1 ? H : rows_needed((tcut[s + 1] - 1) / g.npc + 1);
                 if (r1 <= up_done) continue;
                 if ((rc = upload(up_done, r1))) return rc;
-                HIP_TRY(ctx, hipEventRecord(ev_up[s], ctx->up_stream));
-                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ev_up[s], 0));
+                if (!single) {
+                    HIP_TRY(ctx, hipEventRecord(ev_up[s], ctx->up_stream));
+                    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ev_up[s], 0));
+                }
                 for (int c = 0; c < C_img && r1 > up_done; ++c)
                     HIP_TRY(ctx, launch_minmax(d_raw + ((size_t)c * H + up_done) * W * in_b, src_bits, (size_t)(r1 - up_done) * W,
                                                mm + 16 * c, ctx->stream));
@@ -117,8 +124,10 @@ static int host_submit(umx_ctx* ctx, int slot, const void* src, int src_bits, in
         const int r1 = s == S - 1 ? H : rows_needed((tcut[s + 1] - 1) / g.npc + 1);
         if (r1 > up_done) {
             if ((rc = upload(up_done, r1))) return rc;
-            HIP_TRY(ctx, hipEventRecord(ev_up[s], ctx->up_stream));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ev_up[s], 0));
+            if (!single) {
+                HIP_TRY(ctx, hipEventRecord(ev_up[s], ctx->up_stream));
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ev_up[s], 0));
+            }
             if ((rc = convert(up_done, r1))) return rc;
             up_done = r1;
         }
@@ -134,34 +143,57 @@ static int host_submit(umx_ctx* ctx, int slot, const void* src, int src_bits, in
             unsigned char* const d_slab = base + slab_e * oel;
             if ((rc = umx_stitch_dev(ctx, hs.d_probs, 0, cut[s + 1], H, W, mode, stitch, y_done, y1, d_slab))) return rc;
             if (out_u8) HIP_TRY(ctx, launch_half_to_u8(d_slab, K * rows * W, base + pm_b + slab_e, ctx->stream));
-            HIP_TRY(ctx, hipEventRecord(ev_dn[s], ctx->stream));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->dn_stream, ev_dn[s], 0));
+            if (!single) {
+                HIP_TRY(ctx, hipEventRecord(ev_dn[s], ctx->stream));
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->dn_stream, ev_dn[s], 0));
+            }
             const size_t el = out_u8 ? 1 : oel;
             const unsigned char* const dsrc = out_u8 ? base + pm_b + slab_e : d_slab;
             for (size_t k = 0; k < K; ++k)
                 HIP_TRY(ctx, hipMemcpyAsync((unsigned char*)out_host + (k * plane + (size_t)y_done * W) * el,
-                                            dsrc + k * rows * W * el, rows * W * el, hipMemcpyDeviceToHost, ctx->dn_stream));
+                                            dsrc + k * rows * W * el, rows * W * el, hipMemcpyDeviceToHost, dn_s));
             y_done = y1;
         }
     }
     // the range flag of the split-precision path rides down behind the last planes; `done` then says the call is complete
     // (every upload precedes a kernel that precedes a download on the download stream)
     if (ctx->d_flag) {
-        hipEvent_t ev_f = hs.events[2 * S];
-        HIP_TRY(ctx, hipEventRecord(ev_f, ctx->stream));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->dn_stream, ev_f, 0));
-        HIP_TRY(ctx, hipMemcpyAsync(hs.flag_host, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->dn_stream));
+        if (!single) {
+            hipEvent_t ev_f = hs.events[2 * S];
+            HIP_TRY(ctx, hipEventRecord(ev_f, ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->dn_stream, ev_f, 0));
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(hs.flag_host, ctx->d_flag + fw, sizeof(int), hipMemcpyDeviceToHost, dn_s));
     } else {
         *hs.flag_host = 0;
     }
-    HIP_TRY(ctx, hipEventRecord(hs.done, ctx->dn_stream));
+    HIP_TRY(ctx, hipEventRecord(hs.done, dn_s));
     hs.busy = true;
     return UMX_OK;
 }
 
+static int host_submit(umx_ctx* ctx, int slot, bool sync_call, const void* src, int src_bits, int C_img, int H, int W, int rescale,
+                       double mean, double stdv, int mode, int stitch, int out_u8, void* out_host) {
+    if (slot < 0 || slot > 1) return fail(ctx, UMX_ERR_INVALID, "slot must be 0 or 1");
+    if (ctx->hs[slot].busy) return fail(ctx, UMX_ERR_INVALID, "slot %d still holds a submitted call: wait for it first", slot);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rc = host_submit_impl(ctx, slot, sync_call, src, src_bits, C_img, H, W, rescale, mean, stdv, mode, stitch, out_u8, out_host);
+    ctx->flag_word = 0;
+    if (rc) {
+        // an error in the middle of enqueueing: transfers that reference the caller's buffers and this slot's device buffers may
+        // be in flight -- drain them before the caller (or the next submit) frees or reuses anything
+        const std::string msg = ctx->err;
+        if (ctx->up_stream) hipStreamSynchronize(ctx->up_stream);
+        hipStreamSynchronize(ctx->stream);
+        if (ctx->dn_stream) hipStreamSynchronize(ctx->dn_stream);
+        ctx->err = msg;
+    }
+    return rc;
+}
+
 static int infer_host(umx_ctx* ctx, const void* src, int src_bits, int C_img, int H, int W, int rescale, double mean,
                       double stdv, int mode, int stitch, int out_u8, void* out_host) {
-    int rc = host_submit(ctx, 0, src, src_bits, C_img, H, W, rescale, mean, stdv, mode, stitch, out_u8, out_host);
+    int rc = host_submit(ctx, 0, true, src, src_bits, C_img, H, W, rescale, mean, stdv, mode, stitch, out_u8, out_host);
     if (rc) return rc;
     return host_wait(ctx, 0);
 }
@@ -307,7 +339,7 @@ int umx_infer_image_raw_submit(umx_ctx* ctx, int slot, const void* raw_host, int
         return fail(ctx, UMX_ERR_INVALID, "image has %d channels, model wants 1 or %d", C_img, ctx->hp.nChannels);
     if (!(stdv != 0.0)) return fail(ctx, UMX_ERR_INVALID, "std must be non-zero");
     if (mode != UMX_MODE_ACCUMULATE && mode != UMX_MODE_REPLACE) return fail(ctx, UMX_ERR_INVALID, "bad mode %d", mode);
-    return host_submit(ctx, slot, raw_host, bits, C_img, H, W, rescale, mean, stdv, mode, UMX_STITCH_FP16_COMPAT, 1, out_host);
+    return host_submit(ctx, slot, false, raw_host, bits, C_img, H, W, rescale, mean, stdv, mode, UMX_STITCH_FP16_COMPAT, 1, out_host);
 }
 
 int umx_infer_image_wait(umx_ctx* ctx, int slot) {

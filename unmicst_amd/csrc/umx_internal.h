@@ -47,6 +47,8 @@ struct Launch {
     int H = 0, W = 0, Cout = 0;
     int dst = -1, outH = 0, outW = 0, pool = 0, act = 0;
     std::vector<float> pre_s, pre_b, post_s, post_b;  // size Cout or empty
+    int bn = 0;               // where the BatchNorm affine sits: 0 none, 1 before the activation (pre_*), 2 after it (post_*)
+    int summed_shortcut = 0;  // > 0: a same-source shortcut filter of this size is summed into the main filter (exact algebra)
     // head only
     std::vector<float> head_w;  // [C][K]
     int head_C = 0, head_K = 0;
@@ -139,7 +141,10 @@ struct umx_ctx {
     int precision = UMX_PREC_F16X3;
     int act_shift = 0;          // activations are stored times 2^act_shift in the (hi, lo) binary16 form
     float* d_tiles32 = nullptr; // fp32 staging of gathered tiles before the split (f16 path)
-    int* d_flag = nullptr;      // binary16 range overflow flag
+    int* d_flag = nullptr;      // binary16 range overflow flags (64 words): word 0 for the synchronous entry points, words 16 and
+                                // 32 for the two slots of the submit / wait API -- a flag is cleared and read in stream order by
+                                // the call that owns it, never from the host while another call is in flight
+    int flag_word = 0;          // the word the launches being enqueued report to
     uint4* d_zeros = nullptr;
     bool head_fused = false;
     Launch split_launch;

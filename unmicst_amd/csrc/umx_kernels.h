@@ -51,6 +51,8 @@ struct ConvParams {
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
+constexpr float kLeakySlope = 0.2f;   // tf.nn.leaky_relu's default alpha (reference UnMicst1-5.py:114,134,195,198)
+constexpr double kBnEpsilon = 0.001;  // tf.layers.batch_normalization's default epsilon
 constexpr int kModeReplace = 1;   // == UMX_MODE_REPLACE
 
 size_t conv_lds_bytes(int nt, int plane);

@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_f32(const ConvParams p) {
             for (int r = 0; r < 4; ++r) {
                 float v = acc[m][n][r] * ps[n] + pb[n];
                 if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
-                else if (p.act == ACT_LEAKY) v = v > 0.f ? v : 0.2f * v;
+                else if (p.act == ACT_LEAKY) v = v > 0.f ? v : kLeakySlope * v;
                 acc[m][n][r] = v * qs[n] + qb[n];
             }
 

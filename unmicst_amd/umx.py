@@ -29,7 +29,7 @@ EXPORTS = [
     "umx_tiff_packbits_decode", "umx_shard_unique_id", "umx_shard_init", "umx_shard_fini", "umx_shard_plan",
     "umx_infer_image_sharded_dev",
     "umx_band_tiles_dev", "umx_stitch_dev", "umx_profile_enable", "umx_profile_read", "umx_test_double_to_half",
-    "umx_describe", "umx_version",
+    "umx_describe", "umx_describe_graph", "umx_version",
 ]
 
 
@@ -158,6 +158,8 @@ def load(path: Optional[str] = None):
     L.umx_test_double_to_half.restype = None
     L.umx_test_double_to_half.argtypes = [c_void_p, c_void_p, ctypes.c_size_t]
     L.umx_describe.argtypes = [ctypes.POINTER(_HP), ip, ctypes.POINTER(c_double), ctypes.POINTER(c_double)]
+    L.umx_describe_graph.argtypes = [ctypes.POINTER(_HP), ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    L.umx_describe_graph.restype = c_int
     L.umx_version.restype = ctypes.c_char_p
     for name in ("umx_set_stream", "umx_synchronize", "umx_forward_tiles", "umx_forward_tiles_dev", "umx_tile_grid",
                  "umx_infer_image", "umx_infer_image_dev", "umx_band_tiles_dev", "umx_stitch_dev",
@@ -200,6 +202,21 @@ def describe(hp: HParams) -> dict:
     if rc:
         raise UmxError(rc, load().umx_last_error(None).decode())
     return {"launches": n.value, "flops_per_tile": f.value, "executed_flops_per_tile": e.value}
+
+
+def describe_graph(hp: HParams) -> dict:
+    """The library's wiring of a model (buffers, launch list, constants): see umx_describe_graph in include/umx.h.  Host only."""
+    import json
+    h = _hp_struct(hp)
+    need = ctypes.c_size_t()
+    rc = load().umx_describe_graph(ctypes.byref(h), None, 0, ctypes.byref(need))
+    if rc:
+        raise UmxError(rc, load().umx_last_error(None).decode())
+    buf = ctypes.create_string_buffer(need.value)
+    rc = load().umx_describe_graph(ctypes.byref(h), buf, need.value, ctypes.byref(need))
+    if rc:
+        raise UmxError(rc, load().umx_last_error(None).decode())
+    return json.loads(buf.value.decode())
 
 
 def double_to_half(x: np.ndarray) -> np.ndarray:
