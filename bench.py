@@ -602,7 +602,7 @@ def cpu_baseline(hp, blob, band_f64, mean, std, budget_s):
     cands = {8, 16, 32, 64, cap}
     if quota:
         cands |= {max(1, int(quota // 2)), max(1, int(round(quota))), max(1, int(2 * quota))}
-    threads = sorted(t for t in cands if 1 <= t <= cap)
+    threads = sorted(t for t in cands if 1 <= t <= cap and (not quota or t <= 4 * quota))   # (far beyond the quota: minutes per batch)
     if hp.graph:
         from oracle import train_oracle as to
         T = to.split_blob(hp, np.asarray(blob, dtype=np.float64))

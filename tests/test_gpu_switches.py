@@ -1,0 +1,96 @@
+"""Every planner / layout / host-path switch libumx still reads from the environment (and the `lanes` option), exercised on the GPU:
+the same tiles and the same slide must come out within the parity tolerance of the oracle -- or equal to the default path,
+where the switch changes scheduling only.  A switch without a test here does not exist in the library."""
+import numpy as np
+import pytest
+
+from unmicst_amd import model, umx
+
+pytestmark = pytest.mark.gpu
+
+TILE_TOL = 1e-4
+
+# a v2 graph large enough to have octet-planar tensors (>= 16 x 16 pixels, > 8 stored channels), a fused-phase and a per-phase
+# transposed convolution (<= 80 / > 80 output channels), the dense-K first layer, a fused head and k-step carries
+HP = model.HParams(model.GRAPH_V2, 64, 2, 3, 24, 3, 3, 0, 2)
+
+SWITCHES = [
+    {},                                     # the default plan (reference for the scheduling-only switches)
+    {"UMX_PLANAR": "0"},                    # NHWC activations everywhere
+    {"UMX_PLANAR": "1"},                    # octet-planar wherever eligible (also behind per-phase transposed convolutions)
+    {"UMX_XCD_ORDER": "0"},                 # plain workgroup id -> tile order
+    {"UMX_NO_KSTEP_CARRY": "1"},            # k-steps padded per chunk instead of carried into the next chunk
+    {"UMX_NO_FUSED_HEAD": "1"},             # 1x1 head + softmax as its own kernel on an fp32 tensor
+    {"UMX_NO_FUSED_CONVT": "1"},            # transposed convolutions one sub-pixel phase per workgroup
+    {"UMX_NO_FIRST": "1"},                  # first layer on conv_f16x3 instead of the dense-K kernel
+    {"UMX_PLAN_OVERRIDE": "lu0.conv:3:2,ld1.conv:1:1:12"},   # forced (octets per chunk, k-steps per stage[, piece-index array])
+    {"UMX_PRECISION": "f32"},               # default precision from the environment
+    {"UMX_ACT_SHIFT": "2"},                 # activations stored times 4
+]
+
+
+def _inputs():
+    rng = np.random.default_rng(77)
+    blob = model.random_blob(HP, seed=9)
+    x = rng.normal(size=(5, HP.imSize, HP.imSize, HP.nChannels)).astype(np.float32)
+    img = rng.random((2, 150, 210)) * 0.7
+    return blob, x, img
+
+
+@pytest.fixture(scope="module")
+def reference():
+    from oracle import oracle
+    blob, x, img = _inputs()
+    return blob, x, img, oracle.forward(HP, blob, x)
+
+
+@pytest.mark.parametrize("env", SWITCHES, ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()) or "default")
+def test_switch_keeps_parity(env, reference, monkeypatch):
+    blob, x, img, ref = reference
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    with umx.Engine(HP, blob, max_batch=3) as eng:
+        got = eng.forward_tiles(x)
+        planes = eng.infer_image(img, 0.3, 0.2)
+    assert np.abs(got - ref).max() <= TILE_TOL, env
+    for k in env:
+        monkeypatch.delenv(k)
+    with umx.Engine(HP, blob, max_batch=3) as eng:
+        base = eng.infer_image(img, 0.3, 0.2)
+    # whole image: <= 1e-3 = 2 fp16 ulp below 1.0 (tile probabilities move by ~1e-6 between plans, which can flip a rounding)
+    assert np.abs(planes.astype(np.float32) - base.astype(np.float32)).max() <= 1e-3, env
+
+
+@pytest.mark.parametrize("slabs", ["1", "2"])
+def test_host_slab_count_does_not_change_the_result(slabs, reference, monkeypatch):
+    """UMX_HOST_SLABS: how many upload / download slabs the host entry points cut a slide into (1 = unpipelined)."""
+    blob, x, img, ref = reference
+    with umx.Engine(HP, blob, max_batch=2) as eng:
+        base = eng.infer_image(img, 0.3, 0.2)
+        monkeypatch.setenv("UMX_HOST_SLABS", slabs)
+        got = eng.infer_image(img, 0.3, 0.2)
+    assert np.array_equal(got.view(np.uint16), base.view(np.uint16))
+
+
+def test_two_lanes_option_equals_one_lane(reference):
+    """umx_options.lanes = 2: tile batches alternate between two activation arenas on two streams; same launches, same bits."""
+    blob, x, img, ref = reference
+    with umx.Engine(HP, blob, max_batch=2, lanes=1) as e1, umx.Engine(HP, blob, max_batch=2, lanes=2) as e2:
+        a, b = e1.forward_tiles(x), e2.forward_tiles(x)
+        pa, pb = e1.infer_image(img, 0.3, 0.2), e2.infer_image(img, 0.3, 0.2)
+    assert np.array_equal(a, b) and np.abs(a - ref).max() <= TILE_TOL
+    assert np.array_equal(pa.view(np.uint16), pb.view(np.uint16))
+
+
+def test_more_than_eight_input_channels(reference):
+    """nChannels > 8: the input tiles span two octets and stay NHWC (the advisor's round-2 finding: they were addressed as
+    octet-planar); both precisions against the oracle."""
+    from oracle import oracle
+    hp = model.HParams(model.GRAPH_V2, 32, 11, 3, 16, 2, 3, 0, 2)
+    blob = model.random_blob(hp, seed=3)
+    x = np.random.default_rng(4).normal(size=(3, 32, 32, 11)).astype(np.float32)
+    want = oracle.forward(hp, blob, x)
+    for prec in ("f16x3", "f32"):
+        with umx.Engine(hp, blob, max_batch=3, precision=prec) as eng:
+            got = eng.forward_tiles(x)
+        assert np.abs(got - want).max() <= TILE_TOL, prec

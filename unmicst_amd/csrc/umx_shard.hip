@@ -313,6 +313,10 @@ int umx_infer_image_sharded_dev(umx_ctx* ctx, const double* band_dev, int C_img,
             }
         if ((rc = grow(ctx, &s.gathered, (size_t)world * K * mx_all * W * el))) return rc;
         if ((rc = grow(ctx, &s.slab, (size_t)K * own_max * W * el))) return rc;
+        // the send buffers too: a grow() in the slab loop would synchronise the device and free memory between enqueued
+        // collectives when a later slide is larger.  (Their padded tails stay uninitialised: the scatter never reads them.)
+        for (int i = 0; i < n; ++i)
+            if ((rc = grow(ctx, &s.send[i], (size_t)K * mx_all * W * el))) return rc;
     }
     for (int i = 0; i < n; ++i) {
         if (pa < pb && (rc = tiles(umx_geom::cut(pa, pb, n, i), std::min(umx_geom::cut(pa, pb, n, i + 1), pb - 1)))) return rc;
@@ -326,7 +330,6 @@ int umx_infer_image_sharded_dev(umx_ctx* ctx, const double* band_dev, int C_img,
             mx = std::max(mx, rb[q] - ra[q]);
         }
         const size_t plane_b = (size_t)mx * W * el, send_b = (size_t)K * plane_b;
-        if ((rc = grow(ctx, &s.send[i], send_b))) return rc;
         if (s1 > s0) {
             if ((rc = umx_stitch_dev(ctx, probs, lo, pb, H, W, mode, stitch, s0, s1, s.slab.d))) return rc;
             for (int k = 0; k < K; ++k)     // compact [K][rows][W] -> padded [K][mx][W]
