@@ -52,7 +52,8 @@ def parse_args(argv=None):
                     help="weak: every rank holds a band of --band-rows rows (slide grows with N); strong: the slide of "
                          "8 bands (16384 rows by default) at every N")
     ap.add_argument("--train-batch", type=int, default=8, help="train-synth256: images per optimisation step")
-    ap.add_argument("--batch", type=int, default=256, help="tiles per UNet launch group")
+    ap.add_argument("--batch", type=int, default=0, help="tiles per UNet launch group (0: umx.auto_batch -- 2^24 pixels per group, "
+                                                      "i.e. 256 tiles of the 256-pixel metric tile)")
     ap.add_argument("--precision", default="default", choices=["default", "f32", "f16x3"],
                     help="conv arithmetic: exact fp32 MFMA, or 3 binary16 MFMA products per fp32 product (default)")
     ap.add_argument("--band-rows", type=int, default=0, help="override rows per GPU")
@@ -270,6 +271,8 @@ def main():
     mean, std = NORMALISATION[key]
     H = band_rows * (8 if args.scaling == "strong" else world)
 
+    if args.batch <= 0:
+        args.batch = umx.auto_batch(hp)
     eng = umx.Engine(hp, blob, device=local_rank, max_batch=args.batch, precision=args.precision)
     # every engine launch, torch op and RCCL call of this process is ordered on ONE non-default stream
     work = torch.cuda.Stream(dev)

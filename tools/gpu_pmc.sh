@@ -10,7 +10,8 @@ rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $D/pmc_tcc -o run -- 
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $D/pmc_fetch -o run -- python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 "$@" > $O/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $D/pmc_write -o run -- python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 "$@" > $O/pmc_write.log 2>&1
 # one UNet pass of the split-precision plan = gather (+split), 16 convs (the softmax head is fused into the last one)
-N=pi2d.gather_normalise,ld0.conv,ld1.conv,ld2.conv,ld3.conv,ld4.conv,lb.conv,lu4.convT,lu4.conv,lu3.convT,lu3.conv,lu2.convT,lu2.conv,lu1.convT,lu1.conv,lu0.convT,lu0.conv,pi2d.stitch
+# (UMX_PMC_NAMES overrides the labels: the solo graph has four down-sampling levels, not five)
+N=${UMX_PMC_NAMES:-pi2d.gather_normalise,ld0.conv,ld1.conv,ld2.conv,ld3.conv,ld4.conv,lb.conv,lu4.convT,lu4.conv,lu3.convT,lu3.conv,lu2.convT,lu2.conv,lu1.convT,lu1.conv,lu0.convT,lu0.conv,pi2d.stitch}
 python3 tools/summarize_rocprof.py $D/stats/run_results.db --pmc $D/pmc_sq/run_results.db $D/pmc_tcc/run_results.db $D/pmc_fetch/run_results.db $D/pmc_write/run_results.db --cycle gather_ --names $N -o $O/by_layer_pmc.csv
 python3 tools/summarize_rocprof.py $D/stats/run_results.db -o $O/by_kernel_grid.csv
 python3 - <<PY

@@ -25,25 +25,32 @@ __device__ __forceinline__ void fill_lds(_Float16* lds, const _Float16* src) {
 struct Stamp { long long c0, r0; };
 __device__ __forceinline__ Stamp stamp() { return {(long long)__builtin_amdgcn_s_memtime(), (long long)__builtin_amdgcn_s_memrealtime()}; }
 
-// ---- 16x16x32: 4 x 4 tiles per wave
+// ---- 16x16x32: 4 x 4 tiles per wave; the fragments of trip it+1 are read in front of the MFMAs of trip it
 __global__ void __launch_bounds__(256) k_16(const _Float16* src, float* out, long long* clk, int iters) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     fill_lds(lds, src);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 acc[4][4];
     for (int m = 0; m < 4; ++m) for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0, 0, 0, 0};
-    const Stamp s0 = stamp();
-    for (int it = 0; it < iters; ++it) {
+    h8 a[2][4], b[2][4];
+    auto load = [&](int it, h8 (&A)[4], h8 (&B)[4]) {
         const _Float16* base = lds + ((it * 8 + wave * 2) & 31) * 512 + lane * 8;   // walks the buffer, 1 KiB per fragment
-        h8 a[4], b[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const h8*>(base + m * 512);
+        for (int m = 0; m < 4; ++m) A[m] = *reinterpret_cast<const h8*>(base + m * 512);
 #pragma unroll
-        for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const h8*>(base + (4 + n) * 512);
+        for (int n = 0; n < 4; ++n) B[n] = *reinterpret_cast<const h8*>(base + (4 + n) * 512);
+    };
+    load(0, a[0], b[0]);
+    const Stamp s0 = stamp();
+    for (int it = 0; it < iters; it += 2) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int u = 0; u < 2; ++u) {
+            load(it + u + 1, a[u ^ 1], b[u ^ 1]);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], b[n], acc[m][n], 0, 0, 0);
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u][m], b[u][n], acc[m][n], 0, 0, 0);
+        }
     }
     const Stamp s1 = stamp();
     float s = 0;
@@ -51,30 +58,37 @@ __global__ void __launch_bounds__(256) k_16(const _Float16* src, float* out, lon
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = s1.c0 - s0.c0; clk[1] = s1.r0 - s0.r0; }
 }
-// ---- 32x32x16: 2 x 2 tiles per wave, two K = 16 sub-steps per trip
+// ---- 32x32x16: 2 x 2 tiles per wave, two K = 16 sub-steps per trip, the same prefetch
 __global__ void __launch_bounds__(256) k_32(const _Float16* src, float* out, long long* clk, int iters) {
     extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
     fill_lds(lds, src);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x16 acc[2][2];
     for (int m = 0; m < 2; ++m) for (int n = 0; n < 2; ++n) for (int r = 0; r < 16; ++r) acc[m][n][r] = 0;
-    const Stamp s0 = stamp();
-    for (int it = 0; it < iters; ++it) {
+    h8 a[2][2][2], b[2][2][2];
+    auto load = [&](int it, h8 (&A)[2][2], h8 (&B)[2][2]) {
         const _Float16* base = lds + ((it * 8 + wave * 2) & 31) * 512 + lane * 8;
-        h8 a[2][2], b[2][2];
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                a[k][m] = *reinterpret_cast<const h8*>(base + (k * 2 + m) * 512);
-                b[k][m] = *reinterpret_cast<const h8*>(base + (4 + k * 2 + m) * 512);
+                A[k][m] = *reinterpret_cast<const h8*>(base + (k * 2 + m) * 512);
+                B[k][m] = *reinterpret_cast<const h8*>(base + (4 + k * 2 + m) * 512);
             }
+    };
+    load(0, a[0], b[0]);
+    const Stamp s0 = stamp();
+    for (int it = 0; it < iters; it += 2) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+        for (int u = 0; u < 2; ++u) {
+            load(it + u + 1, a[u ^ 1], b[u ^ 1]);
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int k = 0; k < 2; ++k)
 #pragma unroll
-                for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[k][m], b[k][n], acc[m][n], 0, 0, 0);
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[u][k][m], b[u][k][n], acc[m][n], 0, 0, 0);
+        }
     }
     const Stamp s1 = stamp();
     float s = 0;

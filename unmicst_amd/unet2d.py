@@ -98,7 +98,7 @@ class UNet2D:
         print(UNet2D.DatasetStDev)
         device = _umx.pick_device_most_free_memory() if gpuIndex is None or gpuIndex < 0 else int(gpuIndex)
         # tiles per launch group: enough M to fill 256 CUs at the deepest level (a few hundred MB of activations)
-        batch = UNet2D.max_batch or max(hp.batchSize, min(256, (1 << 22) // (hp.imSize * hp.imSize)))
+        batch = UNet2D.max_batch or _umx.auto_batch(hp)
         UNet2D._engine_args = (hp, art.blob, device, batch)
         UNet2D.Engine = _umx.Engine(hp, art.blob, device=device, max_batch=batch)
         print("Model restored.")
