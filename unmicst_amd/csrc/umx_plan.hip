@@ -87,7 +87,9 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         const int narrow_nt = 5;        // the kernels of <= 5 N-tiles fit 3 waves per SIMD
         const int nt3 = 40 * 1024;      // 4 workgroups per CU (the <= 3-tile kernels are built for 128 VGPRs)
         if (fused) {   // (4 pieces per wave and chunk where the halo fits them: 8 index registers and two thirds of the prologue less)
-            attempts = {{4, kMaxLdsPerWG, 1 << 30}};
+            attempts.clear();
+            if (nt16 <= 3 && !getenv("UMX_NO_CONVT3")) attempts.push_back({4, narrow, 1 << 30});   // 164 registers: three workgroups per CU where the LDS allows
+            attempts.push_back({4, kMaxLdsPerWG, 1 << 30});
             if (nt16 <= 3) attempts.push_back({12, kMaxLdsPerWG, 1 << 30});
         }
         else {
