@@ -542,7 +542,28 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
         return v;
     };
     // this lane's 16-byte unit of N-tile n after the exchange of sets (a, b) -> both planes
-    auto store_unit = [&](int n, const float (&a)[4], const float (&b)[4], int off, bool ok) {
+    constexpr bool kApp = NT <= 5;   // (appended channels exist for narrow tensors only: not in the 6..9-tile kernels)
+    // appended channels: the lanes that will hold octet app_oct read their pixel's two binary16 pairs AHEAD of the arithmetic
+    // (issued at the top of a tile's epilogue, consumed N-tiles later: the loads' latency hides behind the other N-tiles)
+    const bool lane_app = kApp && p.app_c != nullptr && oct_q == (p.app_oct & 1) && (p.app_oct >> 1) >= nblk * NT &&
+                          (p.app_oct >> 1) < (nblk + 1) * NT;
+    auto app_load = [&](int apix, unsigned& ah, unsigned& al) {
+        ah = al = 0u;
+        if (lane_app && apix >= 0) {   // the compact tensor: [pixel]{hi[cw] | lo[cw]}
+            const size_t px = (size_t)img0 * p.outH * p.outW + apix;
+            if (p.app_cw == 2) {
+                const uint2 w = *reinterpret_cast<const uint2*>(p.app_c + px * 8);
+                ah = w.x; al = w.y;
+            } else {
+                const unsigned w = *reinterpret_cast<const unsigned*>(p.app_c + px * 4);
+                ah = w & 0xffffu; al = w >> 16;
+            }
+        }
+    };
+    auto store_unit = [&](int n, const float (&a)[4], const float (&b)[4], int off, bool ok, int apix, unsigned app_h, unsigned app_l) {
+        // appended channels (the raw-input skip riding in a spare word of this unit), loaded by app_load below
+        const int oct_u = (nblk * NT + n) * 2 + oct_q;
+        const bool app = kApp && lane_app && apix >= 0 && oct_u == p.app_oct;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             vmax = max(vmax, max(__float_as_uint(a[r]) & 0x7fffffffu, __float_as_uint(b[r]) & 0x7fffffffu));
@@ -556,16 +577,22 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
         const auto h1 = __builtin_amdgcn_permlane16_swap(ah1, bh1, false, false);
         const auto l0 = __builtin_amdgcn_permlane16_swap(al0, bl0, false, false);
         const auto l1 = __builtin_amdgcn_permlane16_swap(al1, bl1, false, false);
-        const int oct = (nblk * NT + n) * 2 + oct_q;
+        const int oct = oct_u;
         if (ok && oct < noct) {
             const unsigned o = (unsigned)(off + oct * dOct) * 2u;
-            *reinterpret_cast<uint4*>(bhi + o) = make_uint4(h0[0], h1[0], h0[1], h1[1]);
-            *reinterpret_cast<uint4*>(blo + o) = make_uint4(l0[0], l1[0], l0[1], l1[1]);
+            uint4 uh = make_uint4(h0[0], h1[0], h0[1], h1[1]), ul = make_uint4(l0[0], l1[0], l0[1], l1[1]);
+            if (app) {
+                if (p.app_word == 1) { uh.y = app_h; ul.y = app_l; }
+                else if (p.app_word == 2) { uh.z = app_h; ul.z = app_l; }
+                else { uh.w = app_h; ul.w = app_l; }
+            }
+            *reinterpret_cast<uint4*>(bhi + o) = uh;
+            *reinterpret_cast<uint4*>(blo + o) = ul;
         }
     };
     // accumulator sets A, B (two sets of pixels) -> stores; `off`: element offset of THIS lane's pixel (set A's for q even,
     // set B's for q odd) relative to image img0, octet 0; `ok`: the lane's pixel exists
-    auto emit_t = [&](const f32x4 (&A)[NT], const f32x4 (&B)[NT], int off, bool ok, auto POST) {
+    auto emit_t = [&](const f32x4 (&A)[NT], const f32x4 (&B)[NT], int off, bool ok, int apix, unsigned app_h, unsigned app_l, auto POST) {
         if constexpr (decltype(POST)::value) asm volatile("; epilogue stores, second affine");
         else asm volatile("; epilogue stores");
 #pragma unroll
@@ -574,13 +601,13 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
             float a[4], b[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { a[r] = act1(A[n][r], e, r, POST); b[r] = act1(B[n][r], e, r, POST); }
-            store_unit(n, a, b, off, ok);
+            store_unit(n, a, b, off, ok, apix, app_h, app_l);
             __builtin_amdgcn_sched_barrier(0);   // one N-tile at a time
         }
     };
-    auto emit = [&](const f32x4 (&A)[NT], const f32x4 (&B)[NT], int off, bool ok) {
-        if (p.post_affine) emit_t(A, B, off, ok, std::true_type{});
-        else emit_t(A, B, off, ok, std::false_type{});
+    auto emit = [&](const f32x4 (&A)[NT], const f32x4 (&B)[NT], int off, bool ok, int apix, unsigned app_h, unsigned app_l) {
+        if (p.post_affine) emit_t(A, B, off, ok, apix, app_h, app_l, std::true_type{});
+        else emit_t(A, B, off, ok, apix, app_h, app_l, std::false_type{});
     };
     // the same with a fused 2 x 2 max-pool: set A = the pooled row of M-tiles (R0, R1), set B of (R2, R3); rows are vertical
     // neighbours, pixels li, li^1 horizontal ones; both lanes of a pixel pair hold the pooled value, the even one stores it
@@ -603,29 +630,42 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
                 a[r] = fmaxf(va, sa);
                 b[r] = fmaxf(vb, sb);
             }
-            store_unit(n, a, b, off, ok);
+            store_unit(n, a, b, off, ok, -1, 0u, 0u);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     // element offset (relative to image img0) of the image M-tile t's column i belongs to, and the tile-relative (y, x) of
     // that pixel; -1: no such image
+    const int dImgPix = p.outH * p.outW;   // pixels per output image: the appended tensor is indexed by pixel
+    int app_img = 0;                       // (set by pix_off: pixel index of the lane's image inside the appended tensor)
     auto pix_off = [&](int t, int i, int& y_tile, int& x_tile) {
         const int ig = t >> p.th_log2;
         y_tile = y0 + (t & (TH - 1));
         x_tile = x0 + (i & (TWm - 1));
         const int irel = ig * p.nimg_m + (i >> p.twm_log2);
+        if constexpr (kApp) app_img = irel * dImgPix;
         return img0 + irel < p.B ? irel * dImg : -1;
     };
     if constexpr (NPH == 4) {
         // output row 2y+pu of M-tile row y: its 32 pixels 2x+pv come from phases (pu, 0) = set A and (pu, 1) = set B
+        int ibs[KMT], pixs[KMT][2], apx[KMT][2];
+        unsigned aph[KMT][2], apl[KMT][2];
 #pragma unroll
         for (int m = 0; m < KMT; ++m) {
             int yt, xt;
-            const int ib = pix_off(wave * KMT + m, li, yt, xt);
+            ibs[m] = pix_off(wave * KMT + m, li, yt, xt);
+#pragma unroll
+            for (int pu = 0; pu < 2; ++pu) {
+                pixs[m][pu] = (yt * 2 + pu) * p.outW + xt * 2 + (setB ? 1 : 0);
+                apx[m][pu] = ibs[m] >= 0 ? app_img + pixs[m][pu] : -1;
+                app_load(apx[m][pu], aph[m][pu], apl[m][pu]);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < KMT; ++m)
 #pragma unroll
             for (int pu = 0; pu < 2; ++pu)
-                emit(accs[pu * 2 + 0][m], accs[pu * 2 + 1][m], ib + ((yt * 2 + pu) * p.outW + xt * 2 + (setB ? 1 : 0)) * dPix, ib >= 0);
-        }
+                emit(accs[pu * 2 + 0][m], accs[pu * 2 + 1][m], ibs[m] + pixs[m][pu] * dPix, ibs[m] >= 0, apx[m][pu], aph[m][pu], apl[m][pu]);
     } else if (p.pool) {
         static_assert(NPH == 4 || KMT == 4, "the pooled epilogue pairs the two pooled rows of a wave");
         int yt, xt;
@@ -642,7 +682,11 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
         for (int m = 0; m < KMT; m += 2) {
             int yt, xt;
             const int ib = pix_off(wave * KMT + m + (setB ? 1 : 0), li, yt, xt);
-            emit(accs[0][m], accs[0][m + 1], ib + ((yt * om + ph.oy_off) * p.outW + xt * om + ph.ox_off) * dPix, ib >= 0);
+            const int pix = (yt * om + ph.oy_off) * p.outW + xt * om + ph.ox_off;
+            const int apix = ib >= 0 ? app_img + pix : -1;
+            unsigned ah, al;
+            app_load(apix, ah, al);
+            emit(accs[0][m], accs[0][m + 1], ib + pix * dPix, ib >= 0, apix, ah, al);
         }
     }
     if (vmax >= 0x476a6000u) atomicOr(p.overflow_flag, 1);   // |v| >= 60000, infinity or NaN: binary16 range exceeded, the host reports it
@@ -727,10 +771,34 @@ __global__ void __launch_bounds__(256) split_f32_kernel(const float* __restrict_
         lo[e] = (_Float16)(v - (float)h);
     }
 }
+// the compact form for the dense-K first layer and the raw-skip append: [pixel]{hi[CW] | lo[CW]}
+template <int CW>
+__global__ void __launch_bounds__(256) split_f32_compact_kernel(const float* __restrict__ x, size_t npix, int C, float scale,
+                                                               _Float16* __restrict__ out) {
+    for (size_t px = (size_t)blockIdx.x * blockDim.x + threadIdx.x; px < npix; px += (size_t)gridDim.x * blockDim.x) {
+        _Float16 w[2 * CW];
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+            const float v = c < C ? x[px * C + c] * scale : 0.f;
+            w[c] = (_Float16)v;
+            w[CW + c] = (_Float16)(v - (float)w[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 2 * CW; ++c) out[px * (2 * CW) + c] = w[c];
+    }
+}
 
-hipError_t launch_split_f32(const float* x, size_t npix, int C, int Cs, float scale, _Float16* hi, _Float16* lo,
+hipError_t launch_split_f32(const float* x, size_t npix, int C, int Cs, float scale, _Float16* hi, _Float16* lo, int cw,
                             hipStream_t stream) {
     if (npix == 0) return hipSuccess;
+    if (cw > 0) {
+        const unsigned blocks = (unsigned)((npix + 255) / 256 < 256 * 16 ? (npix + 255) / 256 : 256 * 16);
+        if (cw == 1) hipLaunchKernelGGL(split_f32_compact_kernel<1>, dim3(blocks), dim3(256), 0, stream, x, npix, C, scale, hi);
+        else if (cw == 2) hipLaunchKernelGGL(split_f32_compact_kernel<2>, dim3(blocks), dim3(256), 0, stream, x, npix, C, scale, hi);
+        else if (cw == 4) hipLaunchKernelGGL(split_f32_compact_kernel<4>, dim3(blocks), dim3(256), 0, stream, x, npix, C, scale, hi);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     const size_t total = npix * (size_t)Cs;
     const unsigned blocks = (unsigned)((total + 255) / 256 < 256 * 16 ? (total + 255) / 256 : 256 * 16);
     hipLaunchKernelGGL(split_f32_kernel, dim3(blocks), dim3(256), 0, stream, x, npix, C, Cs, scale, hi, lo);
@@ -739,13 +807,16 @@ hipError_t launch_split_f32(const float* x, size_t npix, int C, int Cs, float sc
 
 // ------------------------------------------------------------------------------------------------------------
 // PI2D.getPatch + per-tile normalisation + batch fill (reference PartitionOfImage.py:58-63,77-82, UnMicst1-5.py:700-702)
-// written straight into the (hi, lo) binary16 input planes of the first convolution (channels padded to Cs = 8):
-// one thread per tile pixel, two 16-byte stores.  Same float64 arithmetic as gather_normalise_kernel.
+// written straight into the (hi, lo) binary16 input planes of the first convolution (channels padded to Cs = 8) -- or, CW > 0,
+// into the compact form [pixel]{hi[CW] | lo[CW]} the dense-K first layer and the raw-skip append read (8 bytes per pixel
+// instead of 32 for a two-channel input).  One thread per tile pixel.  Same float64 arithmetic as gather_normalise_kernel.
 // ------------------------------------------------------------------------------------------------------------
+template <int CW>
 __global__ void __launch_bounds__(256) gather_split_kernel(const double* __restrict__ image, int C_img, int band_row0,
                                                           int band_rows, TileGeom g, int Cn, double mean, double stdv,
                                                           int tile0, int ntiles, float scale, uint4* __restrict__ hi,
                                                           uint4* __restrict__ lo) {
+    constexpr int NC = CW > 0 ? CW : 8;
     const size_t total = (size_t)ntiles * g.P * g.P;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(e % g.P);
@@ -755,9 +826,11 @@ __global__ void __launch_bounds__(256) gather_split_kernel(const double* __restr
         const int pr = t / g.npc, pc = t - pr * g.npc;
         const int iy = pr * g.sub + y - g.margin, ix = pc * g.sub + x - g.margin;
         const bool inside = iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
-        union { _Float16 h[8]; uint4 u; } vh, vl;
+        union { _Float16 h[8]; uint4 u; uint2 u2; unsigned u1; } vh, vl;
+        vh.u = make_uint4(0, 0, 0, 0);
+        vl.u = make_uint4(0, 0, 0, 0);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < NC; ++c) {
             float f = 0.f;
             if (c < Cn) {
                 double v = 0.0;
@@ -767,20 +840,36 @@ __global__ void __launch_bounds__(256) gather_split_kernel(const double* __restr
             vh.h[c] = (_Float16)f;
             vl.h[c] = (_Float16)(f - (float)vh.h[c]);
         }
-        hi[e] = vh.u;
-        lo[e] = vl.u;
+        if constexpr (CW == 0) {
+            hi[e] = vh.u;
+            lo[e] = vl.u;
+        } else if constexpr (CW == 1) {
+            reinterpret_cast<unsigned*>(hi)[e] = (vh.u1 & 0xffffu) | (vl.u1 << 16);
+        } else if constexpr (CW == 2) {
+            reinterpret_cast<uint2*>(hi)[e] = make_uint2(vh.u1, vl.u1);
+        } else {
+            hi[e] = make_uint4(vh.u2.x, vh.u2.y, vl.u2.x, vl.u2.y);
+        }
     }
 }
 
 hipError_t launch_gather_split(const double* image, int C_img, int band_row0, int band_rows, const TileGeom& g, int Cn,
-                               double mean, double stdv, int tile0, int ntiles, float scale, _Float16* hi, _Float16* lo,
+                               double mean, double stdv, int tile0, int ntiles, float scale, _Float16* hi, _Float16* lo, int cw,
                                hipStream_t stream) {
     if (ntiles <= 0) return hipSuccess;
-    if (Cn > 8) return hipErrorInvalidValue;
+    if (Cn > 8 || (cw > 0 && Cn > cw)) return hipErrorInvalidValue;
     const size_t total = (size_t)ntiles * g.P * g.P;
     const unsigned blocks = (unsigned)((total + 255) / 256 < 256 * 16 ? (total + 255) / 256 : 256 * 16);
-    hipLaunchKernelGGL(gather_split_kernel, dim3(blocks), dim3(256), 0, stream, image, C_img, band_row0, band_rows, g, Cn,
-                       mean, stdv, tile0, ntiles, scale, reinterpret_cast<uint4*>(hi), reinterpret_cast<uint4*>(lo));
+    uint4* const h4 = reinterpret_cast<uint4*>(hi);
+    uint4* const l4 = reinterpret_cast<uint4*>(lo);
+#define UMX_GS(CWV) hipLaunchKernelGGL(gather_split_kernel<CWV>, dim3(blocks), dim3(256), 0, stream, image, C_img, band_row0, band_rows, g, \
+                                       Cn, mean, stdv, tile0, ntiles, scale, h4, l4)
+    if (cw == 0) UMX_GS(0);
+    else if (cw == 1) UMX_GS(1);
+    else if (cw == 2) UMX_GS(2);
+    else if (cw == 4) UMX_GS(4);
+    else return hipErrorInvalidValue;
+#undef UMX_GS
     return hipGetLastError();
 }
 

@@ -1,7 +1,6 @@
 // First down-sampling layer of the split-precision plan for gfx950 (MI355X, CDNA4): conv ks x ks (main + shortcut filter
 // summed) -> BN affine -> (Leaky)ReLU [-> BN affine, legacy graph] -> 2 x 2 max-pool (reference UnMicst1-5.py:83-118,
-// UnMicst.py:80-104), optionally with PI2D.getPatch + the per-tile normalisation fused into its load
-// (PartitionOfImage.py:58-63,77-82, UnMicst1-5.py:700-702).
+// UnMicst.py:80-104).
 //
 // Why a kernel of its own.  conv_f16x3 spends one (tap, octet) pair = 8 K-slots per tap on an input that has 1-2 real
 // channels: the duo models' first layer runs 3 k-steps of 32 for K = 18 real values, streams its weights through LDS per
@@ -25,7 +24,7 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int NT, int CW, int NKS, bool IMG>
+template <int NT, int CW, int NKS>
 __global__ void __launch_bounds__(256, 2) conv_first(const FirstParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TPL = 8 / CW;   // taps per lane and k-step
@@ -80,34 +79,22 @@ __global__ void __launch_bounds__(256, 2) conv_first(const FirstParams p) {
         const int hx = hp - hy * p.hw;
         const int ty = y0 + hy - pad, tx = x0 + hx - pad;
         const bool in = (unsigned)ty < (unsigned)P && (unsigned)tx < (unsigned)P;
-        _Float16 vh[CW], vl[CW];
+        typedef unsigned uvec __attribute__((ext_vector_type(CW)));   // 4 * CW bytes: hi[CW] | lo[CW]
+        uvec w;
 #pragma unroll
-        for (int c = 0; c < CW; ++c) { vh[c] = (_Float16)0.f; vl[c] = (_Float16)0.f; }
+        for (int c = 0; c < CW; ++c) w[c] = 0u;
         if (in) {
-            if constexpr (IMG) {
-                // PI2D.getPatch on the zero-padded canvas + (v - mean) / std in float64, as gather_split_kernel
-                const int t = p.tile0 + img;
-                const int pr = t / p.g.npc, pc = t - pr * p.g.npc;
-                const int iy = pr * p.g.sub + ty - p.g.margin, ix = pc * p.g.sub + tx - p.g.margin;
-                const bool inside = iy >= 0 && iy < p.g.H && ix >= 0 && ix < p.g.W;
-#pragma unroll
-                for (int c = 0; c < CW; ++c)
-                    if (c < p.Ci) {
-                        double v = 0.0;
-                        if (inside) v = p.image[((size_t)(p.C_img == 1 ? 0 : c) * p.band_rows + (iy - p.band_row0)) * p.g.W + ix];
-                        const float f = (float)((v - p.mean) / p.stdv) * p.in_scale;
-                        vh[c] = (_Float16)f;
-                        vl[c] = (_Float16)(f - (float)vh[c]);
-                    }
+            const size_t px = ((size_t)img * P + ty) * P + tx;
+            if (p.src_c) {   // compact source: already this kernel's pixel format
+                w = *reinterpret_cast<const uvec*>(p.src_c + px * PXB);
             } else {
-                const size_t e = (((size_t)img * P + ty) * P + tx) * 8;
+                _Float16 v[2 * CW];
 #pragma unroll
-                for (int c = 0; c < CW; ++c) { vh[c] = p.src_hi[e + c]; vl[c] = p.src_lo[e + c]; }
+                for (int c = 0; c < CW; ++c) { v[c] = p.src_hi[px * 8 + c]; v[CW + c] = p.src_lo[px * 8 + c]; }
+                __builtin_memcpy(&w, v, sizeof w);
             }
         }
-        _Float16* const d = reinterpret_cast<_Float16*>(smem + hp * PXB);
-#pragma unroll
-        for (int c = 0; c < CW; ++c) { d[c] = vh[c]; d[CW + c] = vl[c]; }
+        *reinterpret_cast<uvec*>(smem + hp * PXB) = w;
     }
     __syncthreads();
 
@@ -219,8 +206,7 @@ __global__ void __launch_bounds__(256, 2) conv_first(const FirstParams p) {
 template <int NT, int CW, int NKS>
 static hipError_t launch_first_k(const FirstParams& p, hipStream_t stream) {
     const dim3 grid((unsigned)(p.B * (p.P >> 4) * (p.P >> p.rw_log2)));
-    if (p.image) hipLaunchKernelGGL((conv_first<NT, CW, NKS, true>), grid, dim3(256), (size_t)p.lds_bytes, stream, p);
-    else hipLaunchKernelGGL((conv_first<NT, CW, NKS, false>), grid, dim3(256), (size_t)p.lds_bytes, stream, p);
+    hipLaunchKernelGGL((conv_first<NT, CW, NKS>), grid, dim3(256), (size_t)p.lds_bytes, stream, p);
     return hipGetLastError();
 }
 

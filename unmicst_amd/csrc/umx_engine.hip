@@ -89,8 +89,9 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
         const Buffer& b0 = cur_bufs(ctx)[0];
         if (ctx->site_split < 0) ctx->site_split = site_of(ctx, "input.split", "split_f32");
         ProfScope ps(ctx, ctx->site_split, 0.0, (double)ns * b0.S * b0.S * (4.0 * b0.C + 4.0 * b0.Cs));
+        _Float16* const chi = ctx->in_cw ? reinterpret_cast<_Float16*>(b0.d) + (size_t)k0 * b0.S * b0.S * 2 * ctx->in_cw : hi_at(b0);
         HIP_TRY(ctx, launch_split_f32(tiles + (size_t)k0 * b0.floats_per_tile, (size_t)ns * b0.S * b0.S, b0.C, b0.Cs,
-                                      std::ldexp(1.f, ctx->act_shift), hi_at(b0), lo_at(b0), run_stream(ctx)));
+                                      std::ldexp(1.f, ctx->act_shift), chi, lo_at(b0), ctx->in_cw, run_stream(ctx)));
         return UMX_OK;
     }
     if (L.head) {
@@ -118,6 +119,17 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
     if (p.head_K > 0) p.probs = probs + (size_t)k0 * L.H * L.W * p.head_K;   // fused softmax head
     else if (db.as_f32) p.dst_f32 = db.d + (size_t)k0 * db.floats_per_tile;
     else { p.dst_hi = hi_at(db); p.dst_lo = lo_at(db); p.dst_planar = db.planar ? 1 : 0; }
+    if (L.app_src >= 0) {   // the raw-input skip rides in the spare channels of this launch's output (Launch::app_src)
+        const Buffer& ab = cur_bufs(ctx)[L.app_src];
+        if (L.app_src != 0 || !ctx->in_cw) return fail(ctx, UMX_ERR_INVALID, "internal: the appended tensor is not in the compact form");
+        p.app_c = reinterpret_cast<const unsigned char*>(ab.d) + (size_t)k0 * ab.S * ab.S * 4 * ctx->in_cw;
+        p.app_cw = ctx->in_cw;
+        p.app_oct = L.app_c0 / 8;                 // the stored octet ...
+        p.app_word = (L.app_c0 % 8) / 2;          // ... and its 32-bit word the two appended binary16 values fill
+    }
+    for (int gi = 0; gi < L.ngroups; ++gi)
+        if (L.g[gi].src == 0 && ctx->in_cw && !L.use_first)
+            return fail(ctx, UMX_ERR_INVALID, "internal: %s reads the compact input tiles through the generic kernel", L.name.c_str());
     char kn[48];
     // the instantiation as rocprofv3 names it (<NT, KMT, NPH>): bench.py groups the timed sites by kernel
     snprintf(kn, sizeof kn, "conv_f16x3<%d, %d, %d, false, %d>", L.nt16, p.kmt, p.fused_phases ? 4 : 1, p.maxp);   // as rocprofv3 prints it
@@ -148,6 +160,7 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
         const Buffer& sb = cur_bufs(ctx)[0];
         f.B = ns;
         f.src_hi = hi_at(sb); f.src_lo = lo_at(sb);
+        f.src_c = ctx->in_cw ? reinterpret_cast<const unsigned char*>(sb.d) + (size_t)k0 * sb.S * sb.S * 4 * ctx->in_cw : nullptr;
         f.dst_hi = p.dst_hi; f.dst_lo = p.dst_lo; f.dst_planar = p.dst_planar;
         f.overflow_flag = p.overflow_flag;
         snprintf(kn, sizeof kn, "conv_first<%d, %d, %d, false>", f.NT, f.CW, f.NKS);
@@ -269,11 +282,11 @@ int tiles_range(umx_ctx* ctx, const double* image_dev, int C_img, const TileGeom
                                                                 : cur_bufs(ctx)[0].d;
         {
             ProfScope ps(ctx, ctx->site_gather, 0.0,
-                         (double)nb * g.P * g.P * (8.0 + (direct16 ? 32.0 : 4.0 * ctx->hp.nChannels)));
+                         (double)nb * g.P * g.P * (8.0 * C_img + (ctx->in_cw ? 4.0 * ctx->in_cw : direct16 ? 32.0 : 4.0 * ctx->hp.nChannels)));
             if (direct16) {   // gather + normalise + (hi, lo) split in one pass
                 const Buffer& b0 = cur_bufs(ctx)[0];
                 HIP_TRY(ctx, launch_gather_split(image_dev, C_img, band_row0, band_rows, g, ctx->hp.nChannels, mean, stdv, t, nb,
-                                                 std::ldexp(1.f, ctx->act_shift), hi_of(b0), lo_of(b0, nb), run_stream(ctx)));
+                                                 std::ldexp(1.f, ctx->act_shift), hi_of(b0), lo_of(b0, nb), ctx->in_cw, run_stream(ctx)));
             } else {
                 HIP_TRY(ctx, launch_gather_normalise(image_dev, C_img, band_row0, band_rows, g, ctx->hp.nChannels, mean, stdv, t,
                                                      nb, tiles32, run_stream(ctx)));
@@ -462,7 +475,10 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
     c->stream = c->own_stream;
 
     struct { std::vector<size_t> buf_floats; std::vector<std::pair<int, int>> buf_geom; size_t pos = 0; } b;
-    build_graph(*hp, weight_blob, &c->plan, &b.buf_floats, &b.buf_geom, &b.pos);
+    // (the raw-skip fold of the split-precision plan: UMX_NO_FOLD=1 keeps the two-group top convolution, for A/B)
+    // and only where the first layer takes the dense-K kernel: the input tiles are then stored once, in the compact form both read)
+    const bool fold = precision == UMX_PREC_F16X3 && conv_first_eligible(*hp) && !getenv("UMX_NO_FOLD");
+    build_graph(*hp, weight_blob, &c->plan, &b.buf_floats, &b.buf_geom, &b.pos, fold);
     if (b.pos != blob_floats) { umx_destroy(ctx.release()); return fail(nullptr, UMX_ERR_BLOB, "internal blob walk mismatch"); }
     c->bufs.resize(b.buf_floats.size());
     auto bail = [&](int code) { std::string m = c->err; umx_destroy(ctx.release()); g_err = m; return code; };
@@ -570,6 +586,12 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
         L.cp.pre_s = L.d_pre_s; L.cp.pre_b = L.d_pre_b; L.cp.post_s = L.d_post_s; L.cp.post_b = L.d_post_b;
     }
     if (f16) c->split_launch.name = "input.split";
+    {   // compact input tiles: the graph folded the raw skip AND the first layer runs on the dense-K kernel
+        bool folded = false, first = false;
+        for (const Launch& L : c->plan) { folded = folded || L.app_src == 0; first = first || L.use_first; }
+        if (folded && !first) { c->err = "internal: raw-skip fold without the dense-K first layer"; return bail(UMX_ERR_INVALID); }
+        if (folded) c->in_cw = c->hp.nChannels == 1 ? 1 : c->hp.nChannels == 2 ? 2 : 4;
+    }
     *out = ctx.release();
     return UMX_OK;
 }

@@ -75,6 +75,7 @@ struct Builder {
     std::vector<size_t> buf_floats;  // per tile
     std::vector<std::pair<int, int>> buf_geom;  // (spatial size, channels) per buffer
 
+    bool fold_top_skip = false;   // split-precision plan: see Launch::app_src
     explicit Builder(const umx_hparams& h, const float* b) : hp(h), blob(b) {}
 
     const float* take(size_t n) {
@@ -263,8 +264,22 @@ struct Builder {
             int cv = new_buf(S2, Cup);
             snprintf(nm, sizeof nm, "lu%d.conv", idx);
             Launch Lc = make(nm, S2, Cup, cv, 0, act);
-            add_conv_group(Lc, ds[idx], w2, 0, Cskip);   // concat3([dsX[index], us]): skip channels first
-            add_conv_group(Lc, us, w2, Cskip, Cup);
+            // Raw-skip fold (top layer of the split-precision plan): the up-sampled tensor has spare stored channels (36 real of
+            // 40), the raw input 1 - 2: the transposed convolution's epilogue writes them there and this convolution reads
+            // [us | skip] as one tensor (filter channels permuted accordingly) -- one operand group, 12 instead of 14 k-steps
+            const bool fold = fold_top_skip && idx == 0 && nx == 0 && Cskip <= 2 && (Cup % 8) != 0 && (Cup % 8) % 2 == 0 &&
+                              (Cup % 8) + Cskip <= 8 && S2 >= 16 && Cup <= 80;   // (<= 5 N-tiles: the kernels that carry the append)
+            if (fold) {
+                Launch& Ltp = plan.back();
+                Ltp.app_src = ds[idx]; Ltp.app_C = Cskip; Ltp.app_c0 = Cup;
+                std::vector<int> cmap(Cup + Cskip);
+                for (int c = 0; c < Cup; ++c) cmap[c] = Cskip + c;
+                for (int c = 0; c < Cskip; ++c) cmap[Cup + c] = c;
+                add_conv_group(Lc, us, w2, 0, Cup + Cskip, nullptr, &cmap);
+            } else {
+                add_conv_group(Lc, ds[idx], w2, 0, Cskip);   // concat3([dsX[index], us]): skip channels first
+                add_conv_group(Lc, us, w2, Cskip, Cup);
+            }
             if (v2) Lc.bn = 1;
             if (v2 && blob) fold_bn(bn, Cup, &Lc.pre_s, &Lc.pre_b);
             finish(Lc);
@@ -309,8 +324,9 @@ struct Builder {
 };
 
 int build_graph(const umx_hparams& hp, const float* blob, std::vector<Launch>* plan, std::vector<size_t>* buf_floats,
-                std::vector<std::pair<int, int>>* buf_geom, size_t* pos) {
+                std::vector<std::pair<int, int>>* buf_geom, size_t* pos, bool fold_top_skip) {
     Builder b(hp, blob);
+    b.fold_top_skip = fold_top_skip;
     const int rc = b.build();
     if (plan) *plan = std::move(b.plan);
     if (buf_floats) *buf_floats = std::move(b.buf_floats);

@@ -47,6 +47,10 @@ struct Launch {
     int H = 0, W = 0, Cout = 0;
     int dst = -1, outH = 0, outW = 0, pool = 0, act = 0;
     std::vector<float> pre_s, pre_b, post_s, post_b;  // size Cout or empty
+    // split-precision plan only: this launch's epilogue also drops `app_C` (<= 2) channels of buffer `app_src` (same pixel grid as
+    // its output) into the spare channels [app_c0, app_c0 + app_C) of its last stored octet -- the raw-input skip of the top
+    // up-layer rides in the up-sampled tensor, so that layer's convolution reads ONE 5-octet tensor instead of 1 + 5 octets
+    int app_src = -1, app_C = 0, app_c0 = 0;
     int bn = 0;               // where the BatchNorm affine sits: 0 none, 1 before the activation (pre_*), 2 after it (post_*)
     int summed_shortcut = 0;  // > 0: a same-source shortcut filter of this size is summed into the main filter (exact algebra)
     // head only
@@ -145,6 +149,8 @@ struct umx_ctx {
                                 // 32 for the two slots of the submit / wait API -- a flag is cleared and read in stream order by
                                 // the call that owns it, never from the host while another call is in flight
     int flag_word = 0;          // the word the launches being enqueued report to
+    int in_cw = 0;              // > 0: the input tiles (buffer 0) are stored in the compact form [pixel]{hi[in_cw] | lo[in_cw]} -- their
+                                // only readers are the dense-K first layer and the raw-skip append of the top transposed convolution
     uint4* d_zeros = nullptr;
     bool head_fused = false;
     Launch split_launch;
@@ -177,13 +183,15 @@ size_t blob_floats_needed(const umx_hparams& hp);
 // builds the launch list and the activation-buffer list (per-tile floats, (spatial size, channels)); blob may be NULL
 // (describe only); *pos = floats of the blob consumed
 int build_graph(const umx_hparams& hp, const float* blob, std::vector<Launch>* plan, std::vector<size_t>* buf_floats,
-                std::vector<std::pair<int, int>>* buf_geom, size_t* pos);
+                std::vector<std::pair<int, int>>* buf_geom, size_t* pos, bool fold_top_skip = false);
 bool conv_geometry(Launch& L, std::string* why);
 
 // ---- umx_plan.hip: split-precision plan of one launch
 int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch* head, std::string* why);
 // dense-K plan of the first down-sampling layer, for a launch plan_f16 has just planned (sets L.use_first when it applies)
 int plan_first(umx_ctx* ctx, Launch& L, int act_shift, std::string* why);
+// the same decision from the hyper-parameters alone (the graph builder folds the raw skip only when the first layer takes this kernel)
+bool conv_first_eligible(const umx_hparams& hp);
 
 // ---- umx_engine.hip
 int dev_alloc(umx_ctx* ctx, void** out, size_t bytes);

@@ -112,6 +112,9 @@ struct HConvParams {
     const uint4* zeros;          // >= 16 bytes of zeros in global memory (source for out-of-image halo slots)
     _Float16* dst_hi;
     _Float16* dst_lo;
+    const unsigned char* app_c;  // non-NULL: word `app_word` (2 channels) of the stored octet `app_oct` is replaced by the channels of
+    int app_cw;                  // this compact tensor ([pixel]{hi[app_cw] | lo[app_cw]}, app_cw = 1 or 2; the output's pixel grid):
+    int app_oct, app_word;       // the raw-input skip rides in the spare channels of the up-sampled tensor
     float* dst_f32;              // non-NULL: write fp32 NHWC [..,Cout] instead of the (hi, lo) pair
     float* probs;                // head_K > 0: fused 1x1 conv + BN affine + softmax head, probabilities NHWC [..,head_K]
     int head_K;                  // (needs nblocks == 1: every channel of a pixel in one workgroup)
@@ -142,11 +145,8 @@ struct TileGeom {
 struct FirstParams {
     const _Float16* src_hi;   // the input tiles as (hi, lo) binary16 NHWC planes with 8 stored channels [B,P,P,8] ...
     const _Float16* src_lo;
-    const double* image;      // ... or (non-NULL) the float64 slide band itself: PI2D.getPatch + normalise fused into the load
-    int C_img, band_row0, band_rows, tile0;
-    TileGeom g;
-    double mean, stdv;
-    float in_scale;           // 2^(activation shift)
+    const unsigned char* src_c;   // ... or (non-NULL) in the compact form [B,P,P]{hi[CW] | lo[CW]}: 4 * CW bytes per pixel, exactly
+                                  // the kernel's LDS pixel format (written by the gather / split kernels for this consumer)
     int B, P, Ci;
     int ks, ntaps;            // ks x ks taps, SAME padding
     int NT, CW, NKS;          // N-tiles of 16 output channels; channel slots per tap (1, 2, 4); k-steps (K = ntaps * CW <= 32 * NKS)
@@ -165,11 +165,12 @@ struct FirstParams {
 bool conv_first_supported(int NT, int CW, int NKS);
 hipError_t launch_conv_first(const FirstParams& p, hipStream_t stream);
 
-hipError_t launch_split_f32(const float* x, size_t npix, int C, int Cs, float scale, _Float16* hi, _Float16* lo,
+// (cw > 0: the compact form [pixel]{hi[cw] | lo[cw]} into `hi` instead of the two 8-channel planes)
+hipError_t launch_split_f32(const float* x, size_t npix, int C, int Cs, float scale, _Float16* hi, _Float16* lo, int cw,
                             hipStream_t stream);
 
 hipError_t launch_gather_split(const double* image, int C_img, int band_row0, int band_rows, const TileGeom& g, int Cn,
-                               double mean, double stdv, int tile0, int ntiles, float scale, _Float16* hi, _Float16* lo,
+                               double mean, double stdv, int tile0, int ntiles, float scale, _Float16* hi, _Float16* lo, int cw,
                                hipStream_t stream);
 
 hipError_t launch_gather_normalise(const double* image, int C_img, int band_row0, int band_rows, const TileGeom& g,

@@ -420,6 +420,12 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
 // the input tiles (buffer 0) with <= 4 input channels and <= 80 output channels on tiles of >= 16 x 16 pixels whose taps
 // x channel slots fit two k-steps; everything else stays on conv_f16x3.  Reuses plan_f16's weight shift and epilogue
 // constants, so the two kernels differ only in the summation order inside the (now single) k-step.
+bool conv_first_eligible(const umx_hparams& hp) {
+    if (getenv("UMX_NO_FIRST") || hp.nExtraConvs != 0 || hp.nChannels < 1 || hp.nChannels > 4 || hp.imSize < 16 || hp.nOut0 > 80) return false;
+    const int CW = hp.nChannels == 1 ? 1 : hp.nChannels == 2 ? 2 : 4;
+    return conv_first_supported((hp.nOut0 + 15) / 16, CW, (hp.ks * hp.ks * CW + 31) / 32);
+}
+
 int plan_first(umx_ctx* ctx, Launch& L, int act_shift, std::string* why) {
     (void)why;
     L.use_first = false;
@@ -447,7 +453,6 @@ int plan_first(umx_ctx* ctx, Launch& L, int act_shift, std::string* why) {
     f.hw = (1 << f.rw_log2) + ks - 1;
     f.inv_hw = 1.f / (float)f.hw;
     f.lds_bytes = ((f.hh * f.hw * 4 * CW + 15) & ~15) + 4 * NT * 16 * (int)sizeof(float);
-    f.in_scale = std::ldexp(1.f, act_shift);
     f.act = L.act;
     f.post_affine = h.post_affine;
     f.econst = reinterpret_cast<const float*>(h.econst);
