@@ -95,9 +95,10 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         else {
             for (int maxp : {4, 12}) {
                 if (maxp == 12 && nt16 > 5) break;
-                // (4-5 N-tiles: the third workgroup per CU pays only while the smaller chunks stay few -- ld1.conv, 6 chunks:
-                // -12 %; lu1.conv, 24 chunks: +1 %)
-                const int few = nt16 <= 3 ? 1 << 30 : 8;
+                // (4-5 N-tiles at three workgroups per CU: round 2 kept them to <= 8 chunks -- lu1.conv, 24 chunks, ran 16 % faster
+                // that way but the step did not, at NHWC-era L2 re-fetch rates; with planar activations and the register epilogue
+                // the same-box A/B is 49.32 / 48.99 / 49.06 -> 48.70 / 48.77 / 48.74 ms per step: the rule is gone)
+                const int few = 1 << 30;
                 if (nt16 <= 3 && maxp == 4) attempts.push_back({maxp, nt3, 1 << 30});
                 if (nt16 <= narrow_nt) attempts.push_back({maxp, narrow, few});
                 attempts.push_back({maxp, kMaxLdsPerWG, 1 << 30});
