@@ -164,6 +164,43 @@ __global__ void __launch_bounds__(256, 2) k_wino(const _Float16* src, float* out
     if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = s1.c0 - s0.c0; clk[1] = s1.r0 - s0.r0; }
 }
 
+// ---- Winograd-shaped trip, positions split over the waves: wave w owns positions 4w..4w+3 for 4 patch tiles x 2 channel tiles
+// (48 fragment reads per 96 MFMAs; the output transform then needs one accumulator exchange through LDS per K loop, not per trip)
+__global__ void __launch_bounds__(256, 2) k_wino_split(const _Float16* src, float* out, long long* clk, int iters) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    fill_lds(lds, src);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 acc[4][4][2];
+    for (int p = 0; p < 4; ++p) for (int m = 0; m < 4; ++m) for (int n = 0; n < 2; ++n) acc[p][m][n] = (f32x4){0, 0, 0, 0};
+    const Stamp s0 = stamp();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            __builtin_amdgcn_iglp_opt(0);
+            const _Float16* bp = lds + ((it * 12 + wave * 5 + p * 12) & 31) * 512 + lane * 8;
+            h8 vh[4], vl[4], uh[2], ul[2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { vh[m] = *reinterpret_cast<const h8*>(bp + (2 * m) * 512); vl[m] = *reinterpret_cast<const h8*>(bp + (2 * m + 1) * 512); }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) { uh[n] = *reinterpret_cast<const h8*>(bp + (8 + 2 * n) * 512); ul[n] = *reinterpret_cast<const h8*>(bp + (9 + 2 * n) * 512); }
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    f32x4 c = acc[p][m][n];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh[n], vl[m], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ul[n], vh[m], c, 0, 0, 0);
+                    acc[p][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(uh[n], vh[m], c, 0, 0, 0);
+                }
+        }
+    }
+    const Stamp s1 = stamp();
+    float s = 0;
+    for (int p = 0; p < 4; ++p) for (int m = 0; m < 4; ++m) for (int n = 0; n < 2; ++n) s += acc[p][m][n][0] + acc[p][m][n][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = s1.c0 - s0.c0; clk[1] = s1.r0 - s0.r0; }
+}
+
 template <typename K>
 static void run(const char* name, K kern, int wgs_per_cu, int iters, double mfma_per_trip_per_wave, double flop_per_mfma,
                 const _Float16* src, float* out, long long* clk) {
@@ -208,6 +245,7 @@ int main() {
     for (int wgs = 1; wgs <= 2; ++wgs) {
         run("conv_f16x3<9,4,1>-shaped", k_conv9, wgs, iters / 4, 108, 2.0 * 16 * 16 * 32, src, out, clk);
         run("winograd F(2x2,3x3)-shaped", k_wino, wgs, iters / 4, 96, 2.0 * 16 * 16 * 32, src, out, clk);
+        run("winograd, positions per wave", k_wino_split, wgs, iters / 4, 96, 2.0 * 16 * 16 * 32, src, out, clk);
     }
     return 0;
 }
