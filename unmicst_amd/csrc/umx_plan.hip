@@ -98,7 +98,9 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                 // (4-5 N-tiles at three workgroups per CU: round 2 kept them to <= 8 chunks -- lu1.conv, 24 chunks, ran 16 % faster
                 // that way but the step did not, at NHWC-era L2 re-fetch rates; with planar activations and the register epilogue
                 // the same-box A/B is 49.32 / 48.99 / 49.06 -> 48.70 / 48.77 / 48.74 ms per step: the rule is gone)
-                const int few = 1 << 30;
+                // ... for plain convolutions.  A per-phase transposed convolution keeps it: the solo model's lu2.convT (8 x 8 input,
+                // 320 -> 160 channels, 40 chunks) ran 1.84 -> 4.35 ms per launch at the tighter budget.
+                const int few = L.nphase == 1 ? 1 << 30 : 8;   // (same-box A/B: solo 81.2 -> 83.1 k tiles/s, synthetic-256 19.12 -> 19.26 k)
                 if (nt16 <= 3 && maxp == 4) attempts.push_back({maxp, nt3, 1 << 30});
                 if (nt16 <= narrow_nt) attempts.push_back({maxp, narrow, few});
                 attempts.push_back({maxp, kMaxLdsPerWG, 1 << 30});
