@@ -223,8 +223,12 @@ typedef struct umx_prof_entry {
     double bytes_per_launch_sum;  /* sum over launches of compulsory HBM bytes */
     double exec_flops_sum;        /* sum over launches of FLOPs issued to the matrix cores (padding and, for
                                      UMX_PREC_F16X3, the three products per fp32 product included) */
+    int64_t launches_seen;        /* every launch of the site while profiling was on; `launches` and the sums above cover the
+                                     launches that were bracketed by events (all of them unless sampling) */
 } umx_prof_entry;
-UMX_API int umx_profile_enable(umx_ctx* ctx, int on);          /* on: bracket every launch with events; resets counters */
+/* on = 0: off; 1: bracket every launch with two events; N >= 2: bracket every N-th launch of each site (two events per launch
+ * cost the synthetic-256 step 1.1 % -- profiles/r03/prof_event_overhead.txt -- so bench.py samples).  Resets the counters. */
+UMX_API int umx_profile_enable(umx_ctx* ctx, int on);
 UMX_API int umx_profile_read(umx_ctx* ctx, umx_prof_entry* entries, int max_entries, int* n_entries);
 
 /* Host-side helpers exported for the CPU test-suite (no GPU needed): the double->float16 round-to-nearest-even

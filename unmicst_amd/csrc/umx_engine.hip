@@ -749,8 +749,8 @@ int umx_profile_enable(umx_ctx* ctx, int on) {
     if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
     int rc = prof_fold(ctx);
     if (rc) return rc;
-    ctx->prof = on != 0;
-    for (auto& s : ctx->sites) { s.launches = 0; s.total_ms = 0; s.flops = 0; s.bytes = 0; s.exec = 0; }
+    ctx->prof = on < 0 ? 0 : on;
+    for (auto& s : ctx->sites) { s.launches = 0; s.seen = 0; s.total_ms = 0; s.flops = 0; s.bytes = 0; s.exec = 0; }
     return UMX_OK;
 }
 
@@ -771,6 +771,7 @@ int umx_profile_read(umx_ctx* ctx, umx_prof_entry* entries, int max_entries, int
             e.flops_per_launch_sum = s.flops;
             e.bytes_per_launch_sum = s.bytes;
             e.exec_flops_sum = s.exec;
+            e.launches_seen = s.seen;
         }
         ++n;
     }

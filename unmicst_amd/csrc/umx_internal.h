@@ -85,7 +85,7 @@ struct Buffer {
 
 struct ProfSite {
     std::string name, kernel;
-    int64_t launches = 0;
+    int64_t launches = 0, seen = 0;
     double total_ms = 0.0, flops = 0.0, bytes = 0.0, exec = 0.0;
 };
 
@@ -136,7 +136,7 @@ struct umx_ctx {
     float* d_io_tiles = nullptr; size_t io_tiles_cap = 0;
     float* d_io_probs = nullptr; size_t io_probs_cap = 0;
     // profiling
-    bool prof = false;
+    int prof = 0;               // 0 off, 1 every launch, N >= 2 every N-th launch of a site bracketed by events
     std::vector<ProfSite> sites;
     std::vector<PendingEvent> pending;
     std::vector<hipEvent_t> free_events;
@@ -218,6 +218,8 @@ struct ProfScope {
     bool on;
     ProfScope(umx_ctx* c, int s, double flops, double bytes, double exec = 0.0) : ctx(c), site(s), on(c->prof && s >= 0) {
         if (!on) return;
+        const int64_t k = ctx->sites[site].seen++;
+        if (ctx->prof > 1 && k % ctx->prof != 0) { on = false; return; }   // sampling: this launch runs unbracketed
         auto get = [&](hipEvent_t* e) {
             if (!ctx->free_events.empty()) { *e = ctx->free_events.back(); ctx->free_events.pop_back(); }
             else if (hipEventCreate(e) != hipSuccess) *e = nullptr;

@@ -52,7 +52,7 @@ class _Options(ctypes.Structure):
 class ProfEntry(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 48), ("kernel", ctypes.c_char * 48), ("launches", ctypes.c_int64),
                 ("total_ms", ctypes.c_double), ("flops", ctypes.c_double), ("bytes", ctypes.c_double),
-                ("exec_flops", ctypes.c_double)]
+                ("exec_flops", ctypes.c_double), ("launches_seen", ctypes.c_int64)]
 
 
 _lib = None
@@ -469,8 +469,9 @@ class Engine:
                                            y1, ctypes.c_void_p(out_ptr)))
 
     # -- profiling
-    def profile_enable(self, on: bool) -> None:
-        self._check(self._L.umx_profile_enable(self._ctx, 1 if on else 0))
+    def profile_enable(self, on) -> None:
+        """False / 0: off; True / 1: two HIP events around every launch; N >= 2: around every N-th launch of each site."""
+        self._check(self._L.umx_profile_enable(self._ctx, int(on)))
 
     def profile_read(self) -> List[dict]:
         n = ctypes.c_int()
@@ -481,5 +482,5 @@ class Engine:
             e = arr[i]
             out.append({"name": e.name.decode(), "kernel": e.kernel.decode(), "launches": int(e.launches),
                         "total_ms": float(e.total_ms), "flops": float(e.flops), "bytes": float(e.bytes),
-                        "exec_flops": float(e.exec_flops)})
+                        "exec_flops": float(e.exec_flops), "seen": int(e.launches_seen)})
         return out
