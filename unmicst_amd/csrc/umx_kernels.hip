@@ -561,12 +561,37 @@ hipError_t launch_stitch(const float* probs, int tpr0, int tpr1, const TileGeom&
 
 template <typename T>
 __global__ void __launch_bounds__(256) minmax_kernel(const T* __restrict__ x, size_t n, unsigned* __restrict__ mm /*[min,max]*/) {
+    // 16-byte loads over the aligned middle of the range (a 2-byte load per lane moved 89 GB/s: 0.38 ms per 16.8 M-pixel slab),
+    // scalar loads for the unaligned head and the tail
+    constexpr int PER = 16 / (int)sizeof(T);
     unsigned lo = 0xFFFFFFFFu, hi = 0u;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const unsigned v = x[i];
-        lo = min(lo, v);
-        hi = max(hi, v);
+    const size_t addr = reinterpret_cast<size_t>(x);
+    size_t head = ((16 - (addr & 15)) & 15) / sizeof(T);
+    if (head > n) head = n;
+    const size_t nvec = (n - head) / PER;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (size_t)gridDim.x * blockDim.x;
+    const uint4* const xv = reinterpret_cast<const uint4*>(x + head);
+    for (size_t i = gid; i < nvec; i += gsz) {
+        const uint4 w = xv[i];
+        const unsigned ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (sizeof(T) == 2) {
+                const unsigned a = ws[k] & 0xFFFFu, b = ws[k] >> 16;
+                lo = min(lo, min(a, b));
+                hi = max(hi, max(a, b));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned a = (ws[k] >> (8 * j)) & 0xFFu;
+                    lo = min(lo, a);
+                    hi = max(hi, a);
+                }
+            }
+        }
     }
+    for (size_t i = gid; i < head; i += gsz) { const unsigned v = x[i]; lo = min(lo, v); hi = max(hi, v); }
+    for (size_t i = head + nvec * PER + gid; i < n; i += gsz) { const unsigned v = x[i]; lo = min(lo, v); hi = max(hi, v); }
     for (int o = 32; o > 0; o >>= 1) {
         lo = min(lo, (unsigned)__shfl_xor((int)lo, o));
         hi = max(hi, (unsigned)__shfl_xor((int)hi, o));
@@ -608,7 +633,7 @@ hipError_t launch_minmax_init(unsigned* mm, hipStream_t stream) {
 // mm = (min(mm[0], min x), max(mm[1], max x)): accumulates, so that a plane can be reduced slab by slab as it is uploaded
 hipError_t launch_minmax(const void* raw, int bits, size_t n, unsigned* mm, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
+    const unsigned blocks = (unsigned)std::min<size_t>((n / 8 + 255) / 256 + 1, 256 * 8);
     if (bits == 16)
         hipLaunchKernelGGL(minmax_kernel<unsigned short>, dim3(blocks), dim3(256), 0, stream, (const unsigned short*)raw, n, mm);
     else if (bits == 8)
