@@ -10,9 +10,10 @@ pytestmark = pytest.mark.gpu
 
 TILE_TOL = 1e-4
 
-# a v2 graph large enough to have octet-planar tensors (>= 16 x 16 pixels, > 8 stored channels), a fused-phase and a per-phase
-# transposed convolution (<= 80 / > 80 output channels), the dense-K first layer, a fused head and k-step carries
-HP = model.HParams(model.GRAPH_V2, 64, 2, 3, 24, 3, 3, 0, 2)
+# a v2 graph large enough to have octet-planar tensors (>= 16 x 16 pixels, > 8 stored channels), fused-phase transposed
+# convolutions of 2 and 4 N-tiles and a per-phase one (28 / 56 / 112 output channels), the dense-K first layer, the raw-skip
+# fold with compact input tiles (28 real of 32 stored channels at the top), a fused head and k-step carries
+HP = model.HParams(model.GRAPH_V2, 64, 2, 3, 28, 3, 3, 0, 2)
 
 SWITCHES = [
     {},                                     # the default plan (reference for the scheduling-only switches)
@@ -22,7 +23,9 @@ SWITCHES = [
     {"UMX_NO_KSTEP_CARRY": "1"},            # k-steps padded per chunk instead of carried into the next chunk
     {"UMX_NO_FUSED_HEAD": "1"},             # 1x1 head + softmax as its own kernel on an fp32 tensor
     {"UMX_NO_FUSED_CONVT": "1"},            # transposed convolutions one sub-pixel phase per workgroup
-    {"UMX_NO_FIRST": "1"},                  # first layer on conv_f16x3 instead of the dense-K kernel
+    {"UMX_NO_FIRST": "1"},                  # first layer on conv_f16x3 instead of the dense-K kernel (and therefore no fold)
+    {"UMX_NO_FOLD": "1"},                   # two-group top convolution, input tiles as (hi, lo) planes
+    {"UMX_NO_CONVT3": "1"},                 # narrow fused transposed convolution at two workgroups per CU
     {"UMX_PLAN_OVERRIDE": "lu0.conv:3:2,ld1.conv:1:1:12"},   # forced (octets per chunk, k-steps per stage[, piece-index array])
     {"UMX_PRECISION": "f32"},               # default precision from the environment
     {"UMX_ACT_SHIFT": "2"},                 # activations stored times 4
