@@ -51,7 +51,11 @@ __device__ __forceinline__ void static_for(F&& f) {   // compile-time loop: the 
 constexpr int conv_f16x3_waves(int NT, int KMT, int NPH, int MAXP) {   // resident waves per SIMD the register budget is set for
     return NPH != 1 ? 2 : (NT <= 3 && MAXP == 4) ? 4 : (NT <= 3 || (NT <= 5 && MAXP == 4)) ? 3 : 2;
 }
-template <int NT, int KMT, int NPH, bool DBG = false, int MAXP = 4>
+// PK = true: the LAST N-tile holds <= 8 real output channels and is packed [w_hi of channels 0..7 | w_lo of channels 0..7] in its
+//       16 rows (one weight image): x_hi and x_lo against it are 2 MFMAs instead of 3 (rows 0..7 collect w_hi.x_hi + w_hi.x_lo,
+//       rows 8..15 w_lo.x_hi + the 2^-22 term w_lo.x_lo the 3-product form drops), and rows j, j + 8 -- lanes l, l + 32 -- are
+//       added once, after the K loop (v_permlane32_swap).  36 channels: 8 MFMAs per (M-tile, k-step) instead of 9, 72: 14 of 15.
+template <int NT, int KMT, int NPH, bool DBG = false, int MAXP = 4, bool PK = false>
 __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) conv_f16x3(const HConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -299,7 +303,7 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
                             // pixels): D[channel][pixel], so a lane ends up with 4 consecutive channels of one pixel
                             f32x4 c = accs[h][m][n];
                             c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[m], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[m], c, 0, 0, 0);
+                            if (!(PK && n == NT - 1)) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[m], c, 0, 0, 0);
                             accs[h][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[m], c, 0, 0, 0);
                         }
                     }
@@ -309,6 +313,18 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
         wq_drain(cur.nk * NT);
         cur = nxt;
         if (DBG && p.dbg) { t_a = __builtin_amdgcn_s_memtime(); t_comp += t_a - t_b; }
+    }
+    if constexpr (PK) {   // packed last N-tile: rows j (w_hi products) += rows j + 8 (w_lo products), i.e. lane l += lane l + 32
+#pragma unroll
+        for (int h = 0; h < NPH; ++h)
+#pragma unroll
+            for (int m = 0; m < KMT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned u = __float_as_uint(accs[h][m][NT - 1][r]);
+                    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // {lanes 0..31 twice, lanes 32..63 twice}
+                    accs[h][m][NT - 1][r] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                }
     }
     struct DbgOut {   // written when the kernel returns (both epilogue paths)
         const HConvParams& p; long long t_in, t_pro, t_wait, t_comp, t_epi; int tid; const long long& t_vm; const long long& t_iss;
@@ -692,17 +708,17 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
     if (vmax >= 0x476a6000u) atomicOr(p.overflow_flag, 1);   // |v| >= 60000, infinity or NaN: binary16 range exceeded, the host reports it
 }
 
-template <int NT, int KMT, int NPH, bool DBG, int MAXP>
+template <int NT, int KMT, int NPH, bool DBG, int MAXP, bool PK = false>
 static hipError_t launch_h_k(const HConvParams& p, hipStream_t stream) {
     const int img_groups = (p.B + p.imgs - 1) / p.imgs;
     dim3 grid((unsigned)(img_groups * p.tiles_y * p.tiles_x), (unsigned)p.nblocks, (unsigned)(NPH == 1 ? p.nphase : 1));
     const size_t lds = (size_t)p.lds_bytes;
-    const void* kern = reinterpret_cast<const void*>(conv_f16x3<NT, KMT, NPH, DBG, MAXP>);
+    const void* kern = reinterpret_cast<const void*>(conv_f16x3<NT, KMT, NPH, DBG, MAXP, PK>);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((conv_f16x3<NT, KMT, NPH, DBG, MAXP>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_f16x3<NT, KMT, NPH, DBG, MAXP, PK>), grid, dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -711,6 +727,15 @@ template <int NT, int KMT, int NPH>
 static hipError_t launch_h_nt(const HConvParams& p, hipStream_t stream) {
     constexpr bool has4 = true, has12 = NT <= 5 && !(NPH == 4 && NT > 3);
     if (p.maxp != 4 && p.maxp != 12) return hipErrorInvalidValue;
+    if (p.pk) {   // packed last N-tile: the narrow kernels only (the planner asks for it at <= 5 N-tiles), no stamped twins
+        if constexpr (NT >= 2 && NT <= 5 && NPH == 1) {
+            if constexpr (has12) {
+                if (p.maxp == 12) return launch_h_k<NT, KMT, NPH, false, 12, true>(p, stream);
+            }
+            if (p.maxp == 4) return launch_h_k<NT, KMT, NPH, false, 4, true>(p, stream);
+        }
+        return hipErrorInvalidValue;
+    }
     if constexpr (has12) {
         if (p.maxp == 12) {
             if constexpr (NT == 3 && NPH == 4) {   // (stamped twin of the top transposed convolution)

@@ -132,7 +132,7 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
             return fail(ctx, UMX_ERR_INVALID, "internal: %s reads the compact input tiles through the generic kernel", L.name.c_str());
     char kn[48];
     // the instantiation as rocprofv3 names it (<NT, KMT, NPH>): bench.py groups the timed sites by kernel
-    snprintf(kn, sizeof kn, "conv_f16x3<%d, %d, %d, false, %d>", L.nt16, p.kmt, p.fused_phases ? 4 : 1, p.maxp);   // as rocprofv3 prints it
+    snprintf(kn, sizeof kn, "conv_f16x3<%d, %d, %d, false, %d, %s>", L.nt16, p.kmt, p.fused_phases ? 4 : 1, p.maxp, p.pk ? "true" : "false");
     {
         // diagnostic: UMX_DEBUG_STAMPS=<layer name> prints the mean s_memtime segments of that layer's workgroups
         static const char* dbg_layer = getenv("UMX_DEBUG_STAMPS");

@@ -127,6 +127,7 @@ struct HConvParams {
     float inv_imgplane, inv_hw;  // 1 / imgplane, 1 / hw
     int act;
     int post_affine;             // 0: post_s == 1 and post_b == 0 on every real channel (the epilogue skips the second affine)
+    int pk;                      // 1: the last N-tile's weight image is [w_hi | w_lo] of its <= 8 real channels (conv_f16x3's PK form)
     int* overflow_flag;
     long long* dbg;              // diagnostic builds only (UMX_DEBUG_STAMPS): per-workgroup s_memtime segments, or NULL
 };

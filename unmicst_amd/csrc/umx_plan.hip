@@ -40,6 +40,12 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     }
     L.nt16 = nt16;
     h.NT = nt16; h.nblocks = Np16 / (16 * nt16);
+    // packed last N-tile (conv_f16x3's PK form): <= 8 real channels in the last of 2..5 N-tiles of a single N-block
+    const int last_real = L.Cout - (nt16 - 1) * 16;
+    // (not the fused-phase transposed convolutions: four accumulator sets through the lane exchange cost 19 registers, i.e. the
+    // third workgroup per CU of the 3-tile kernel, and those layers are not matrix-bound)
+    h.pk = (!fused && h.nblocks == 1 && nt16 >= 2 && nt16 <= 5 && last_real >= 1 && last_real <= 8 && !getenv("UMX_NO_PACKED_TILE") &&
+            !getenv("UMX_DEBUG_STAMPS")) ? 1 : 0;
     h.outH = L.outH; h.outW = L.outW; h.pool = L.pool; h.act = L.act;
     if (h.nhalo > kHaloChunks * 64) { *why = "halo too large for the split-precision kernel"; return UMX_ERR_INVALID; }
     h.plane_slots = round_up(h.nhalo, 16);
@@ -305,13 +311,16 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                             if (pr2.tap < 0) continue;
                             const Group& G = L.g[pr2.gi];
                             const int Cp = round_up(G.C, 4);
-                            const int co = nb * nt16 * 16 + n * 16 + (lane & 15);
+                            const bool packed = h.pk && n == nt16 - 1;   // rows 0..7: w_hi, rows 8..15: w_lo of the same 8 channels
+                            const int row = lane & 15;
+                            const int co = nb * nt16 * 16 + n * 16 + (packed ? (row & 7) : row);
                             const size_t base = blk + 32 + (((size_t)j * nt16 + n) * 2) * 512 + (size_t)lane * 8;
                             for (int e = 0; e < 8; ++e) {
                                 const int c = pr2.oct * 8 + e;
                                 if (c >= G.C || co >= L.Cout) continue;
                                 const float v = G.packed[pr2.ph][((size_t)pr2.tap * Cp + c) * L.Np + co] * wscale;
                                 const _Float16 hi = (_Float16)v;
+                                if (packed) { W[base + e] = row < 8 ? hi : (_Float16)(v - (float)hi); continue; }   // (no lo image)
                                 W[base + e] = hi;
                                 W[base + 512 + e] = (_Float16)(v - (float)hi);
                             }
@@ -396,7 +405,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     }
     if (getenv("UMX_DEBUG_PLAN"))
         fprintf(stderr, "[umx plan] %-12s %sNT %d x %d blocks, OC %d x %d halo slot(s), S %d, LDS %d B, k-steps %d, wshift %d\n",
-                L.name.c_str(), fused ? "fused-phase " : "", nt16, h.nblocks, OC, bestSlots, S, h.lds_bytes, L.n_ksteps,
+                L.name.c_str(), fused ? (h.pk ? "fused-phase packed " : "fused-phase ") : (h.pk ? "packed " : ""), nt16, h.nblocks, OC, bestSlots, S, h.lds_bytes, L.n_ksteps,
                 L.wshift);
     h.inv_imgplane = 1.f / (float)h.imgplane;
     h.inv_hw = 1.f / (float)h.hw;
@@ -416,6 +425,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         h.ph[list].w = reinterpret_cast<const uint4*>(d);
     }
     L.exec_flops = 2.0 * 3.0 * (double)L.n_ksteps * 32.0 * Np16 * L.H * L.W;   // MFMA work incl. split and padding
+    if (h.pk) L.exec_flops -= 2.0 * (double)L.n_ksteps * 32.0 * 16.0 * L.H * L.W;    // (the packed N-tile takes 2 products)
     return UMX_OK;
 }
 
