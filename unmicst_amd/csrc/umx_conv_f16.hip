@@ -314,17 +314,19 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
         cur = nxt;
         if (DBG && p.dbg) { t_a = __builtin_amdgcn_s_memtime(); t_comp += t_a - t_b; }
     }
-    if constexpr (PK) {   // packed last N-tile: rows j (w_hi products) += rows j + 8 (w_lo products), i.e. lane l += lane l + 32
+    // packed last N-tile: rows j (w_hi products) += rows j + 8 (w_lo products), i.e. lane l += lane l + 32.  The plain kernels do it
+    // here, once; the fused-phase kernels where an accumulator is consumed (emit_t): their four accumulator sets moved to vector
+    // registers at this point cost 19 registers, i.e. the third workgroup per CU of the 3-tile kernel
+    auto pk_sum = [](float v) {
+        const unsigned u = __float_as_uint(v);
+        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // {lanes 0..31 twice, lanes 32..63 twice}
+        return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    };
+    if constexpr (PK && NPH == 1) {
 #pragma unroll
-        for (int h = 0; h < NPH; ++h)
+        for (int m = 0; m < KMT; ++m)
 #pragma unroll
-            for (int m = 0; m < KMT; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const unsigned u = __float_as_uint(accs[h][m][NT - 1][r]);
-                    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // {lanes 0..31 twice, lanes 32..63 twice}
-                    accs[h][m][NT - 1][r] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-                }
+            for (int r = 0; r < 4; ++r) accs[0][m][NT - 1][r] = pk_sum(accs[0][m][NT - 1][r]);
     }
     struct DbgOut {   // written when the kernel returns (both epilogue paths)
         const HConvParams& p; long long t_in, t_pro, t_wait, t_comp, t_epi; int tid; const long long& t_vm; const long long& t_iss;
@@ -616,7 +618,13 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
             const EC e = load_ec(n, POST);
             float a[4], b[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { a[r] = act1(A[n][r], e, r, POST); b[r] = act1(B[n][r], e, r, POST); }
+            for (int r = 0; r < 4; ++r) {
+                float av = A[n][r], bv = B[n][r];
+                if constexpr (PK && NPH == 4) {
+                    if (n == NT - 1) { av = pk_sum(av); bv = pk_sum(bv); }
+                }
+                a[r] = act1(av, e, r, POST); b[r] = act1(bv, e, r, POST);
+            }
             store_unit(n, a, b, off, ok, apix, app_h, app_l);
             __builtin_amdgcn_sched_barrier(0);   // one N-tile at a time
         }
@@ -728,7 +736,7 @@ static hipError_t launch_h_nt(const HConvParams& p, hipStream_t stream) {
     constexpr bool has4 = true, has12 = NT <= 5 && !(NPH == 4 && NT > 3);
     if (p.maxp != 4 && p.maxp != 12) return hipErrorInvalidValue;
     if (p.pk) {   // packed last N-tile: the narrow kernels only (the planner asks for it at <= 5 N-tiles), no stamped twins
-        if constexpr (NT >= 2 && NT <= 5 && NPH == 1) {
+        if constexpr (NT >= 2 && NT <= 5) {
             if constexpr (has12) {
                 if (p.maxp == 12) return launch_h_k<NT, KMT, NPH, false, 12, true>(p, stream);
             }

@@ -42,10 +42,10 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     h.NT = nt16; h.nblocks = Np16 / (16 * nt16);
     // packed last N-tile (conv_f16x3's PK form): <= 8 real channels in the last of 2..5 N-tiles of a single N-block
     const int last_real = L.Cout - (nt16 - 1) * 16;
-    // (not the fused-phase transposed convolutions: four accumulator sets through the lane exchange cost 19 registers, i.e. the
-    // third workgroup per CU of the 3-tile kernel, and those layers are not matrix-bound)
-    h.pk = (!fused && h.nblocks == 1 && nt16 >= 2 && nt16 <= 5 && last_real >= 1 && last_real <= 8 && !getenv("UMX_NO_PACKED_TILE") &&
-            !getenv("UMX_DEBUG_STAMPS")) ? 1 : 0;
+    // (UMX_NO_PACKED_TILE=1: nowhere; =convt: not in the fused-phase transposed convolutions)
+    const char* const nopk = getenv("UMX_NO_PACKED_TILE");
+    const bool pk_off = nopk && (!strcmp(nopk, "1") || (fused && !strcmp(nopk, "convt")));
+    h.pk = (h.nblocks == 1 && nt16 >= 2 && nt16 <= 5 && last_real >= 1 && last_real <= 8 && !pk_off && !getenv("UMX_DEBUG_STAMPS")) ? 1 : 0;
     h.outH = L.outH; h.outW = L.outW; h.pool = L.pool; h.act = L.act;
     if (h.nhalo > kHaloChunks * 64) { *why = "halo too large for the split-precision kernel"; return UMX_ERR_INVALID; }
     h.plane_slots = round_up(h.nhalo, 16);
