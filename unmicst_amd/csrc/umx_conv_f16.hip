@@ -48,15 +48,20 @@ __device__ __forceinline__ void static_for(F&& f) {   // compile-time loop: the 
 // DBG = true: the same kernel with in-kernel s_memtime stamps (UMX_DEBUG_STAMPS); the product build carries none of it.
 // MAXP: halo pieces per wave and chunk the kernel keeps a pixel index for (4 or 12; the planner picks the smallest that holds
 //       its chunking -- 12 costs 8 vector registers, i.e. a wave per SIMD on the narrow kernels).
-constexpr int conv_f16x3_waves(int NT, int KMT, int NPH, int MAXP) {   // resident waves per SIMD the register budget is set for
-    return NPH != 1 ? 2 : (NT <= 3 && MAXP == 4) ? 4 : (NT <= 3 || (NT <= 5 && MAXP == 4)) ? 3 : 2;
+constexpr int conv_f16x3_waves(int NT, int KMT, int NPH, int MAXP, bool D2S = false) {   // resident waves per SIMD the register budget is set for
+    return NPH != 1 || D2S ? 2 : (NT <= 3 && MAXP == 4) ? 4 : (NT <= 3 || (NT <= 5 && MAXP == 4)) ? 3 : 2;
 }
 // PK = true: the LAST N-tile holds <= 8 real output channels and is packed [w_hi of channels 0..7 | w_lo of channels 0..7] in its
 //       16 rows (one weight image): x_hi and x_lo against it are 2 MFMAs instead of 3 (rows 0..7 collect w_hi.x_hi + w_hi.x_lo,
 //       rows 8..15 w_lo.x_hi + the 2^-22 term w_lo.x_lo the 3-product form drops), and rows j, j + 8 -- lanes l, l + 32 -- are
 //       added once, after the K loop (v_permlane32_swap).  36 channels: 8 MFMAs per (M-tile, k-step) instead of 9, 72: 14 of 15.
-template <int NT, int KMT, int NPH, bool DBG = false, int MAXP = 4, bool PK = false>
-__global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) conv_f16x3(const HConvParams p) {
+// D2S = true: a stride-2 transposed convolution in its depth-to-space form (umx_plan.hip, make_d2s): ONE plain convolution over the
+//       union of the phases' taps whose N axis is [phase][channel] -- 4 x 36 channels are 9 full N-tiles instead of 4 x 3 --
+//       with KMT = 4 and no phase loop; only the epilogue differs: a stored octet's phase (sub-pixel offset) and destination
+//       octet come from a per-octet table, and an optional last "remainder" tile carries <= 4 channels of each phase in lane
+//       group q = phase slot, stored without the set exchange together with the appended raw-skip channels.
+template <int NT, int KMT, int NPH, bool DBG = false, int MAXP = 4, bool PK = false, bool D2S = false>
+__global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)) conv_f16x3(const HConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
@@ -199,7 +204,7 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
 
     // epilogue constants of this N-block ([pre_s | pre_b | post_s | post_b] x NT*16 floats, defaults and 2^shift factors
     // folded on the host): loaded by LDS-DMA under the MFMAs of the last stage, into the weight buffer that stage frees
-    const int ec_units = p.head_K > 0 ? (4 + p.head_K) * (NT * 4) + 4 : NT * 16;   // uint4 per N-block
+    const int ec_units = (p.head_K > 0 ? (4 + p.head_K) * (NT * 4) + 4 : NT * 16) + (D2S ? 16 : 0);   // uint4 per N-block
     auto issue_econst = [&](int buf) {
         if (wave == kWaves - 1) {
             float* const dst = reinterpret_cast<float*>(Bl + buf * p.wbuf_bytes);
@@ -209,11 +214,35 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
                     UMX_GLDS16(p.econst + (size_t)nblk * ec_units + i * 64 + lane, dst + i * 256);
         }
     };
+    // depth-to-space form with appended channels: the workgroup's 32 x 32 output pixels of the compact raw-skip tensor go to LDS
+    // behind the constants, under the MFMAs of the last stage as well (read by global loads in the epilogue their latency was
+    // exposed twice per wave: 14 k of a 71 k-cycle workgroup).  One piece = the two output rows of two M-tiles: lane = (M-tile
+    // parity, output row parity, 16-byte segment of the row's 32 pixels).
+    auto issue_app = [&](int buf) {
+        if constexpr (D2S) {
+            if (p.app_c != nullptr && p.d2s_mix && wave == kWaves - 2) {
+                const int apb = 4 * p.app_cw;   // bytes per compact pixel
+                const size_t oHW = (size_t)p.outH * p.outW, left = (size_t)(p.B - img0) * oHW * apb;
+                const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(p.app_c + (size_t)img0 * oHW * apb), 0, (int)(left < 0x7fffffffu ? left : 0x7fffffffu), 0x00020000);
+                unsigned char* const dst = Bl + buf * p.wbuf_bytes + ec_units * 16;
+                const int oy = (lane >> 4) & 1, seg = lane & 15;
+#pragma unroll
+                for (int i = 0; i < kMW / 2; ++i) {
+                    const int t = 2 * i + (lane >> 5);
+                    const int irel = (t >> p.th_log2) * p.nimg_m, yt = y0 + (t & (TH - 1));
+                    const bool ok = img0 + irel < p.B && seg * 16 < 32 * apb;
+                    const int voff = ok ? (int)((irel * (int)oHW + (2 * yt + oy) * p.outW + 2 * x0) * apb + seg * 16) : 0x7fffffff;
+                    UMX_BLDS16(ra, dst + i * 1024, voff, 0);
+                }
+            }
+        }
+    };
     // stage s uses weight buffer (s + par0) & 1, with par0 such that the buffer the LAST stage frees -- where the epilogue
     // constants go -- is always buffer 1: the epilogue's transpose staging may then use everything below it
     const int par0 = (ph.nstages + 1) & 1;
     const float* const ec = reinterpret_cast<const float*>(Bl + p.wbuf_bytes);
-    if (ph.nstages == 0) issue_econst(1);
+    if (ph.nstages == 0) { issue_econst(1); issue_app(1); }
     // the stage table is read through the constant address space: a plain global pointer gets a VECTOR load and a full
     // s_waitcnt vmcnt(0) round trip at the top of every stage (the kernel stores and fences, so the compiler will not
     // prove the table unclobbered); the host writes it before the launch and nothing writes it afterwards
@@ -252,6 +281,7 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
         } else {
             wq_np = 0;   // no block after the last stage
             issue_econst(1);   // == (s + 1 + par0) & 1
+            issue_app(1);
         }
         if (DBG && p.dbg) t_iss += (long long)__builtin_amdgcn_s_memtime() - t_b;
 
@@ -670,7 +700,140 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
         if constexpr (kApp) app_img = irel * dImgPix;
         return img0 + irel < p.B ? irel * dImg : -1;
     };
-    if constexpr (NPH == 4) {
+    if constexpr (D2S) {
+        static_assert(NPH == 1 && (KMT & 1) == 0 && !PK, "the depth-to-space form runs on the plain kernel");
+        const int z = blockIdx.z;
+        // (the table sits behind the epilogue constants in LDS; an entry is read where it is used: 9 of them held in registers
+        // spilled 34)
+        const int* const dtab = reinterpret_cast<const int*>(ec) + 4 * NT * 16 + z * (2 * NT + 8);
+        const bool mix = p.d2s_mix != 0;                  // (wave-uniform) the last N-tile is the remainder tile
+        constexpr int NTR = NT - 1;                       // N-tiles that are regular whatever `mix` says
+        // Two passes, so that neither carries the other's registers (one pass spilled 37, and every scratch reload waits for the
+        // stores in front of it).  Pass 1, the regular N-tiles: sets A, B = M-tiles m, m + 1 (rows y, y + 1 of one image: the planner
+        // asks for >= 2 rows), exchanged into 16-byte units; the octet's phase and destination come from the table.
+        const int rowB = 2 * p.outW * dPix;               // element offset of set B's pixel relative to set A's
+#pragma unroll
+        for (int m = 0; m < KMT; m += 2) {
+            int yt, xt;
+            const int ib = pix_off(wave * KMT + m, li, yt, xt);
+            const int off = ib + ((yt * 2) * p.outW + xt * 2) * dPix + (setB ? rowB : 0);
+            const bool ok = ib >= 0;
+            auto body = [&](auto POST) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    if (n == NTR && mix) break;   // (wave-uniform)
+                    const EC e = load_ec(n, POST);
+                    float a[4], b[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { a[r] = act1(accs[0][m][n][r], e, r, POST); b[r] = act1(accs[0][m + 1][n][r], e, r, POST); }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        vmax = max(vmax, max(__float_as_uint(a[r]) & 0x7fffffffu, __float_as_uint(b[r]) & 0x7fffffffu));
+                    unsigned ah0, ah1, al0, al1, bh0, bh1, bl0, bl1;
+                    pack_split(a[0], a[1], ah0, al0);
+                    pack_split(a[2], a[3], ah1, al1);
+                    pack_split(b[0], b[1], bh0, bl0);
+                    pack_split(b[2], b[3], bh1, bl1);
+                    // (every lane takes part in the exchange: never under a divergent branch)
+                    const auto h0 = __builtin_amdgcn_permlane16_swap(ah0, bh0, false, false);
+                    const auto h1 = __builtin_amdgcn_permlane16_swap(ah1, bh1, false, false);
+                    const auto l0 = __builtin_amdgcn_permlane16_swap(al0, bl0, false, false);
+                    const auto l1 = __builtin_amdgcn_permlane16_swap(al1, bl1, false, false);
+                    const int dsel = dtab[2 * n + oct_q];
+                    if (ok && dsel >= 0) {
+                        const unsigned o = (unsigned)(off + dsel) * 2u;
+                        *reinterpret_cast<uint4*>(bhi + o) = make_uint4(h0[0], h1[0], h0[1], h1[1]);
+                        *reinterpret_cast<uint4*>(blo + o) = make_uint4(l0[0], l1[0], l0[1], l1[1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // one N-tile at a time
+                }
+            };
+            if (p.post_affine) body(std::true_type{});
+            else body(std::false_type{});
+        }
+        // Pass 2, the remainder tile: lane group q holds 4 channels of phase slot q for its pixel; with the appended raw-skip
+        // channels (from the LDS copy, issue_app) and zeros they are that phase's last stored octet -- no exchange, one M-tile at a time
+        if (mix) {
+            const int dmix = dtab[2 * NT + q];            // this lane group's (sub-pixel phase, last octet) offset, < 0: no phase
+            const int cmix = dtab[2 * NT + 4 + q];        // ... and the phase's sub-pixel code oy * 2 + ox
+            const bool app_on = p.app_c != nullptr;
+            const int apb = 4 * p.app_cw;
+            const unsigned char* const apl = reinterpret_cast<const unsigned char*>(ec) + ec_units * 16 + (cmix >> 1) * 256 +
+                                             (2 * li + (cmix & 1)) * apb;
+            auto tail = [&](auto POST) {
+                const EC e = load_ec(NTR, POST);
+#pragma unroll
+                for (int m = 0; m < KMT; ++m) {
+                    int yt, xt;
+                    const int ib = pix_off(wave * KMT + m, li, yt, xt);
+                    float a[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        a[r] = act1(accs[0][m][NTR][r], e, r, POST);
+                        vmax = max(vmax, __float_as_uint(a[r]) & 0x7fffffffu);
+                    }
+                    uint4 uh = make_uint4(0u, 0u, 0u, 0u), ul = make_uint4(0u, 0u, 0u, 0u);
+                    pack_split(a[0], a[1], uh.x, ul.x);
+                    pack_split(a[2], a[3], uh.y, ul.y);
+                    if (app_on && dmix >= 0) {
+                        unsigned aph, apl_w;
+                        const unsigned char* const src = apl + (wave * KMT + m) * 512;
+                        if (p.app_cw == 2) {
+                            const uint2 w = *reinterpret_cast<const uint2*>(src);
+                            aph = w.x; apl_w = w.y;
+                        } else {
+                            const unsigned w = *reinterpret_cast<const unsigned*>(src);
+                            aph = w & 0xffffu; apl_w = w >> 16;
+                        }
+                        if (p.app_word == 1) { uh.y = aph; ul.y = apl_w; }
+                        else if (p.app_word == 2) { uh.z = aph; ul.z = apl_w; }
+                        else { uh.w = aph; ul.w = apl_w; }
+                    }
+                    if (ib >= 0 && dmix >= 0) {
+                        const unsigned o = (unsigned)(ib + ((yt * 2) * p.outW + xt * 2) * dPix + dmix) * 2u;
+                        *reinterpret_cast<uint4*>(bhi + o) = uh;
+                        *reinterpret_cast<uint4*>(blo + o) = ul;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (p.post_affine) tail(std::true_type{});
+            else tail(std::false_type{});
+        } else {   // (no remainder tile: the last N-tile is a regular one)
+#pragma unroll
+            for (int m = 0; m < KMT; m += 2) {
+                int yt, xt;
+                const int ib = pix_off(wave * KMT + m, li, yt, xt);
+                const int off = ib + ((yt * 2) * p.outW + xt * 2) * dPix + (setB ? rowB : 0);
+                auto last = [&](auto POST) {
+                    const EC e = load_ec(NTR, POST);
+                    float a[4], b[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { a[r] = act1(accs[0][m][NTR][r], e, r, POST); b[r] = act1(accs[0][m + 1][NTR][r], e, r, POST); }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        vmax = max(vmax, max(__float_as_uint(a[r]) & 0x7fffffffu, __float_as_uint(b[r]) & 0x7fffffffu));
+                    unsigned ah0, ah1, al0, al1, bh0, bh1, bl0, bl1;
+                    pack_split(a[0], a[1], ah0, al0);
+                    pack_split(a[2], a[3], ah1, al1);
+                    pack_split(b[0], b[1], bh0, bl0);
+                    pack_split(b[2], b[3], bh1, bl1);
+                    const auto h0 = __builtin_amdgcn_permlane16_swap(ah0, bh0, false, false);
+                    const auto h1 = __builtin_amdgcn_permlane16_swap(ah1, bh1, false, false);
+                    const auto l0 = __builtin_amdgcn_permlane16_swap(al0, bl0, false, false);
+                    const auto l1 = __builtin_amdgcn_permlane16_swap(al1, bl1, false, false);
+                    const int dsel = dtab[2 * NTR + oct_q];
+                    if (ib >= 0 && dsel >= 0) {
+                        const unsigned o = (unsigned)(off + dsel) * 2u;
+                        *reinterpret_cast<uint4*>(bhi + o) = make_uint4(h0[0], h1[0], h0[1], h1[1]);
+                        *reinterpret_cast<uint4*>(blo + o) = make_uint4(l0[0], l1[0], l0[1], l1[1]);
+                    }
+                };
+                if (p.post_affine) last(std::true_type{});
+                else last(std::false_type{});
+            }
+        }
+    } else if constexpr (NPH == 4) {
         // output row 2y+pu of M-tile row y: its 32 pixels 2x+pv come from phases (pu, 0) = set A and (pu, 1) = set B
         int ibs[KMT], pixs[KMT][2], apx[KMT][2];
         unsigned aph[KMT][2], apl[KMT][2];
@@ -716,17 +879,17 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP)) con
     if (vmax >= 0x476a6000u) atomicOr(p.overflow_flag, 1);   // |v| >= 60000, infinity or NaN: binary16 range exceeded, the host reports it
 }
 
-template <int NT, int KMT, int NPH, bool DBG, int MAXP, bool PK = false>
+template <int NT, int KMT, int NPH, bool DBG, int MAXP, bool PK = false, bool D2S = false>
 static hipError_t launch_h_k(const HConvParams& p, hipStream_t stream) {
     const int img_groups = (p.B + p.imgs - 1) / p.imgs;
     dim3 grid((unsigned)(img_groups * p.tiles_y * p.tiles_x), (unsigned)p.nblocks, (unsigned)(NPH == 1 ? p.nphase : 1));
     const size_t lds = (size_t)p.lds_bytes;
-    const void* kern = reinterpret_cast<const void*>(conv_f16x3<NT, KMT, NPH, DBG, MAXP, PK>);
+    const void* kern = reinterpret_cast<const void*>(conv_f16x3<NT, KMT, NPH, DBG, MAXP, PK, D2S>);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((conv_f16x3<NT, KMT, NPH, DBG, MAXP, PK>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_f16x3<NT, KMT, NPH, DBG, MAXP, PK, D2S>), grid, dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -735,6 +898,15 @@ template <int NT, int KMT, int NPH>
 static hipError_t launch_h_nt(const HConvParams& p, hipStream_t stream) {
     constexpr bool has4 = true, has12 = NT <= 5 && !(NPH == 4 && NT > 3);
     if (p.maxp != 4 && p.maxp != 12) return hipErrorInvalidValue;
+    if (p.d2s) {   // depth-to-space transposed convolution: the wide plain kernels, 4 pixel indices per wave
+        if constexpr (NT >= 5 && NPH == 1) {
+            if constexpr (NT == 9) {   // (stamped twin for the tile count the bench graph uses)
+                if (p.maxp == 4 && !p.pk && p.dbg) return launch_h_k<NT, KMT, NPH, true, 4, false, true>(p, stream);
+            }
+            if (p.maxp == 4 && !p.pk) return launch_h_k<NT, KMT, NPH, false, 4, false, true>(p, stream);
+        }
+        return hipErrorInvalidValue;
+    }
     if (p.pk) {   // packed last N-tile: the narrow kernels only (the planner asks for it at <= 5 N-tiles), no stamped twins
         if constexpr (NT >= 2 && NT <= 5) {
             if constexpr (has12) {

@@ -132,7 +132,8 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
             return fail(ctx, UMX_ERR_INVALID, "internal: %s reads the compact input tiles through the generic kernel", L.name.c_str());
     char kn[48];
     // the instantiation as rocprofv3 names it (<NT, KMT, NPH>): bench.py groups the timed sites by kernel
-    snprintf(kn, sizeof kn, "conv_f16x3<%d, %d, %d, false, %d, %s>", L.nt16, p.kmt, p.fused_phases ? 4 : 1, p.maxp, p.pk ? "true" : "false");
+    snprintf(kn, sizeof kn, "conv_f16x3<%d, %d, %d, false, %d, %s, %s>", L.nt16, p.kmt, p.fused_phases ? 4 : 1, p.maxp, p.pk ? "true" : "false",
+             p.d2s ? "true" : "false");
     {
         // diagnostic: UMX_DEBUG_STAMPS=<layer name> prints the mean s_memtime segments of that layer's workgroups
         static const char* dbg_layer = getenv("UMX_DEBUG_STAMPS");
@@ -557,6 +558,7 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
             if ((rc = upload(c, L.head_w, &L.d_head_w))) return bail(rc);
             continue;
         }
+        if (f16) make_d2s(L);   // (narrow stride-2 transposed convolutions: depth-to-space form, before the geometry is laid out)
         if (!conv_geometry(L, &why)) { c->err = L.name + ": " + why; return bail(UMX_ERR_INVALID); }
         if (f16) {
             if ((rc = plan_f16(c, L, act_shift, L.dst == head_src, &c->plan.back(), &why))) {

@@ -67,6 +67,13 @@ struct Launch {
     HConvParams hcp;
     FirstParams first;        // dense-K plan of the first down-sampling layer (use_first; umx_conv_first.hip)
     bool use_first = false;
+    // depth-to-space form of a stride-2 transposed convolution (make_d2s): nphase = number of N-blocks, each a plain convolution
+    // over the union of its phases' taps with the N axis [phase slot][full octets] (+ one remainder tile of <= 4 channels per phase)
+    int d2s = 0;              // 1: rewritten
+    int d2s_Cout = 0;         // the real output channels (Cout holds the N extent of one block)
+    int d2s_F = 0, d2s_R = 0; // full octets / remainder channels per phase
+    int d2s_npb = 0;          // phases per block (4 or 2)
+    int d2s_oy[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, d2s_ox[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // sub-pixel offset of (block, phase slot)
     int nt16 = 1;             // N-tiles per workgroup of the split-precision kernel
     int wshift = 0;           // weights are stored times 2^wshift
     int n_ksteps = 0;         // K-slots of 32 executed per output tile, all phases (for the executed-FLOP figure)
@@ -190,6 +197,8 @@ bool conv_geometry(Launch& L, std::string* why);
 int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch* head, std::string* why);
 // dense-K plan of the first down-sampling layer, for a launch plan_f16 has just planned (sets L.use_first when it applies)
 int plan_first(umx_ctx* ctx, Launch& L, int act_shift, std::string* why);
+// depth-to-space rewrite of a narrow stride-2 transposed convolution (before conv_geometry / plan_f16); true if L was rewritten
+bool make_d2s(Launch& L);
 // the same decision from the hyper-parameters alone (the graph builder folds the raw skip only when the first layer takes this kernel)
 bool conv_first_eligible(const umx_hparams& hp);
 

@@ -127,6 +127,11 @@ struct HConvParams {
     float inv_imgplane, inv_hw;  // 1 / imgplane, 1 / hw
     int act;
     int post_affine;             // 0: post_s == 1 and post_b == 0 on every real channel (the epilogue skips the second affine)
+    int d2s;                     // 1: depth-to-space transposed convolution (conv_f16x3's D2S form; blockIdx.z = N-block of phases):
+    int d2s_mix;                 //    the last N-tile is the remainder tile (lane group q = phase slot q).  Behind the epilogue
+                                 //    constants, 64 ints: per block z [2 NT + 8]: element offset of (sub-pixel phase, destination
+                                 //    octet) relative to output pixel (2y, 2x) per stored octet of the N axis (< 0: padding), then the
+                                 //    same for the remainder tile's 4 lane groups, then their sub-pixel codes oy * 2 + ox
     int pk;                      // 1: the last N-tile's weight image is [w_hi | w_lo] of its <= 8 real channels (conv_f16x3's PK form)
     int* overflow_flag;
     long long* dbg;              // diagnostic builds only (UMX_DEBUG_STAMPS): per-workgroup s_memtime segments, or NULL

@@ -2,6 +2,8 @@
 // one convolution launch for conv_f16x3 (layout documented in umx_conv_f16.hip).  Host code only.
 #include "umx_internal.h"
 
+#include <algorithm>
+
 namespace umx {
 
 // ---- split-precision plan of one conv launch: chunking of the input octets, k-step table, stage table, weight images
@@ -28,7 +30,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     h.imgplane = h.hh * h.hw; h.nhalo = h.imgs * h.imgplane;
     h.ymin = g.ymin; h.xmin = g.xmin;
     h.nphase = L.nphase; h.o_mul = L.o_mul;
-    h.H = L.H; h.W = L.W; h.Cout = L.Cout; h.Cds = round_up(L.Cout, 8);
+    h.H = L.H; h.W = L.W; h.Cout = L.Cout; h.Cds = round_up(L.d2s ? L.d2s_Cout : L.Cout, 8);   // (stored channels of the destination)
     int nt16 = 1, Np16 = 16;
     {   // N-tiles per workgroup: minimise padded N, prefer wide workgroups (fewer re-reads of the input halo)
         int best_pad = 1 << 30;
@@ -45,7 +47,9 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     // (UMX_NO_PACKED_TILE=1: nowhere; =convt: not in the fused-phase transposed convolutions)
     const char* const nopk = getenv("UMX_NO_PACKED_TILE");
     const bool pk_off = nopk && (!strcmp(nopk, "1") || (fused && !strcmp(nopk, "convt")));
-    h.pk = (h.nblocks == 1 && nt16 >= 2 && nt16 <= 5 && last_real >= 1 && last_real <= 8 && !pk_off && !getenv("UMX_DEBUG_STAMPS")) ? 1 : 0;
+    h.d2s = L.d2s;
+    h.d2s_mix = L.d2s && L.d2s_R > 0;
+    h.pk = (!L.d2s && h.nblocks == 1 && nt16 >= 2 && nt16 <= 5 && last_real >= 1 && last_real <= 8 && !pk_off && !getenv("UMX_DEBUG_STAMPS")) ? 1 : 0;
     h.outH = L.outH; h.outW = L.outW; h.pool = L.pool; h.act = L.act;
     if (h.nhalo > kHaloChunks * 64) { *why = "halo too large for the split-precision kernel"; return UMX_ERR_INVALID; }
     h.plane_slots = round_up(h.nhalo, 16);
@@ -100,7 +104,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         }
         else {
             for (int maxp : {4, 12}) {
-                if (maxp == 12 && nt16 > 5) break;
+                if (maxp == 12 && (nt16 > 5 || L.d2s)) break;   // (the depth-to-space instantiations keep 4 pixel indices)
                 // (4-5 N-tiles at three workgroups per CU: round 2 kept them to <= 8 chunks -- lu1.conv, 24 chunks, ran 16 % faster
                 // that way but the step did not, at NHWC-era L2 re-fetch rates; with planar activations and the register epilogue
                 // the same-box A/B is 49.32 / 48.99 / 49.06 -> 48.70 / 48.77 / 48.74 ms per step: the rule is gone)
@@ -339,7 +343,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         // a fused softmax head needs every channel of a pixel in one workgroup; it replaces the fp32 store of this layer
         const bool fuse_head = head && out_f32 && h.nblocks == 1 && head->head_K <= 4 && !fused && !getenv("UMX_NO_FUSED_HEAD");
         h.head_K = fuse_head ? head->head_K : 0;
-        const size_t per_blk = fuse_head ? (size_t)(4 + h.head_K) * nb16 + 16 : (size_t)4 * nb16;
+        const size_t per_blk = (fuse_head ? (size_t)(4 + h.head_K) * nb16 + 16 : (size_t)4 * nb16) + (L.d2s ? 64 : 0);
         std::vector<float> ec((size_t)h.nblocks * per_blk, 0.f);
         for (int nb = 0; nb < h.nblocks; ++nb)
             for (int i = 0; i < nb16; ++i) {
@@ -352,6 +356,29 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                 e[3 * nb16 + i] = (L.post_b.empty() ? 0.f : L.post_b[c]) * oscale;
                 for (int k = 0; k < h.head_K; ++k) e[(4 + k) * nb16 + i] = head->head_w[(size_t)c * head->head_K + k];
             }
+        if (L.d2s) {   // destination table of the depth-to-space epilogue (HConvParams::d2s_mix), in the destination's layout
+            const Buffer& db = ctx->bufs[L.dst];
+            const int dPix = db.planar ? 8 : h.Cds, dOct = db.planar ? L.outH * L.outW * 8 : 8;
+            int* const tab = reinterpret_cast<int*>(&ec[(size_t)4 * nb16]);
+            const int per_z = 2 * nt16 + 8;
+            if (h.nblocks != 1 || 2 * per_z > 64 || L.nphase > 2) { *why = "internal: depth-to-space table"; return UMX_ERR_INVALID; }
+            for (int z = 0; z < L.nphase; ++z) {
+                for (int vo = 0; vo < 2 * nt16; ++vo) {
+                    int d = -1;
+                    if (vo < L.d2s_npb * L.d2s_F) {   // (make_d2s: the octets of slots 2i, 2i + 1 alternate)
+                        const int pr = vo / (2 * L.d2s_F), rm = vo % (2 * L.d2s_F), j = 2 * pr + (rm & 1), o = rm / 2;
+                        d = (L.d2s_oy[z][j] * L.outW + L.d2s_ox[z][j]) * dPix + o * dOct;
+                    }
+                    tab[z * per_z + vo] = d;
+                }
+                for (int j = 0; j < 4; ++j) {
+                    const bool on = L.d2s_R > 0 && j < L.d2s_npb;
+                    const int pp = on ? L.d2s_oy[z][j] * L.outW + L.d2s_ox[z][j] : 0;
+                    tab[z * per_z + 2 * nt16 + j] = on ? pp * dPix + L.d2s_F * dOct : -1;
+                    tab[z * per_z + 2 * nt16 + 4 + j] = on ? L.d2s_oy[z][j] * 2 + L.d2s_ox[z][j] : 0;
+                }
+            }
+        }
         if (fuse_head) {
             // The 1x1 head runs on the matrix cores (conv_f16x3's fused-head epilogue): its weights as MFMA A-fragments, rows =
             // classes, scaled by 2^hs so that their lo parts stay normal binary16 numbers; the head's BN scale absorbs 2^-hs.
@@ -497,6 +524,90 @@ int plan_first(umx_ctx* ctx, Launch& L, int act_shift, std::string* why) {
         fprintf(stderr, "[umx plan] %-12s dense-K first layer: NT %d, %d channel slot(s) x %d taps = %d k-step(s), region 16 x %d, LDS %d B\n",
                 L.name.c_str(), NT, CW, ntaps, NKS, 1 << f.rw_log2, f.lds_bytes);
     return UMX_OK;
+}
+
+// ---- depth-to-space form of a narrow stride-2 transposed convolution.  Output pixel (2y + pu, 2x + pv) of phase (pu, pv) is a
+// convolution of the input at (y, x) over that phase's taps; all phases' taps lie in one small window (2 x 2 for a 3 x 3 filter),
+// so the four phases are ONE plain convolution over the window whose output channels are [phase][channel] (structural zeros where
+// a phase has no tap), followed by a depth-to-space store.  What it buys over the fused-phase kernel (KMT = 2, one phase per
+// stage, 4 x ceil(Cout / 16) N-tiles): 4 x 36 channels fill 9 N-tiles exactly instead of 12, the K loop is 9 k-steps of 108 MFMAs
+// instead of 22 of 18 (half the barriers, a quarter of the weight-fragment reads per MFMA), workgroups cover 256 input pixels.
+// What it costs: the structural zeros are multiplied (81 tile-k-steps instead of 59).  N layout of a block of `npb` phases:
+// [slots 0, 1: F octets each, alternating] [slots 2, 3 likewise] [remainder tile: 4 channel slots per phase, R <= 4 real] -- F = Cout / 8,
+// R = Cout % 8 -- so that a stored octet belongs to one phase, and the remainder tile's lane group q to phase slot q.
+// One block of all four phases if that is <= 9 N-tiles, else two blocks by output row parity (the pu = 1 block has no dy = -1
+// taps: half the K loop); wider layers stay on the per-phase / fused-phase forms.
+bool make_d2s(Launch& L) {
+    if (getenv("UMX_NO_D2S")) return false;
+    if (L.head || L.nphase != 4 || L.o_mul != 2 || L.ngroups != 1 || L.pool || L.H < 2) return false;   // (M-tile pairs = row pairs of an image)
+    for (int ph = 0; ph < 4; ++ph)
+        if (L.oy_off[ph] != (ph >> 1) || L.ox_off[ph] != (ph & 1) || L.g[0].taps[ph].empty() || L.g[0].packed[ph].empty()) return false;
+    const int F = L.Cout / 8, R = L.Cout % 8, rem = R > 0 ? 1 : 0;
+    if (R > 4 || F < 1) return false;
+    int nz, npb;
+    if (2 * F + rem >= 5 && 2 * F + rem <= 9) { nz = 1; npb = 4; }
+    else if (F + rem >= 5 && F + rem <= 9) { nz = 2; npb = 2; }
+    else return false;
+    if (L.app_src >= 0 && (!rem || L.app_c0 / 8 != F || (L.app_c0 % 8) / 2 < 1 || L.W < 16)) return false;   // appended channels ride in the remainder tile
+    const int NT = npb * F / 2 + rem, Nv = NT * 16;
+    // N index of (phase slot j, channel co).  The full octets of the two phases of an output row (slots 2i, 2i + 1: pixels 2x and
+    // 2x + 1) alternate, so that the two octets of an N-tile are the SAME destination octet of neighbouring output pixels and one
+    // store instruction writes whole 512-byte runs of an output row (not 16 bytes at a 32-byte stride, completed later)
+    auto vchan = [&](int j, int co) {
+        return co < 8 * F ? ((j >> 1) * 2 * F + 2 * (co / 8) + (j & 1)) * 8 + (co & 7) : npb * 8 * F + 4 * j + (co - 8 * F);
+    };
+    Group& g = L.g[0];
+    const int Cp = round_up(g.C, 4), Np_old = L.Np;
+    std::vector<std::pair<int, int>> taps_v[2];
+    std::vector<float> packed_v[2];
+    for (int z = 0; z < nz; ++z) {
+        std::vector<std::pair<int, int>>& U = taps_v[z];
+        for (int j = 0; j < npb; ++j)
+            for (auto& t : g.taps[z * npb + j])
+                if (std::find(U.begin(), U.end(), t) == U.end()) U.push_back(t);
+        std::sort(U.begin(), U.end());
+        packed_v[z].assign(U.size() * (size_t)Cp * Nv, 0.f);
+        for (int j = 0; j < npb; ++j) {
+            const int ph = z * npb + j;
+            L.d2s_oy[z][j] = L.oy_off[ph];
+            L.d2s_ox[z][j] = L.ox_off[ph];
+            for (size_t t = 0; t < g.taps[ph].size(); ++t) {
+                const size_t u = std::find(U.begin(), U.end(), g.taps[ph][t]) - U.begin();
+                for (int c = 0; c < g.C; ++c)
+                    for (int co = 0; co < L.Cout; ++co) {
+                        const int v = vchan(j, co);
+                        packed_v[z][(u * Cp + c) * Nv + v] = g.packed[ph][(t * Cp + c) * Np_old + co];
+                    }
+            }
+        }
+    }
+    // epilogue constants in the N order of a block (the same for every block): padding channels store exact zeros
+    auto permute = [&](const std::vector<float>& src, float dflt, float pad) {
+        std::vector<float> out((size_t)Nv, pad);
+        for (int j = 0; j < npb; ++j)
+            for (int co = 0; co < L.Cout; ++co) {
+                const int v = vchan(j, co);
+                out[v] = src.empty() ? dflt : src[co];
+            }
+        return out;
+    };
+    L.pre_s = permute(L.pre_s, 1.f, 0.f);
+    L.pre_b = permute(L.pre_b, 0.f, 0.f);
+    if (!L.post_s.empty() || !L.post_b.empty()) {
+        L.post_s = permute(L.post_s, 1.f, 1.f);
+        L.post_b = permute(L.post_b, 0.f, 0.f);
+    }
+    L.d2s = 1; L.d2s_Cout = L.Cout; L.d2s_F = F; L.d2s_R = R; L.d2s_npb = npb;
+    for (int ph = 0; ph < 4; ++ph) {
+        g.taps[ph].clear();
+        std::vector<float>().swap(g.packed[ph]);
+        L.oy_off[ph] = L.ox_off[ph] = 0;
+    }
+    for (int z = 0; z < nz; ++z) { g.taps[z] = taps_v[z]; g.packed[z] = std::move(packed_v[z]); }
+    L.nphase = nz;
+    L.Cout = Nv;
+    L.Np = Nv;
+    return true;
 }
 
 }  // namespace umx
