@@ -100,3 +100,44 @@ def test_more_than_eight_input_channels(reference):
         with umx.Engine(hp, blob, max_batch=3, precision=prec) as eng:
             got = eng.forward_tiles(x)
         assert np.abs(got - want).max() <= TILE_TOL, prec
+
+
+# (nOut0, nChannels, ks, imSize): the depth-to-space shapes of make_d2s -- per transposed convolution F = Cout // 8 full octets
+# and R = Cout % 8 left-over channels per phase -- one block of four phases or two blocks by output-row parity, with and
+# without the remainder tile, with (1-2 input channels) and without (3) the raw-skip fold into the top layer's remainder tile
+D2S_SHAPES = [
+    (18, 1, 3, 32),    # top 36 -> 18: F 2, R 2, one block of 5 tiles + fold (one compact channel); below 72 -> 36: F 4, R 4, 9 tiles
+    (20, 2, 3, 64),    # 20: F 2, R 4 (5 tiles, fold of two channels); 40: F 5 -> two blocks of 5
+    (22, 3, 3, 32),    # 22: R 6 -> stays on the fused-phase kernel; 44: F 5, R 4 -> two blocks of 6 with a two-phase remainder tile
+    (24, 3, 3, 32),    # 24: F 3, R 0 (6 tiles, no remainder tile, no fold); 48: two blocks of 6
+    (33, 2, 3, 32),    # 33: F 4, R 1 (9 tiles, fold); 66: F 8, R 2 -> two blocks of 9 with remainder tiles
+    (36, 2, 3, 64),    # the duo widths: 36 (9 tiles, fold) and 72 (two blocks of 9)
+    (12, 1, 5, 32),    # 5 x 5 filters: the phases have 9 / 6 / 6 / 4 taps in a 3 x 3 window; 24 -> 12: F 1 -> not eligible; 48 -> 24: 6 tiles
+]
+
+
+@pytest.mark.parametrize("shape", D2S_SHAPES, ids=lambda s: "n%d_c%d_k%d_s%d" % s)
+def test_depth_to_space_transposed_convolution_shapes(shape):
+    """conv_f16x3's D2S form against the oracle, and against the fused-phase form of the same engine (UMX_NO_D2S), on graphs chosen
+    to hit every branch of its N layout; the profile must show that the depth-to-space kernel actually ran."""
+    import os
+    from oracle import oracle
+    n0, C, ks, S = shape
+    hp = model.HParams(model.GRAPH_V2, S, C, 3, n0, 2, ks, 0, 2)
+    blob = model.random_blob(hp, seed=40 + n0)
+    x = np.random.default_rng(n0).normal(size=(5, S, S, C)).astype(np.float32)
+    want = oracle.forward(hp, blob, x)
+    with umx.Engine(hp, blob, max_batch=3, precision="f16x3") as eng:
+        eng.profile_enable(1)
+        got = eng.forward_tiles(x)
+        kernels = {e["name"]: e["kernel"] for e in eng.profile_read()}
+    assert np.abs(got - want).max() <= TILE_TOL, shape
+    d2s = [n for n, k in kernels.items() if k.startswith("conv_f16x3") and k.endswith(", true>")]
+    assert d2s and all("convT" in n for n in d2s), kernels
+    os.environ["UMX_NO_D2S"] = "1"
+    try:
+        with umx.Engine(hp, blob, max_batch=3, precision="f16x3") as eng:
+            base = eng.forward_tiles(x)
+    finally:
+        del os.environ["UMX_NO_D2S"]
+    assert np.abs(got - base).max() <= 2e-6, shape   # same arithmetic, other summation order
