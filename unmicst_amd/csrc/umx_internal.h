@@ -75,6 +75,7 @@ struct Launch {
     int d2s_npb = 0;          // phases per block (4 or 2)
     int d2s_oy[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, d2s_ox[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // sub-pixel offset of (block, phase slot)
     int nt16 = 1;             // N-tiles per workgroup of the split-precision kernel
+    int force_nt16 = 0;       // > 0: the planner's N-tile choice is overridden (its own trial of narrower N-blocks)
     int wshift = 0;           // weights are stored times 2^wshift
     int n_ksteps = 0;         // K-slots of 32 executed per output tile, all phases (for the executed-FLOP figure)
     float* d_head_w = nullptr;
@@ -194,7 +195,7 @@ int build_graph(const umx_hparams& hp, const float* blob, std::vector<Launch>* p
 bool conv_geometry(Launch& L, std::string* why);
 
 // ---- umx_plan.hip: split-precision plan of one launch
-int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch* head, std::string* why);
+int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch* head, std::string* why, bool dry = false);
 // dense-K plan of the first down-sampling layer, for a launch plan_f16 has just planned (sets L.use_first when it applies)
 int plan_first(umx_ctx* ctx, Launch& L, int act_shift, std::string* why);
 // depth-to-space rewrite of a narrow stride-2 transposed convolution (before conv_geometry / plan_f16); true if L was rewritten

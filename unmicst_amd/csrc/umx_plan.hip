@@ -8,7 +8,25 @@ namespace umx {
 
 // ---- split-precision plan of one conv launch: chunking of the input octets, k-step table, stage table, weight images
 // (layout documented in umx_conv_f16.hip).  Reads the fp32 packing [tap][Cp][Np] produced by the Builder.
-int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch* head, std::string* why) {
+int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch* head, std::string* why, bool dry) {
+    // A per-phase transposed convolution of tiny images (the solo model's 4 x 4 -> 8 x 8 layer: 16 images per tile, one octet per
+    // halo chunk next to 8 N-tiles of weights) fills its k-steps with 1 - 2 (tap, octet) pairs of 4 in the phases that have 1 - 2
+    // taps: 640 executed k-steps for 360.  Narrower N-blocks leave LDS for two octets per chunk (400 k-steps; lu3.convT -16 %,
+    // the solo step -1.6 %): dry-run the search for every N-tile count with the same padding and take a >= 20 % shorter K loop.
+    if (!dry && !L.force_nt16 && L.nphase == 4 && !L.d2s && !getenv("UMX_PLAN_NT") && !getenv("UMX_PLAN_OVERRIDE") &&
+        !getenv("UMX_NO_NT_TRIAL")) {
+        const int t16 = (L.Cout + 15) / 16;
+        int base_k = 0, base_nt = 0, best_k = 0, best_nt = 0;
+        for (int c = std::min(t16, kMaxNT16); c >= 4; --c) {   // (narrower than 4 N-tiles re-reads the halo too often)
+            L.force_nt16 = c;
+            std::string w2;
+            if (plan_f16(ctx, L, act_shift, out_f32, head, &w2, true) != UMX_OK || L.hcp.fused_phases) { L.force_nt16 = 0; continue; }
+            if (L.nt16 != c) continue;                       // (c does not keep the padded width: the planner chose another count)
+            if (!base_nt) { base_nt = c; base_k = L.n_ksteps; best_nt = c; best_k = base_k; }   // the default choice comes first
+            else if (L.n_ksteps < best_k) { best_nt = c; best_k = L.n_ksteps; }
+        }
+        L.force_nt16 = (base_nt && best_nt != base_nt && best_k * 5 <= base_k * 4) ? best_nt : 0;
+    }
     const ConvParams& g = L.cp;   // tile geometry shared with the fp32 kernel
     HConvParams& h = L.hcp;
     memset(&h, 0, sizeof h);
@@ -39,6 +57,15 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
             if (padded < best_pad || (padded == best_pad && c > nt16)) { nt16 = c; best_pad = padded; }
         }
         Np16 = best_pad * 16;
+        if (L.force_nt16 > 0 && L.force_nt16 <= (fused ? 5 : kMaxNT16) && round_up(t16, L.force_nt16) == best_pad) nt16 = L.force_nt16;
+        if (const char* e = getenv("UMX_PLAN_NT")) {   // tuning aid: "layer:NT" forces a layer's N-tiles per workgroup
+            char nm[64];
+            int c = 0;
+            if (sscanf(e, "%63[^:]:%d", nm, &c) == 2 && L.name == nm && c >= 1 && c <= (fused ? 5 : kMaxNT16)) {
+                nt16 = c;
+                Np16 = round_up(t16, c) * 16;
+            }
+        }
     }
     L.nt16 = nt16;
     h.NT = nt16; h.nblocks = Np16 / (16 * nt16);
@@ -218,6 +245,11 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     }
     }
     if (!bestOC) { *why = "LDS footprint too large for the split-precision kernel"; return UMX_ERR_INVALID; }
+    if (dry) {   // the planner's own trial: executed k-steps of this N-tile count, nothing built
+        L.n_ksteps = 0;
+        for (int list = 0; list < nlists; ++list) L.n_ksteps += plan_list(bestOC, bestS, list, nullptr, nullptr, nullptr);
+        return UMX_OK;
+    }
     if (const char* e = getenv("UMX_PLAN_OVERRIDE")) {   // tuning aid: "layer:OC:S[,layer:OC:S...]" forces a layer's (OC, S)
         std::string spec(e);
         size_t pos = 0;
