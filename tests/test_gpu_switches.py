@@ -113,6 +113,7 @@ D2S_SHAPES = [
     (24, 3, 3, 32),    # 24: F 3, R 0 (6 tiles, no remainder tile, no fold); 48: two blocks of 6
     (33, 2, 3, 32),    # 33: F 4, R 1 (9 tiles, fold); 66: F 8, R 2 -> two blocks of 9 with remainder tiles
     (36, 2, 3, 64),    # the duo widths: 36 (9 tiles, fold) and 72 (two blocks of 9)
+    (40, 1, 3, 32),    # 40: F 5 -> two blocks of 5; 80 (the solo model's top layer, F 10) stays on the fused-phase kernel
     (12, 1, 5, 32),    # 5 x 5 filters: the phases have 9 / 6 / 6 / 4 taps in a 3 x 3 window; 24 -> 12: F 1 -> not eligible; 48 -> 24: 6 tiles
 ]
 

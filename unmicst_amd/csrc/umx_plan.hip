@@ -391,17 +391,19 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         if (L.d2s) {   // destination table of the depth-to-space epilogue (HConvParams::d2s_mix), in the destination's layout
             const Buffer& db = ctx->bufs[L.dst];
             const int dPix = db.planar ? 8 : h.Cds, dOct = db.planar ? L.outH * L.outW * 8 : 8;
-            int* const tab = reinterpret_cast<int*>(&ec[(size_t)4 * nb16]);
             const int per_z = 2 * nt16 + 8;
-            if (h.nblocks != 1 || 2 * per_z > 64 || L.nphase > 2) { *why = "internal: depth-to-space table"; return UMX_ERR_INVALID; }
+            if ((h.nblocks != 1 && L.d2s_R > 0) || 2 * per_z > 64 || L.nphase > 2) { *why = "internal: depth-to-space table"; return UMX_ERR_INVALID; }
+            for (int nb = 0; nb < h.nblocks; ++nb) {   // (every N-block carries its own copy behind its constants)
+            int* const tab = reinterpret_cast<int*>(&ec[(size_t)nb * per_blk + (size_t)4 * nb16]);
             for (int z = 0; z < L.nphase; ++z) {
-                for (int vo = 0; vo < 2 * nt16; ++vo) {
+                for (int vl = 0; vl < 2 * nt16; ++vl) {
+                    const int vo = nb * 2 * nt16 + vl;   // stored octet along the block's N axis
                     int d = -1;
                     if (vo < L.d2s_npb * L.d2s_F) {   // (make_d2s: the octets of slots 2i, 2i + 1 alternate)
                         const int pr = vo / (2 * L.d2s_F), rm = vo % (2 * L.d2s_F), j = 2 * pr + (rm & 1), o = rm / 2;
                         d = (L.d2s_oy[z][j] * L.outW + L.d2s_ox[z][j]) * dPix + o * dOct;
                     }
-                    tab[z * per_z + vo] = d;
+                    tab[z * per_z + vl] = d;
                 }
                 for (int j = 0; j < 4; ++j) {
                     const bool on = L.d2s_R > 0 && j < L.d2s_npb;
@@ -409,6 +411,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                     tab[z * per_z + 2 * nt16 + j] = on ? pp * dPix + L.d2s_F * dOct : -1;
                     tab[z * per_z + 2 * nt16 + 4 + j] = on ? L.d2s_oy[z][j] * 2 + L.d2s_ox[z][j] : 0;
                 }
+            }
             }
         }
         if (fuse_head) {
@@ -579,6 +582,7 @@ bool make_d2s(Launch& L) {
     int nz, npb;
     if (2 * F + rem >= 5 && 2 * F + rem <= 9) { nz = 1; npb = 4; }
     else if (F + rem >= 5 && F + rem <= 9) { nz = 2; npb = 2; }
+    // (two N-blocks per row parity -- F = 10, the solo model's top layer 160 -> 80 -- measured 20 % slower than the fused-phase form)
     else return false;
     if (L.app_src >= 0 && (!rem || L.app_c0 / 8 != F || (L.app_c0 % 8) / 2 < 1 || L.W < 16)) return false;   // appended channels ride in the remainder tile
     const int NT = npb * F / 2 + rem, Nv = NT * 16;
