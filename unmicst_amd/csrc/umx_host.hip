@@ -58,8 +58,14 @@ static int host_submit_impl(umx_ctx* ctx, int slot, bool sync_call, const void* 
     if (const char* e = getenv("UMX_HOST_SLABS")) S = std::max(1, std::min(atoi(e), S));
     // A synchronous call on a slide of one launch group has nothing to overlap: its upload, kernels and download go down ONE
     // stream in order, without the copy streams and the events that hand slabs from one stream to the next (a 1024 x 1024
-    // slide is a 1 - 3 ms call).  Submitted calls keep the copy streams: slide i+1's upload rides under slide i's kernels.
-    const bool single = S == 1 && sync_call;
+    // slide is a 1 - 3 ms call).  Submitted calls keep the copy streams: slide i+1's upload rides under slide i's kernels --
+    // unless the slide is so small (< 0.6 TFLOP, about 2 ms of kernels: the legacy model's 1024 x 1024 slide is 1 ms) that the
+    // cross-stream events cost more than the overlap returns: that call measured 1.03 ms on some boxes and 1.54 on others through
+    // the copy streams, 1.02 as one in-order stream.
+    double slide_flops = 0.0;
+    for (const Launch& L : ctx->plan) slide_flops += L.flops;
+    slide_flops *= (double)T;
+    const bool single = S == 1 && (sync_call || slide_flops < 0.6e12);
     const hipStream_t up_s = single ? ctx->stream : ctx->up_stream, dn_s = single ? ctx->stream : ctx->dn_stream;
     // this call's range flag: its own word, cleared in stream order in front of its kernels
     const int fw = 16 * (slot + 1);
