@@ -27,6 +27,7 @@ SWITCHES = [
     {"UMX_NO_FOLD": "1"},                   # two-group top convolution, input tiles as (hi, lo) planes
     {"UMX_NO_CONVT3": "1"},                 # narrow fused transposed convolution at two workgroups per CU
     {"UMX_NO_NT_TRIAL": "1"},               # per-phase transposed convolutions keep the widest N-block whatever their k-step fill
+    {"UMX_NO_D2S_SKIP": "1"},               # depth-to-space form: the k-steps of row -1 taps also multiply the odd rows' (zero) N-tiles
     {"UMX_NO_D2S": "1"},                    # narrow transposed convolutions on the fused-phase kernel instead of the depth-to-space form
     {"UMX_NO_PACKED_TILE": "1"},            # last N-tile of <= 8 real channels as (hi, lo) images and 3 products instead of packed [hi | lo] and 2
     {"UMX_NO_PACKED_TILE": "convt"},        # ... in the fused-phase transposed convolutions only

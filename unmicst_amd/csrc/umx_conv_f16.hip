@@ -292,52 +292,63 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
         for (int j = 0; j < kStageK; ++j)
             kbs[j] = (unsigned)*reinterpret_cast<const unsigned short*>(wl + (j * 4 + q) * 2) << 4;
         // the k-steps of this stage on one accumulator set (the phase loop is unrolled: static register indexing)
+        // one k-step on accumulator set h.  SK (depth-to-space form, one block of four phases): the k-step's four (tap, octet) pairs
+        // are taps the odd output rows do not have, so the N-tiles of that row pair -- [NT / 2, 2 (NT / 2)) -- hold zero weights:
+        // no fragment reads and no MFMAs for them (lu0.convT: 5 of 9 tiles in every second k-step)
+        auto kstep = [&](int h, int j, bool sk) {   // (sk: wave-uniform; the skippable tiles sit under one scalar branch each)
+            constexpr int kLo = NT / 2, kHi = 2 * (NT / 2);
+            auto live = [&](int n) { return !(D2S && sk && n >= kLo && n < kHi); };
+            const unsigned char* const bp = wl + 64 + j * (NT * 2048) + lane * 16;
+            const unsigned char* const ap = smem + kbs[j];
+            h8 ah[KMT], al[KMT];
+#pragma unroll
+            for (int m = 0; m < KMT; ++m) {
+                ah[m] = *reinterpret_cast<const h8*>(ap + abase[m]);
+                al[m] = *reinterpret_cast<const h8*>(ap + abase[m] + lo_off);
+            }
+            // B (weight) fragments are streamed with a prefetch distance of two N-tiles (three (hi, lo) pairs live),
+            // and the scheduler is asked for its DS-read / MFMA interleaving pipeline (iglp_opt 0): left to itself it
+            // puts a full lgkmcnt(0) wait between a fragment read and the MFMA block of the previous tile
+            // (+4 % on the whole bench; explicit sched_group_barrier patterns were slower).
+            constexpr int kBPre = 2;
+            h8 bhq[kBPre + 1], blq[kBPre + 1];
+#pragma unroll
+            for (int n = 0; n < kBPre && n < NT; ++n) {
+                if (!live(n)) continue;
+                bhq[n] = *reinterpret_cast<const h8*>(bp + n * 2048);
+                blq[n] = *reinterpret_cast<const h8*>(bp + n * 2048 + 1024);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                wq_one(j * NT + n);   // next stage's weight pieces, one per N-tile: spread under the MFMAs
+                __builtin_amdgcn_iglp_opt(0);
+                if (n + kBPre < NT && live(n + kBPre)) {
+                    bhq[(n + kBPre) % (kBPre + 1)] = *reinterpret_cast<const h8*>(bp + (n + kBPre) * 2048);
+                    blq[(n + kBPre) % (kBPre + 1)] = *reinterpret_cast<const h8*>(bp + (n + kBPre) * 2048 + 1024);
+                }
+                if (!live(n)) continue;
+                const h8 bh = bhq[n % (kBPre + 1)], bl = blq[n % (kBPre + 1)];
+#pragma unroll
+                for (int m = 0; m < KMT; ++m) {
+                    // weights are the A operand (rows = output channels), activations the B operand (columns =
+                    // pixels): D[channel][pixel], so a lane ends up with 4 consecutive channels of one pixel
+                    f32x4 c = accs[h][m][n];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[m], c, 0, 0, 0);
+                    if (!(PK && n == NT - 1)) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[m], c, 0, 0, 0);
+                    accs[h][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[m], c, 0, 0, 0);
+                }
+            }
+        };
+        // (depth-to-space form: one flag byte per k-step behind the k-map)
+        unsigned skips = 0u;
+        if constexpr (D2S) skips = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned*>(wl + 32));
 #pragma unroll
         for (int h = 0; h < NPH; ++h) {
             if (NPH > 1 && cur.phase != h) continue;   // wave-uniform
 #pragma unroll
             for (int j = 0; j < kStageK; ++j) {
                 if (j >= cur.nk) break;
-                {
-                    const unsigned char* const bp = wl + 64 + j * (NT * 2048) + lane * 16;
-                    const unsigned char* const ap = smem + kbs[j];
-                    h8 ah[KMT], al[KMT];
-#pragma unroll
-                    for (int m = 0; m < KMT; ++m) {
-                        ah[m] = *reinterpret_cast<const h8*>(ap + abase[m]);
-                        al[m] = *reinterpret_cast<const h8*>(ap + abase[m] + lo_off);
-                    }
-                    // B (weight) fragments are streamed with a prefetch distance of two N-tiles (three (hi, lo) pairs live),
-                    // and the scheduler is asked for its DS-read / MFMA interleaving pipeline (iglp_opt 0): left to itself it
-                    // puts a full lgkmcnt(0) wait between a fragment read and the MFMA block of the previous tile
-                    // (+4 % on the whole bench; explicit sched_group_barrier patterns were slower).
-                    constexpr int kBPre = 2;
-                    h8 bhq[kBPre + 1], blq[kBPre + 1];
-#pragma unroll
-                    for (int n = 0; n < kBPre && n < NT; ++n) {
-                        bhq[n] = *reinterpret_cast<const h8*>(bp + n * 2048);
-                        blq[n] = *reinterpret_cast<const h8*>(bp + n * 2048 + 1024);
-                    }
-#pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        wq_one(j * NT + n);   // next stage's weight pieces, one per N-tile: spread under the MFMAs
-                        __builtin_amdgcn_iglp_opt(0);
-                        if (n + kBPre < NT) {
-                            bhq[(n + kBPre) % (kBPre + 1)] = *reinterpret_cast<const h8*>(bp + (n + kBPre) * 2048);
-                            blq[(n + kBPre) % (kBPre + 1)] = *reinterpret_cast<const h8*>(bp + (n + kBPre) * 2048 + 1024);
-                        }
-                        const h8 bh = bhq[n % (kBPre + 1)], bl = blq[n % (kBPre + 1)];
-#pragma unroll
-                        for (int m = 0; m < KMT; ++m) {
-                            // weights are the A operand (rows = output channels), activations the B operand (columns =
-                            // pixels): D[channel][pixel], so a lane ends up with 4 consecutive channels of one pixel
-                            f32x4 c = accs[h][m][n];
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[m], c, 0, 0, 0);
-                            if (!(PK && n == NT - 1)) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[m], c, 0, 0, 0);
-                            accs[h][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[m], c, 0, 0, 0);
-                        }
-                    }
-                }
+                kstep(h, j, D2S && ((skips >> (8 * j)) & 1u) != 0u);
             }
         }
         wq_drain(cur.nk * NT);

@@ -74,6 +74,7 @@ struct Launch {
     int d2s_F = 0, d2s_R = 0; // full octets / remainder channels per phase
     int d2s_npb = 0;          // phases per block (4 or 2)
     int d2s_oy[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, d2s_ox[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};   // sub-pixel offset of (block, phase slot)
+    unsigned char d2s_tapmask[2][16] = {{0}, {0}};   // per block and tap of its window: bit j set = phase slot j has that tap
     int nt16 = 1;             // N-tiles per workgroup of the split-precision kernel
     int force_nt16 = 0;       // > 0: the planner's N-tile choice is overridden (its own trial of narrower N-blocks)
     int wshift = 0;           // weights are stored times 2^wshift

@@ -341,6 +341,16 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                         }
                         hdr[j * 4 + qq] = (unsigned short)slot;
                     }
+                    if (L.d2s && L.d2s_npb == 4 && !getenv("UMX_NO_D2S_SKIP")) {
+                        // depth-to-space form, one block of four phases: a k-step made only of taps the odd output rows (phase slots
+                        // 2, 3) do not have leaves their N-tiles without weights -- the kernel skips them (flag byte j behind the k-map)
+                        bool dead = true;
+                        for (int qq = 0; qq < 4; ++qq) {
+                            const Pair& pr2 = steps[ks][qq];
+                            if (pr2.tap >= 0 && (pr2.tap >= 16 || (L.d2s_tapmask[pr2.ph][pr2.tap] & 0xC))) dead = false;
+                        }
+                        reinterpret_cast<unsigned char*>(hdr)[32 + j] = dead ? 1 : 0;
+                    }
                     for (int n = 0; n < nt16; ++n)
                         for (int lane = 0; lane < 64; ++lane) {
                             const Pair& pr2 = steps[ks][lane >> 4];
@@ -579,6 +589,7 @@ bool make_d2s(Launch& L) {
         if (L.oy_off[ph] != (ph >> 1) || L.ox_off[ph] != (ph & 1) || L.g[0].taps[ph].empty() || L.g[0].packed[ph].empty()) return false;
     const int F = L.Cout / 8, R = L.Cout % 8, rem = R > 0 ? 1 : 0;
     if (R > 4 || F < 1) return false;
+    memset(L.d2s_tapmask, 0, sizeof L.d2s_tapmask);
     int nz, npb;
     if (2 * F + rem >= 5 && 2 * F + rem <= 9) { nz = 1; npb = 4; }
     else if (F + rem >= 5 && F + rem <= 9) { nz = 2; npb = 2; }
@@ -609,6 +620,7 @@ bool make_d2s(Launch& L) {
             L.d2s_ox[z][j] = L.ox_off[ph];
             for (size_t t = 0; t < g.taps[ph].size(); ++t) {
                 const size_t u = std::find(U.begin(), U.end(), g.taps[ph][t]) - U.begin();
+                if (u < 16) L.d2s_tapmask[z][u] |= (unsigned char)(1u << j);
                 for (int c = 0; c < g.C; ++c)
                     for (int co = 0; co < L.Cout; ++co) {
                         const int v = vchan(j, co);
