@@ -32,6 +32,7 @@ SWITCHES = [
     {"UMX_NO_PACKED_TILE": "1"},            # last N-tile of <= 8 real channels as (hi, lo) images and 3 products instead of packed [hi | lo] and 2
     {"UMX_NO_PACKED_TILE": "convt"},        # ... in the fused-phase transposed convolutions only
     {"UMX_PLAN_OVERRIDE": "lu0.conv:3:2,ld1.conv:1:1:12"},   # forced (octets per chunk, k-steps per stage[, piece-index array])
+    {"UMX_PLAN_NT": "lu2.convT:4"},         # forced N-tiles per workgroup of one layer (here 8 padded N-tiles in two blocks instead of 7 in one)
     {"UMX_PRECISION": "f32"},               # default precision from the environment
     {"UMX_ACT_SHIFT": "2"},                 # activations stored times 4
 ]
