@@ -145,3 +145,24 @@ def test_depth_to_space_transposed_convolution_shapes(shape):
     finally:
         del os.environ["UMX_NO_D2S"]
     assert np.abs(got - base).max() <= 2e-6, shape   # same arithmetic, other summation order
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.uint8])
+def test_raw_gather_equals_the_float64_image_path(dtype, reference, monkeypatch):
+    """UMX_NO_RAW_GATHER: without an intensity rescale the tile gather reads the raw planes and converts as it reads (one multiply,
+    never fused with the normalisation); with the switch the slide goes through the float64 image first.  Same bytes out, and the
+    same bytes as the float64 entry point fed with the host's im2double."""
+    blob, x, img, ref = reference
+    raw = np.random.default_rng(5).integers(0, np.iinfo(dtype).max + 1, size=(2, 150, 210)).astype(dtype)
+    with umx.Engine(HP, blob, max_batch=3) as eng:
+        direct = eng.infer_image_raw(raw, False, 0.3, 0.2)
+        rescaled = eng.infer_image_raw(raw, True, 0.3, 0.2)          # (rescale keeps the float64 image: min / max come first)
+        monkeypatch.setenv("UMX_NO_RAW_GATHER", "1")
+        staged = eng.infer_image_raw(raw, False, 0.3, 0.2)
+        rescaled2 = eng.infer_image_raw(raw, True, 0.3, 0.2)
+        planes = eng.infer_image(raw.astype(np.float64) * (1.0 / np.iinfo(dtype).max), 0.3, 0.2)
+    assert np.array_equal(direct, staged) and np.array_equal(rescaled, rescaled2)
+    # the reference's double uint8 cast of the float16 planes (umx_kernels.hip half_to_u8_kernel)
+    first = (np.float16(255) * planes).astype(np.uint8)
+    want = (255.0 * (first.astype(np.float64) * (1.0 / 255))).astype(np.uint8)
+    assert np.array_equal(direct, want)

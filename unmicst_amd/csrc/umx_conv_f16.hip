@@ -1027,8 +1027,8 @@ hipError_t launch_split_f32(const float* x, size_t npix, int C, int Cs, float sc
 // into the compact form [pixel]{hi[CW] | lo[CW]} the dense-K first layer and the raw-skip append read (8 bytes per pixel
 // instead of 32 for a two-channel input).  One thread per tile pixel.  Same float64 arithmetic as gather_normalise_kernel.
 // ------------------------------------------------------------------------------------------------------------
-template <int CW>
-__global__ void __launch_bounds__(256) gather_split_kernel(const double* __restrict__ image, int C_img, int band_row0,
+template <int CW, int SRC>
+__global__ void __launch_bounds__(256) gather_split_kernel(const void* __restrict__ image_v, double inv_max, int C_img, int band_row0,
                                                           int band_rows, TileGeom g, int Cn, double mean, double stdv,
                                                           int tile0, int ntiles, float scale, uint4* __restrict__ hi,
                                                           uint4* __restrict__ lo) {
@@ -1050,7 +1050,14 @@ __global__ void __launch_bounds__(256) gather_split_kernel(const double* __restr
             float f = 0.f;
             if (c < Cn) {
                 double v = 0.0;
-                if (inside) v = image[((size_t)(C_img == 1 ? 0 : c) * band_rows + (iy - band_row0)) * g.W + ix];
+                if (inside) {
+                    const size_t at = ((size_t)(C_img == 1 ? 0 : c) * band_rows + (iy - band_row0)) * g.W + ix;
+                    // SRC 1 / 2: the raw uint16 / uint8 plane; im2double is the host path's own multiply, one rounding, never fused
+                    // with the subtraction below (umx_kernels.hip raw_to_double_kernel: np.multiply(I, 1.0 / imax))
+                    if constexpr (SRC == 0) v = static_cast<const double*>(image_v)[at];
+                    else if constexpr (SRC == 1) v = __dmul_rn((double)static_cast<const unsigned short*>(image_v)[at], inv_max);
+                    else v = __dmul_rn((double)static_cast<const unsigned char*>(image_v)[at], inv_max);
+                }
                 f = (float)((v - mean) / stdv) * scale;
             }
             vh.h[c] = (_Float16)f;
@@ -1069,23 +1076,27 @@ __global__ void __launch_bounds__(256) gather_split_kernel(const double* __restr
     }
 }
 
-hipError_t launch_gather_split(const double* image, int C_img, int band_row0, int band_rows, const TileGeom& g, int Cn,
+// `raw_bits` 0: `image` holds float64 planes; 16 / 8: the raw integer planes (im2double happens in the gather)
+hipError_t launch_gather_split(const void* image, int raw_bits, int C_img, int band_row0, int band_rows, const TileGeom& g, int Cn,
                                double mean, double stdv, int tile0, int ntiles, float scale, _Float16* hi, _Float16* lo, int cw,
                                hipStream_t stream) {
     if (ntiles <= 0) return hipSuccess;
-    if (Cn > 8 || (cw > 0 && Cn > cw)) return hipErrorInvalidValue;
+    if (Cn > 8 || (cw > 0 && Cn > cw) || (raw_bits != 0 && raw_bits != 8 && raw_bits != 16)) return hipErrorInvalidValue;
     const size_t total = (size_t)ntiles * g.P * g.P;
     const unsigned blocks = (unsigned)((total + 255) / 256 < 256 * 16 ? (total + 255) / 256 : 256 * 16);
     uint4* const h4 = reinterpret_cast<uint4*>(hi);
     uint4* const l4 = reinterpret_cast<uint4*>(lo);
-#define UMX_GS(CWV) hipLaunchKernelGGL(gather_split_kernel<CWV>, dim3(blocks), dim3(256), 0, stream, image, C_img, band_row0, band_rows, g, \
-                                       Cn, mean, stdv, tile0, ntiles, scale, h4, l4)
+    const double inv_max = raw_bits == 16 ? 1.0 / 65535 : 1.0 / 255;
+#define UMX_GS2(CWV, SRCV) hipLaunchKernelGGL((gather_split_kernel<CWV, SRCV>), dim3(blocks), dim3(256), 0, stream, image, inv_max, C_img, \
+                                              band_row0, band_rows, g, Cn, mean, stdv, tile0, ntiles, scale, h4, l4)
+#define UMX_GS(CWV) do { if (raw_bits == 0) UMX_GS2(CWV, 0); else if (raw_bits == 16) UMX_GS2(CWV, 1); else UMX_GS2(CWV, 2); } while (0)
     if (cw == 0) UMX_GS(0);
     else if (cw == 1) UMX_GS(1);
     else if (cw == 2) UMX_GS(2);
     else if (cw == 4) UMX_GS(4);
     else return hipErrorInvalidValue;
 #undef UMX_GS
+#undef UMX_GS2
     return hipGetLastError();
 }
 

@@ -271,11 +271,18 @@ TileGeom geom_of(const umx_hparams& hp, int H, int W) {
 
 // tiles [t0, t1) of the slide (row-major tile index) -> probs_dev (tile t0 first): gather + normalise + UNet, in launch
 // groups of <= max_batch tiles
+bool gathers_raw(const umx_ctx* ctx) {
+    return ctx->precision == UMX_PREC_F16X3 && ctx->hp.nChannels <= 8 && ctx->bufs[0].Cs == 8 && !getenv("UMX_NO_RAW_GATHER");
+}
+
 int tiles_range(umx_ctx* ctx, const double* image_dev, int C_img, const TileGeom& g, int band_row0, int band_rows,
-                       double mean, double stdv, int t0, int t1, float* probs_dev) {
+                       double mean, double stdv, int t0, int t1, float* probs_dev, const void* raw_dev, int raw_bits) {
     const size_t prob_f = (size_t)g.P * g.P * ctx->hp.nClasses;
     if (ctx->site_gather < 0) ctx->site_gather = site_of(ctx, "pi2d.gather_normalise", "gather_normalise");
     const bool direct16 = ctx->precision == UMX_PREC_F16X3 && ctx->hp.nChannels <= 8 && ctx->bufs[0].Cs == 8;
+    if (raw_dev && !direct16) return fail(ctx, UMX_ERR_INVALID, "internal: raw planes handed to an engine that does not gather from them");
+    const void* const src = raw_dev ? raw_dev : (const void*)image_dev;
+    const double src_b = raw_dev ? raw_bits / 8.0 : 8.0;
     LaneLoop ll(ctx, t1 - t0);
     for (int t = t0, nb; t < t1; t += nb) {
         nb = ll.next(t1 - t);
@@ -283,10 +290,10 @@ int tiles_range(umx_ctx* ctx, const double* image_dev, int C_img, const TileGeom
                                                                 : cur_bufs(ctx)[0].d;
         {
             ProfScope ps(ctx, ctx->site_gather, 0.0,
-                         (double)nb * g.P * g.P * (8.0 * C_img + (ctx->in_cw ? 4.0 * ctx->in_cw : direct16 ? 32.0 : 4.0 * ctx->hp.nChannels)));
+                         (double)nb * g.P * g.P * (src_b * C_img + (ctx->in_cw ? 4.0 * ctx->in_cw : direct16 ? 32.0 : 4.0 * ctx->hp.nChannels)));
             if (direct16) {   // gather + normalise + (hi, lo) split in one pass
                 const Buffer& b0 = cur_bufs(ctx)[0];
-                HIP_TRY(ctx, launch_gather_split(image_dev, C_img, band_row0, band_rows, g, ctx->hp.nChannels, mean, stdv, t, nb,
+                HIP_TRY(ctx, launch_gather_split(src, raw_dev ? raw_bits : 0, C_img, band_row0, band_rows, g, ctx->hp.nChannels, mean, stdv, t, nb,
                                                  std::ldexp(1.f, ctx->act_shift), hi_of(b0), lo_of(b0, nb), ctx->in_cw, run_stream(ctx)));
             } else {
                 HIP_TRY(ctx, launch_gather_normalise(image_dev, C_img, band_row0, band_rows, g, ctx->hp.nChannels, mean, stdv, t,

@@ -96,8 +96,11 @@ static int host_submit_impl(umx_ctx* ctx, int slot, bool sync_call, const void* 
         }
         return UMX_OK;
     };
+    // raw planes without an intensity rescale: the tile gather converts as it reads (the float64 image -- 8 bytes written and
+    // 14 read per pixel and channel -- is never made)
+    const bool raw_gather = src_bits != 0 && !rescale && gathers_raw(ctx);
     auto convert = [&](int r0, int r1) -> int {   // raw rows -> float64 rows (im2double [+ rescale])
-        for (int c = 0; c < C_img && src_bits && r1 > r0; ++c) {
+        for (int c = 0; c < C_img && src_bits && !raw_gather && r1 > r0; ++c) {
             const size_t e0 = ((size_t)c * H + r0) * W;
             HIP_TRY(ctx, launch_raw_convert(d_raw + e0 * in_b, src_bits, (size_t)(r1 - r0) * W, rescale, mm + 16 * c,
                                             hs.d_image + e0, ctx->stream));
@@ -139,7 +142,9 @@ static int host_submit_impl(umx_ctx* ctx, int slot, bool sync_call, const void* 
         }
         if (tcut[s + 1] > tcut[s]) {
             float* const pr = hs.d_probs + (size_t)tcut[s] * g.P * g.P * K;
-            if ((rc = tiles_range(ctx, hs.d_image, C_img, g, 0, H, mean, stdv, tcut[s], tcut[s + 1], pr))) return rc;
+            if ((rc = tiles_range(ctx, hs.d_image, C_img, g, 0, H, mean, stdv, tcut[s], tcut[s + 1], pr, raw_gather ? d_raw : nullptr,
+                                  raw_gather ? src_bits : 0)))
+                return rc;
         }
         // image rows no later tile touches: below the first incomplete patch row
         const int y1 = s == S - 1 ? H : std::max(y_done, std::min(H, cut[s + 1] * g.sub - g.margin));
