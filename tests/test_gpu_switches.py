@@ -20,6 +20,7 @@ SWITCHES = [
     {"UMX_PLANAR": "0"},                    # NHWC activations everywhere
     {"UMX_PLANAR": "1"},                    # octet-planar wherever eligible (also behind per-phase transposed convolutions)
     {"UMX_XCD_ORDER": "0"},                 # plain workgroup id -> tile order
+    {"UMX_XCD_ORDER": "2"},                 # one-dimensional grids with (N-block, phase) fastest inside an XCD wherever a layer has several
     {"UMX_NO_KSTEP_CARRY": "1"},            # k-steps padded per chunk instead of carried into the next chunk
     {"UMX_NO_FUSED_HEAD": "1"},             # 1x1 head + softmax as its own kernel on an fp32 tensor
     {"UMX_NO_FUSED_CONVT": "1"},            # transposed convolutions one sub-pixel phase per workgroup

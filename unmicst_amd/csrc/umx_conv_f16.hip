@@ -72,9 +72,24 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
 
     // ---- workgroup -> (image group, spatial tile), N block, phase
     const int TWm = 1 << p.twm_log2, TH = 1 << p.th_log2;
-    int bid = blockIdx.x;
-    if (p.xcd_order) {   // consecutive ids go round-robin over the 8 XCDs: give each XCD a contiguous run of tiles, so that
-                         // tiles that share halo lines meet in ONE L2
+    int bid = blockIdx.x, nblk_i = blockIdx.y, z_i = NPH == 1 ? blockIdx.z : 0;
+    if (p.xcd_order == 2) {
+        // One-dimensional grid, (N-block, phase) fastest inside an XCD: the workgroups that read the SAME input tile run on one
+        // XCD at the same time and share its halo through that L2.  For the layers of many N-blocks x phases over small images
+        // (the solo model's 4 x 4 and 8 x 8-pixel transposed convolutions: 32 and 16 workgroups per tile) the x-fastest order
+        // keeps 16 - 64 different tiles resident per XCD, nothing is shared, and the layer runs at the fabric's 6 - 6.7 TB/s on
+        // 30 - 70 x its compulsory bytes.  Tiles are dealt to the XCDs in the same contiguous ranges as in order 1; the grid holds
+        // `tiles_per_xcd` = ceil(tiles / 8) slots per XCD, the spare ones leave at once.
+        const int YZ = p.nblocks * (NPH == 1 ? p.nphase : 1);
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int tl = idx / YZ, yz = idx - tl * YZ;
+        const int q8 = p.ntiles_grid >> 3, r8 = p.ntiles_grid & 7;   // the first r8 XCDs own q8 + 1 tiles, the others q8
+        bid = xcd < r8 ? xcd * (q8 + 1) + tl : r8 * (q8 + 1) + (xcd - r8) * q8 + tl;
+        nblk_i = yz % p.nblocks;
+        z_i = yz / p.nblocks;
+        if (tl >= (xcd < r8 ? q8 + 1 : q8)) return;   // (wave-uniform: the whole workgroup; the grid holds tiles_per_xcd slots per XCD)
+    } else if (p.xcd_order) {   // consecutive ids go round-robin over the 8 XCDs: give each XCD a contiguous run of tiles, so that
+                                // tiles that share halo lines meet in ONE L2
         const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7, idx = bid >> 3;
         bid = xcd < r8 ? xcd * (q8 + 1) + idx : r8 * (q8 + 1) + (xcd - r8) * q8 + idx;
     }
@@ -82,8 +97,8 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
     const int ty_i = bid % p.tiles_y; bid /= p.tiles_y;
     const int img0 = bid * p.imgs;
     const int y0 = ty_i * TH, x0 = tx_i * TWm;
-    const int nblk = blockIdx.y;
-    const HPhase& ph = p.ph[NPH == 1 ? blockIdx.z : 0];
+    const int nblk = nblk_i;
+    const HPhase& ph = p.ph[z_i];
     // diagnostic stamps (shader-clock cycles), wave 0 only: [0] prologue, [1] waiting for loads + barriers, [2] MFMA
     // blocks, [3] epilogue, [4] whole kernel
     long long t_in = 0, t_wait = 0, t_comp = 0, t_a = 0, t_b = 0, t_vm = 0, t_iss = 0;
@@ -713,7 +728,7 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
     };
     if constexpr (D2S) {
         static_assert(NPH == 1 && (KMT & 1) == 0 && !PK, "the depth-to-space form runs on the plain kernel");
-        const int z = blockIdx.z;
+        const int z = z_i;
         // (the table sits behind the epilogue constants in LDS; an entry is read where it is used: 9 of them held in registers
         // spilled 34)
         const int* const dtab = reinterpret_cast<const int*>(ec) + 4 * NT * 16 + z * (2 * NT + 8);
@@ -894,6 +909,10 @@ template <int NT, int KMT, int NPH, bool DBG, int MAXP, bool PK = false, bool D2
 static hipError_t launch_h_k(const HConvParams& p, hipStream_t stream) {
     const int img_groups = (p.B + p.imgs - 1) / p.imgs;
     dim3 grid((unsigned)(img_groups * p.tiles_y * p.tiles_x), (unsigned)p.nblocks, (unsigned)(NPH == 1 ? p.nphase : 1));
+    if (p.xcd_order == 2) {   // (the caller filled ntiles_grid / tiles_per_xcd)
+        if (p.ntiles_grid != (int)grid.x || p.tiles_per_xcd * 8 < p.ntiles_grid) return hipErrorInvalidValue;
+        grid = dim3((unsigned)(8 * p.tiles_per_xcd) * grid.y * grid.z, 1, 1);
+    }
     const size_t lds = (size_t)p.lds_bytes;
     const void* kern = reinterpret_cast<const void*>(conv_f16x3<NT, KMT, NPH, DBG, MAXP, PK, D2S>);
     if (lds > 48 * 1024) {

@@ -130,6 +130,31 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
     for (int gi = 0; gi < L.ngroups; ++gi)
         if (L.g[gi].src == 0 && ctx->in_cw && !L.use_first)
             return fail(ctx, UMX_ERR_INVALID, "internal: %s reads the compact input tiles through the generic kernel", L.name.c_str());
+    {   // workgroup order (HConvParams::xcd_order): (N-block, phase) fastest inside an XCD for the layers that the x-fastest order
+        // makes fabric-bound -- every one of a tile's N-blocks x phases workgroups re-reads its halo, and with 16 - 64 tiles resident
+        // per XCD none of it is shared: if those bytes over the layer's matrix time (its executed FLOPs at 0.9 PFLOP/s) exceed
+        // 4 TB/s the halo goes through ONE L2 instead.  (Settled per launch: the batch decides.  The solo model's 4 x 4 ... 16 x 16
+        // pixel transposed convolutions: 5.9 - 7 TB/s, -13 ... -30 %; the 9-tile layers of the 256-pixel graph: 2.4 - 2.8 TB/s, and
+        // order 2 costs them 8 - 17 % -- their weight slabs then compete for the L2.)  UMX_XCD_ORDER=2 forces it wherever there
+        // is more than one (N-block, phase); =1 keeps order 1.
+        const int ntiles = ((ns + p.imgs - 1) / p.imgs) * p.tiles_y * p.tiles_x;
+        const int YZ = p.nblocks * (p.fused_phases ? 1 : p.nphase);
+        static const char* xo = getenv("UMX_XCD_ORDER");
+        const bool force2 = xo && !strcmp(xo, "2");
+        bool want2 = force2;
+        if (!xo && YZ >= 4 && ntiles >= 64) {
+            double octets = 0.0;
+            for (int gi = 0; gi < L.ngroups; ++gi) octets += (double)((L.g[gi].C + 7) / 8);
+            const double halo_bytes = 1.3 * (double)p.nhalo * octets * 32.0 * (double)ntiles * YZ;   // (1.3: 128-byte lines of short rows)
+            const double matrix_s = L.exec_flops * ns / 0.9e15;
+            want2 = matrix_s > 0.0 && halo_bytes / matrix_s > 4e12;
+        }
+        if (p.xcd_order == 1 && YZ > 1 && want2) {
+            p.xcd_order = 2;
+            p.ntiles_grid = ntiles;
+            p.tiles_per_xcd = (ntiles + 7) / 8;
+        }
+    }
     char kn[48];
     // the instantiation as rocprofv3 names it (<NT, KMT, NPH>): bench.py groups the timed sites by kernel
     snprintf(kn, sizeof kn, "conv_f16x3<%d, %d, %d, false, %d, %s, %s>", L.nt16, p.kmt, p.fused_phases ? 4 : 1, p.maxp, p.pk ? "true" : "false",
@@ -142,6 +167,7 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
             long long* d = nullptr;
             HIP_TRY(ctx, hipMalloc((void**)&d, nwg * 7 * sizeof(long long)));
             p.dbg = d;
+            if (p.xcd_order == 2) p.xcd_order = 1;   // (the stamp records are indexed by the three-dimensional grid)
             HIP_TRY(ctx, launch_conv_f16(p, run_stream(ctx)));
             HIP_TRY(ctx, hipStreamSynchronize(run_stream(ctx)));
             std::vector<long long> hst(nwg * 7);

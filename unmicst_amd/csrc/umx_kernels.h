@@ -100,7 +100,8 @@ struct HConvParams {
     int piece_bytes;               // PP*OC*16: LDS bytes one piece fills (the image stays dense: slot = pixel*OC + octet)
     int inv_oc_q16;                // 65536/OC + 1: lane / OC == (lane * inv_oc_q16) >> 16 for lane < 64
     int kmt;                       // M-tiles per wave: 4 (plain kernel) or 2 (fused transposed convolution)
-    int xcd_order;                 // 1: workgroup ids are re-ordered so that each XCD (ids = x mod 8) walks a contiguous range of tiles
+    int xcd_order;                 // 1: workgroup ids are re-ordered so that each XCD (ids = x mod 8) walks a contiguous range of tiles;
+    int ntiles_grid, tiles_per_xcd;   // 2: the same ranges on a one-dimensional grid with (N-block, phase) fastest inside an XCD
     int maxp;                      // halo pieces per wave and chunk the launched instantiation indexes: 4 or 12
     int lo_off, b_off, lds_bytes;  // LDS byte offsets: lo planes, weight buffers; total dynamic LDS
     int wbuf_bytes;                // one weight buffer (there are two): 64 + S * NT * 2048

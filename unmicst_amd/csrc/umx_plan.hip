@@ -291,7 +291,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         h.xcd_order = 1;
         if (const char* e = getenv("UMX_XCD_ORDER")) {
             std::string spec(e);
-            h.xcd_order = (spec == "1" || spec == "all") ? 1 : 0;
+            h.xcd_order = (spec == "1" || spec == "2" || spec == "all") ? 1 : 0;   // ("2": run_launch_f16 turns 1 into 2)
             size_t pos = 0;
             while (pos < spec.size()) {
                 const size_t end = spec.find(',', pos);
