@@ -142,7 +142,10 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
         static const char* xo = getenv("UMX_XCD_ORDER");
         const bool force2 = xo && !strcmp(xo, "2");
         bool want2 = force2;
-        if (!xo && YZ >= 4 && ntiles >= 64) {
+        // (plain convolutions of 2 - 4 N-blocks: the blocks of a tile share its halo through the L2 and only 2 - 4 weight slabs
+        // compete for it -- the solo model's lu1.conv / lu2.conv -9 / -7 %, the 256-pixel graph's lu3.conv / lu4.conv -2 / -1 %)
+        if (!xo && !p.fused_phases && p.nphase == 1 && YZ >= 2 && YZ <= 4 && ntiles >= 64) want2 = true;
+        if (!xo && !want2 && YZ >= 4 && ntiles >= 64) {
             double octets = 0.0;
             for (int gi = 0; gi < L.ngroups; ++gi) octets += (double)((L.g[gi].C + 7) / 8);
             const double halo_bytes = 1.3 * (double)p.nhalo * octets * 32.0 * (double)ntiles * YZ;   // (1.3: 128-byte lines of short rows)
