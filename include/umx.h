@@ -216,7 +216,7 @@ UMX_API int umx_stitch_dev(umx_ctx* ctx, const float* probs_dev, int tpr0, int t
 /* Per-launch-site timing with HIP events on the ctx stream (used by bench.py for the roofline object). */
 typedef struct umx_prof_entry {
     char name[48];          /* layer name, e.g. "lu1.conv" */
-    char kernel[48];        /* kernel family, e.g. "conv_mfma_f32<NT=5>" */
+    char kernel[64];        /* kernel instantiation as rocprofv3 names it, e.g. "conv_f16x3<9, 4, 1, false, 4, false, false, false>" */
     int64_t launches;
     double total_ms;
     double flops_per_launch_sum;  /* sum over launches of algorithmic FLOPs (no padded work counted) */
@@ -225,11 +225,18 @@ typedef struct umx_prof_entry {
                                      UMX_PREC_F16X3, the three products per fp32 product included) */
     int64_t launches_seen;        /* every launch of the site while profiling was on; `launches` and the sums above cover the
                                      launches that were bracketed by events (all of them unless sampling) */
+    int32_t xcd_order;            /* conv_f16x3 sites, last launch: workgroup order (0 plain, 1 contiguous tile run per XCD, 2 (N-block,
+                                     phase) fastest inside an XCD) */
+    int32_t reserved;
 } umx_prof_entry;
 /* on = 0: off; 1: bracket every launch with two events; N >= 2: bracket every N-th launch of each site (two events per launch
  * cost the synthetic-256 step 1.1 % -- profiles/r03/prof_event_overhead.txt -- so bench.py samples).  Resets the counters. */
 UMX_API int umx_profile_enable(umx_ctx* ctx, int on);
 UMX_API int umx_profile_read(umx_ctx* ctx, umx_prof_entry* entries, int max_entries, int* n_entries);
+/* sizeof(umx_prof_entry) of THIS build: a binding whose mirror of the struct has another size must not call umx_profile_read
+ * (the struct grew in rounds 3 and 4; unmicst_amd/umx.py checks it when it loads the library, so that two builds compared
+ * through UMX_LIB cannot be decoded with the wrong stride). */
+UMX_API int umx_prof_entry_size(void);
 
 /* Host-side helpers exported for the CPU test-suite (no GPU needed): the double->float16 round-to-nearest-even
  * used by the fp16-compat stitch, and the library's view of a model (layer count, packed weight bytes, FLOPs). */

@@ -132,4 +132,5 @@ def test_precision_options_are_validated_before_any_device_work(lib):
                 umx.Engine(hp, blob, precision=prec)
             assert e.value.code == 3
     assert ctypes.sizeof(umx._Options) == 64      # umx_options: 4 + 12 reserved int32
-    assert ctypes.sizeof(umx.ProfEntry) == 48 + 48 + 8 + 4 * 8 + 8   # + launches_seen (sampled profiling)
+    # name[48] kernel[64] launches, 4 sums, launches_seen, (xcd_order, pers_grid) -- and the library reports the same size
+    assert ctypes.sizeof(umx.ProfEntry) == 48 + 64 + 8 + 4 * 8 + 8 + 8 == lib.umx_prof_entry_size()

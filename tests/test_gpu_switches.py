@@ -71,6 +71,29 @@ def test_switch_keeps_parity(env, reference, monkeypatch):
     assert np.abs(planes.astype(np.float32) - base.astype(np.float32)).max() <= 1e-3, env
 
 
+def _kernels_run(eng, x, key="kernel"):
+    eng.profile_enable(1)
+    eng.forward_tiles(x)
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    return {p["name"]: p[key] for p in prof if p["kernel"].startswith("conv_f16x3")}
+
+
+def test_forced_xcd_order_2_really_runs(reference, monkeypatch):
+    """UMX_XCD_ORDER used to be latched at the first launch of the process, so a later `=2` never took effect (and the
+    parametrised case above ran order 1).  The profile entry now carries the order a site's last launch used."""
+    blob, x, img, ref = reference
+    with umx.Engine(HP, blob, max_batch=5) as eng:
+        base = eng.forward_tiles(x)
+        assert 2 not in _kernels_run(eng, x, "xcd_order").values()     # (5 tiles: below the automatic rule's 64)
+    monkeypatch.setenv("UMX_XCD_ORDER", "2")
+    with umx.Engine(HP, blob, max_batch=5) as eng:
+        got = eng.forward_tiles(x)
+        orders = _kernels_run(eng, x, "xcd_order")
+    assert sum(1 for o in orders.values() if o == 2) >= 2, orders      # every layer with more than one (N-block, phase)
+    assert np.abs(got - ref).max() <= TILE_TOL and np.array_equal(got, base)
+
+
 @pytest.mark.parametrize("slabs", ["1", "2"])
 def test_host_slab_count_does_not_change_the_result(slabs, reference, monkeypatch):
     """UMX_HOST_SLABS: how many upload / download slabs the host entry points cut a slide into (1 = unpipelined)."""

@@ -54,7 +54,7 @@ int grow(umx_ctx* ctx, void** buf, size_t* cap, size_t bytes) {
 
 int site_of(umx_ctx* ctx, const std::string& name, const std::string& kernel) {
     for (size_t i = 0; i < ctx->sites.size(); ++i)
-        if (ctx->sites[i].name == name) return (int)i;
+        if (ctx->sites[i].name == name && ctx->sites[i].kernel == kernel) return (int)i;   // (a layer that runs on two kernels -- e.g. the persistent form for large launch groups only -- has two entries)
     ProfSite s;
     s.name = name;
     s.kernel = kernel;
@@ -139,7 +139,7 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
         // is more than one (N-block, phase); =1 keeps order 1.
         const int ntiles = ((ns + p.imgs - 1) / p.imgs) * p.tiles_y * p.tiles_x;
         const int YZ = p.nblocks * (p.fused_phases ? 1 : p.nphase);
-        static const char* xo = getenv("UMX_XCD_ORDER");
+        const char* const xo = getenv("UMX_XCD_ORDER");   // (read per launch: a switch set after the first launch of the process must count)
         const bool force2 = xo && !strcmp(xo, "2");
         bool want2 = force2;
         // (plain convolutions of 2 - 4 N-blocks: the blocks of a tile share its halo through the L2 and only 2 - 4 weight slabs
@@ -158,13 +158,13 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
             p.tiles_per_xcd = (ntiles + 7) / 8;
         }
     }
-    char kn[48];
+    char kn[64];
     // the instantiation as rocprofv3 names it (<NT, KMT, NPH>): bench.py groups the timed sites by kernel
     snprintf(kn, sizeof kn, "conv_f16x3<%d, %d, %d, false, %d, %s, %s>", L.nt16, p.kmt, p.fused_phases ? 4 : 1, p.maxp, p.pk ? "true" : "false",
              p.d2s ? "true" : "false");
     {
         // diagnostic: UMX_DEBUG_STAMPS=<layer name> prints the mean s_memtime segments of that layer's workgroups
-        static const char* dbg_layer = getenv("UMX_DEBUG_STAMPS");
+        const char* const dbg_layer = getenv("UMX_DEBUG_STAMPS");
         if (dbg_layer && L.name == dbg_layer) {
             const size_t nwg = (size_t)((ns + p.imgs - 1) / p.imgs) * p.tiles_y * p.tiles_x * p.nblocks * (p.fused_phases ? 1 : p.nphase);
             long long* d = nullptr;
@@ -198,7 +198,9 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
         HIP_TRY(ctx, launch_conv_first(f, run_stream(ctx)));
         return UMX_OK;
     }
-    ProfScope ps(ctx, site_of(ctx, L.name, kn), L.flops * ns, L.bytes * ns, L.exec_flops * ns);
+    const int site = site_of(ctx, L.name, kn);
+    ctx->sites[site].xcd_order = p.xcd_order;
+    ProfScope ps(ctx, site, L.flops * ns, L.bytes * ns, L.exec_flops * ns);
     HIP_TRY(ctx, launch_conv_f16(p, run_stream(ctx)));
     return UMX_OK;
 }
@@ -347,7 +349,8 @@ void umx_internal_set_destroy_hook(void (*hook)(umx_ctx*)) { g_destroy_hook = ho
 
 extern "C" {
 
-const char* umx_version(void) { return "umx 0.1 (gfx950)"; }
+const char* umx_version(void) { return "umx 0.4 (gfx950)"; }
+int umx_prof_entry_size(void) { return (int)sizeof(umx_prof_entry); }
 
 int umx_device_count(void) {
     int n = 0;
@@ -810,6 +813,7 @@ int umx_profile_read(umx_ctx* ctx, umx_prof_entry* entries, int max_entries, int
             e.bytes_per_launch_sum = s.bytes;
             e.exec_flops_sum = s.exec;
             e.launches_seen = s.seen;
+            e.xcd_order = s.xcd_order;
         }
         ++n;
     }

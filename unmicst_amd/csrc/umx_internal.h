@@ -96,6 +96,7 @@ struct ProfSite {
     std::string name, kernel;
     int64_t launches = 0, seen = 0;
     double total_ms = 0.0, flops = 0.0, bytes = 0.0, exec = 0.0;
+    int xcd_order = 0;   // of the site's last launch (conv_f16x3 only)
 };
 
 struct PendingEvent {

@@ -28,7 +28,7 @@ EXPORTS = [
     "umx_infer_image_raw", "umx_infer_image_raw_scaled", "umx_infer_image_raw_outlier", "umx_infer_image_raw_submit", "umx_infer_image_wait", "umx_tiff_lzw_decode",
     "umx_tiff_packbits_decode", "umx_shard_unique_id", "umx_shard_init", "umx_shard_fini", "umx_shard_plan",
     "umx_infer_image_sharded_dev",
-    "umx_band_tiles_dev", "umx_stitch_dev", "umx_profile_enable", "umx_profile_read", "umx_test_double_to_half",
+    "umx_band_tiles_dev", "umx_stitch_dev", "umx_profile_enable", "umx_profile_read", "umx_prof_entry_size", "umx_test_double_to_half",
     "umx_describe", "umx_describe_graph", "umx_version",
 ]
 
@@ -50,9 +50,10 @@ class _Options(ctypes.Structure):
 
 
 class ProfEntry(ctypes.Structure):
-    _fields_ = [("name", ctypes.c_char * 48), ("kernel", ctypes.c_char * 48), ("launches", ctypes.c_int64),
+    _fields_ = [("name", ctypes.c_char * 48), ("kernel", ctypes.c_char * 64), ("launches", ctypes.c_int64),
                 ("total_ms", ctypes.c_double), ("flops", ctypes.c_double), ("bytes", ctypes.c_double),
-                ("exec_flops", ctypes.c_double), ("launches_seen", ctypes.c_int64)]
+                ("exec_flops", ctypes.c_double), ("launches_seen", ctypes.c_int64), ("xcd_order", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 
 _lib = None
@@ -161,6 +162,10 @@ def load(path: Optional[str] = None):
     L.umx_describe_graph.argtypes = [ctypes.POINTER(_HP), ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.umx_describe_graph.restype = c_int
     L.umx_version.restype = ctypes.c_char_p
+    L.umx_prof_entry_size.restype = c_int
+    if L.umx_prof_entry_size() != ctypes.sizeof(ProfEntry):
+        raise RuntimeError("libumx (%s) lays umx_prof_entry out in %d bytes, this binding in %d: mixed builds" % (
+            L.umx_version().decode(), L.umx_prof_entry_size(), ctypes.sizeof(ProfEntry)))
     for name in ("umx_set_stream", "umx_synchronize", "umx_forward_tiles", "umx_forward_tiles_dev", "umx_tile_grid",
                  "umx_infer_image", "umx_infer_image_dev", "umx_band_tiles_dev", "umx_stitch_dev",
                  "umx_profile_enable", "umx_profile_read", "umx_describe"):
@@ -482,5 +487,5 @@ class Engine:
             e = arr[i]
             out.append({"name": e.name.decode(), "kernel": e.kernel.decode(), "launches": int(e.launches),
                         "total_ms": float(e.total_ms), "flops": float(e.flops), "bytes": float(e.bytes),
-                        "exec_flops": float(e.exec_flops), "seen": int(e.launches_seen)})
+                        "exec_flops": float(e.exec_flops), "seen": int(e.launches_seen), "xcd_order": int(e.xcd_order)})
         return out
