@@ -8,9 +8,10 @@ N = 1 goes through the library's host entry point (umx_infer_image_raw: uint16 p
 two copy streams under the tile kernels); the same slide resident in HBM (umx_infer_image_dev) is timed right after it
 and reported as `resident` in the same JSON line (kernel-only number, never `value`).
 Default workload (``wsi-synth256``): BASELINE.json's metric tile (256x256x2, v2 graph, duo widths 36..1152, seeded
-weights) on a 2-channel synthetic slide of 2048*N x 16384 px -- each rank holds a 2048-row band, so per-GPU work is
-fixed ("weak") and N=8 is exactly the 16384 x 16384 slide of the north star (86 x 86 = 7396 tiles).  ``--scaling strong``
-keeps the 16384 x 16384 slide at every N.  Other workloads are parity-test configs of BASELINE.json, not the headline.
+weights) on the north star's 2-channel synthetic 16384 x 16384 slide (86 x 86 = 7396 tiles) at EVERY N ("strong": N ranks split
+the same slide into bands of patch rows; the N = 1 line is the denominator of the 1 -> 8 curve, 20 steps = 7 s of timed region).
+``--scaling weak`` gives every rank a 2048-row band of a 2048*N x 16384 slide instead (946 tiles per GPU: rounds 1-3's line; at
+N = 1 the default line carries it as `weak_band`).  Other workloads are parity-test configs of BASELINE.json, not the headline.
 
 Prints ONE JSON line on rank 0.  Launch: `python bench.py [--gpus N]` -- for N > 1 outside torch.distributed.run this
 process starts `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` as a CHILD (before anything
@@ -48,9 +49,10 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="wsi-synth256", choices=sorted(WORKLOADS) + ["train-synth256"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: every rank holds a band of --band-rows rows (slide grows with N); strong: the slide of "
-                         "8 bands (16384 rows by default) at every N")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="strong (default for the 16384-wide workloads): the slide of 8 bands (16384 rows: the north star's slide) at "
+                         "every N; weak (default for the fixed-size parity configs): every rank holds a band of --band-rows rows "
+                         "(the slide grows with N)")
     ap.add_argument("--train-batch", type=int, default=8, help="train-synth256: images per optimisation step")
     ap.add_argument("--batch", type=int, default=0, help="tiles per UNet launch group (0: umx.auto_batch -- 2^24 pixels per group, "
                                                       "i.e. 256 tiles of the 256-pixel metric tile)")
@@ -60,9 +62,10 @@ def parse_args(argv=None):
     ap.add_argument("--cols", type=int, default=0, help="override slide width")
     ap.add_argument("--cpu-seconds", type=float, default=45.0, help="budget of the CPU-baseline legs (0 = skip)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-layer table to stderr")
-    ap.add_argument("--profile-every", type=int, default=4,
+    ap.add_argument("--profile-every", type=int, default=5,
                     help="bracket every N-th launch of each layer with HIP events inside the timed region (1: every launch, "
-                         "costs the synthetic-256 step 1.1 %%)")
+                         "costs the synthetic-256 step 1.1 %%; 5 is coprime with the 29 / 4 launch groups of the default slide / band, "
+                         "so the sampled launches walk through every group position)")
     ap.add_argument("--slabs", type=int, default=2, help="N>1 path: row slabs per band (stitch + async all-gather each)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N>1 code path (band halo exchange + slab all-gathers) even in a world of one rank")
@@ -74,7 +77,10 @@ def parse_args(argv=None):
     ap.add_argument("--master-port", type=int, default=29577)
     ap.add_argument("--dry-launch", action="store_true",
                     help="N>1 launch test: every rank prints its rank/world line and exits before touching a GPU")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.scaling is None:
+        args.scaling = "strong" if args.workload in ("wsi-synth256", "solo-16384") else "weak"
+    return args
 
 
 def self_launch(args):
@@ -428,6 +434,36 @@ def main():
                          "calls": ns, "note": "synchronous umx_infer_image_raw(rescale=1), one slide at a time: the per-file "
                                               "driver's call (`value` above streams two slides through submit / wait)"}
     res_elapsed, res_prof, res_r = timed(step_resident)
+    # rounds 1-3 quoted the 2048-row band of the same slide (946 tiles: one rank's share at N = 8): kept beside the slide at N = 1
+    weak_band = None
+    if not sharded and args.workload == "wsi-synth256" and args.scaling == "strong" and host_elapsed is not None and H > 2048:
+        Hb = 2048
+        nb_r, nb_c, _, _ = eng.tile_grid(Hb, W)
+        band_u16 = torch.empty((C_img, Hb, W), dtype=torch.int16).pin_memory()
+        band_u16.copy_(host_u16[:, :Hb])
+        band_outs = [torch.empty((K, Hb, W), dtype=torch.uint8).pin_memory() for _ in range(2)]
+
+        def step_band():
+            slot = step_band.n & 1
+            step_band.n += 1
+            if len(inflight) == 2:
+                eng.infer_image_wait(inflight.pop(0))
+            eng.infer_image_raw_submit(slot, band_u16.data_ptr(), 16, C_img, Hb, W, False, mean, std, band_outs[slot].data_ptr())
+            inflight.append(slot)
+        step_band.n = 0
+        for _ in range(2):
+            step_band()
+        fence()
+        nbs = 40
+        t0 = time.perf_counter()
+        for _ in range(nbs):
+            step_band()
+        fence()
+        dtb = time.perf_counter() - t0
+        weak_band = {"value": round(nb_r * nb_c * nbs / dtb, 2), "unit": "tiles/s", "tiles_per_step": int(nb_r * nb_c), "slide": [Hb, W],
+                     "steps": nbs, "ms_per_step": round(1e3 * dtb / nbs, 3),
+                     "note": "the first 2048 rows as a slide of their own, same host path (H2D + D2H inside): the workload of the "
+                             "round-1..3 lines"}
     # the two paths must agree: uint8 planes of the host path == np.uint8(255 * fp16 planes) of the resident path
     with torch.cuda.stream(work):
         if not sharded:
@@ -479,7 +515,7 @@ def main():
             "resident": {"value": round(tiles_total * args.steps / res_elapsed, 2), "unit": "tiles/s",
                          "ms_per_step": round(1e3 * res_elapsed / args.steps, 3),
                          "note": "same slide already in HBM as float64, result left in HBM (no H2D / D2H): kernel-only"},
-            "host_sync": host_sync, "ranks": ranks,
+            "host_sync": host_sync, "weak_band": weak_band, "ranks": ranks,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -10,6 +10,11 @@ os.environ.setdefault("OMP_NUM_THREADS", _NT)
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 os.environ.setdefault("MKL_NUM_THREADS", _NT)
 
+# The test processes import torch at some point (oracles, sharding, the bench): bind libumx to torch's HIP runtime whatever the import
+# order.  The product default -- the system ROCm runtime unless torch is already imported -- is what the CLI subprocesses of
+# tests/test_gpu_cli.py run with (they drop this variable).
+os.environ.setdefault("UMX_HIP_RUNTIME", "torch")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

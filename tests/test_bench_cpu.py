@@ -30,16 +30,17 @@ def test_bench_gpus_2_launches_two_ranks():
     assert len(lines) == 1, r.stdout[-800:]
     blk = json.loads(lines[0])["ranks"]
     assert blk["world_size_from_communicator"] == 2 and blk["backend"] == "gloo"
-    # default workload, weak scaling: 2 bands of 2048 rows x 16384 columns of 192-pixel sub-patches
-    assert blk["patch_rows"] == 22 and blk["patch_cols"] == 86
+    # default workload, strong scaling (round 4): the north star's 16384 x 16384 slide, 86 x 86 sub-patches of 192 pixels, split into
+    # two bands of 43 patch rows
+    assert blk["patch_rows"] == 86 and blk["patch_cols"] == 86
     per = blk["per_rank"]
     assert [p["rank"] for p in per] == [0, 1]
-    assert per[0]["patch_row0"] == 0 and per[0]["patch_row1"] == per[1]["patch_row0"] and per[1]["patch_row1"] == 22
-    assert sum(p["tiles"] for p in per) == blk["tiles_total"] == 22 * 86
+    assert per[0]["patch_row0"] == 0 and per[0]["patch_row1"] == per[1]["patch_row0"] == 43 and per[1]["patch_row1"] == 86
+    assert sum(p["tiles"] for p in per) == blk["tiles_total"] == 86 * 86
     assert per[0]["owned_image_rows"][0] == 0 and per[0]["owned_image_rows"][1] == per[1]["owned_image_rows"][0]
-    assert per[1]["owned_image_rows"][1] == 4096
+    assert per[1]["owned_image_rows"][1] == 16384
     ag = blk["allgather_bytes_per_step"]
-    assert sum(ag["contributed_per_rank"]) == ag["received_per_rank"] == 3 * 4096 * 16384 * 2
+    assert sum(ag["contributed_per_rank"]) == ag["received_per_rank"] == 3 * 16384 * 16384 * 2
 
 
 def test_bench_rejects_a_world_that_does_not_match_gpus():
@@ -54,4 +55,7 @@ def test_bench_strong_and_weak_slide_sizes():
     import bench
     a = bench.parse_args(["--gpus", "4", "--scaling", "strong"])
     assert a.scaling == "strong" and a.gpus == 4
+    # defaults: the north star's slide at every N for the 16384-wide workloads, the fixed-size parity configs as they are
+    assert bench.parse_args([]).scaling == "strong" and bench.parse_args(["--workload", "solo-16384"]).scaling == "strong"
+    assert bench.parse_args(["--workload", "duo-4096"]).scaling == "weak" and bench.parse_args(["--scaling", "weak"]).scaling == "weak"
     assert bench.WORKLOADS["solo-16384"][0] == "nucleiDAPI1-5"

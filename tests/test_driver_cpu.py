@@ -234,3 +234,17 @@ def test_driver_end_to_end_with_oracle_engine(tmp_path, monkeypatch):
     driver.run("unmicst-legacy", [str(reg / "s.tif"), "--model", str(models / "nucleiDAPI"), "--outputPath",
                                   str(tmp_path / "o6"), "--scalingFactor", "0.5"])     # not the fast path
     assert "raw" not in seen and seen.pop("img").shape == (150, 160)
+
+
+def test_preview_page_by_lookup_equals_the_float64_recipe():
+    """driver.preview_u8: np.uint8(255 * (im2double(raw) / max)) through a table of the 2^16 (2^8) possible values."""
+    from unmicst_amd import driver, imtools
+    rng = np.random.default_rng(5)
+    for dt, top in ((np.uint16, 51234), (np.uint8, 201), (np.uint16, 65535)):
+        raw = rng.integers(0, top + 1, (300, 257)).astype(dt)
+        raw[17, 5] = top
+        rawI = imtools.im2double(raw)
+        want = np.uint8(255 * (rawI / np.max(rawI)))
+        assert np.array_equal(driver.preview_u8(raw), want)
+    small = rng.integers(0, 4000, (10, 12)).astype(np.uint16)          # (below the table's break-even: the direct recipe)
+    assert np.array_equal(driver.preview_u8(small), np.uint8(255 * (imtools.im2double(small) / np.max(imtools.im2double(small)))))

@@ -60,11 +60,14 @@ def test_legacy_script_in_process(workspace):
 def test_wrapper_subprocess_stack_output(workspace):
     """The CI recipe of the reference (.github/workflows/ci.yml:34-35): wrapper, --stackOutput."""
     base, models, img = workspace
-    env = dict(os.environ, UMX_MODELS_DIR=models)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "unmicstWrapper.py"), "--tool", "unmicst-legacy",
+    env = dict(os.environ, UMX_MODELS_DIR=models, UMX_CLI_TIMING="1")
+    env.pop("UMX_HIP_RUNTIME", None)     # the product default: the per-file tools bind the system HIP runtime and never import torch
+    r = subprocess.run([sys.executable, "-X", "importtime", os.path.join(ROOT, "unmicstWrapper.py"), "--tool", "unmicst-legacy",
                         "--channel", "2", "--stackOutput", "--outputPath", str(base / "out_b"), img],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+    assert "umx-cli-timing" in r.stderr
+    assert not any(l.rstrip().endswith("| torch") for l in r.stderr.splitlines() if l.startswith("import time:")), "the CLI imported torch"
     stack = tiffio.imread_all(str(base / "out_b" / "105_Probabilities_2.tif"))
     prev = tiffio.imread_all(str(base / "out_b" / "qc" / "105_Preview_2.tif"))
     assert stack.shape == (3, 832, 960) and prev.shape == (2, 832, 960)
@@ -127,7 +130,7 @@ def test_clean_checkout_runs_on_the_shipped_models_directory(workspace):
     weights come from <repo>/models/nucleiDAPI/umx_model.npz (reference UnMicst.py:547,556: models/<--model>)."""
     base, _, img = workspace
     out = str(base / "out_clean")
-    env = {k: v for k, v in os.environ.items() if k != "UMX_MODELS_DIR"}
+    env = {k: v for k, v in os.environ.items() if k not in ("UMX_MODELS_DIR", "UMX_HIP_RUNTIME")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "unmicstWrapper.py"), "--tool", "unmicst-legacy", img, "--channel", "2",
                         "--outputPath", out], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -155,7 +158,7 @@ def test_duo_script_on_a_two_page_ome_tiff_4096(tmp_path):
     tiffio.imsave(img, planes[0], append=False)
     tiffio.imsave(img, planes[1], append=True)
     out = str(tmp_path / "out")
-    env = {k: v for k, v in os.environ.items() if k != "UMX_MODELS_DIR"}
+    env = {k: v for k, v in os.environ.items() if k not in ("UMX_MODELS_DIR", "UMX_HIP_RUNTIME")}
     env["UMX_SYNTHETIC_WEIGHTS"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "UnMicst2.py"), img, "--channel", "0", "1", "--stackOutput",
                         "--outputPath", out], capture_output=True, text=True, timeout=900, env=env)

@@ -219,7 +219,7 @@ def imsave(path: str, img: np.ndarray, append: bool = False) -> None:
             pos = f.tell()
             pos += (-pos) % 16
             f.seek(pos)
-            f.write(img.tobytes())
+            f.write(memoryview(img).cast("B"))       # (no tobytes(): a page of a 16384 x 16384 slide is 268 MB)
             ifd_pos = f.tell()
             ifd_pos += (-ifd_pos) % 8
             f.seek(ifd_pos)
@@ -230,7 +230,7 @@ def imsave(path: str, img: np.ndarray, append: bool = False) -> None:
     with open(path, "wb") as f:
         f.write(b"II" + struct.pack("<HHHQ", 43, 8, 0, 0))
         pos = 16
-        f.write(img.tobytes())
+        f.write(memoryview(img).cast("B"))
         ifd_pos = pos + img.nbytes
         ifd_pos += (-ifd_pos) % 8
         f.seek(ifd_pos)

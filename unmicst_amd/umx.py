@@ -64,12 +64,14 @@ def _bind_hip_runtime() -> str:
 
     libumx.so is linked without a HIP runtime dependency.  PyTorch wheels bundle their own libamdhip64 +
     libhsa-runtime64; a second copy (e.g. /opt/rocm's) initialised in the same process leaves one of the two
-    without a GPU.  Policy (UMX_HIP_RUNTIME = auto | torch | system, default auto): use PyTorch's copy whenever
-    PyTorch is importable -- the multi-GPU path and bench.py need torch.distributed in the same process -- else
-    the system ROCm runtime.
+    without a GPU.  Policy (UMX_HIP_RUNTIME = auto | torch | system, default auto): PyTorch's copy if PyTorch is ALREADY
+    imported in this process (bench.py, the multi-GPU path and the tests import it first: torch.distributed has to share
+    the runtime), else the system ROCm runtime -- the per-file command-line tools never need torch, and importing it only
+    to find a libamdhip64 cost them 1.5 - 2 s of a 2 - 3 s run (profiles/r04/cli_walltime.txt).  `torch`: import it if needed.
     """
+    import sys
     mode = os.environ.get("UMX_HIP_RUNTIME", "auto")
-    if mode in ("auto", "torch"):
+    if mode == "torch" or (mode == "auto" and "torch" in sys.modules):
         try:
             import torch  # noqa: F401  (loads its bundled libamdhip64.so)
             cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
