@@ -43,7 +43,10 @@ static int host_submit_impl(umx_ctx* ctx, int slot, bool sync_call, const void* 
     const size_t raw_b = src_bits ? plane * C_img * in_b : 0;
     const size_t mm_off = (raw_off + raw_b + 255) & ~(size_t)255;
     int rc;
-    if ((rc = grow(ctx, (void**)&hs.d_image, &hs.image_cap, plane * C_img * sizeof(double)))) return rc;
+    // raw planes without an intensity rescale: the tile gather converts as it reads (the float64 image -- 8 bytes written and
+    // 14 read per pixel and channel -- is never made, and not allocated either: 4.3 GB for a two-channel 16384 x 16384 slide)
+    const bool raw_gather = src_bits != 0 && !rescale && gathers_raw(ctx);
+    if (!raw_gather && (rc = grow(ctx, (void**)&hs.d_image, &hs.image_cap, plane * C_img * sizeof(double)))) return rc;
     if ((rc = grow(ctx, &hs.d_out, &hs.out_cap, mm_off + 64 * (size_t)C_img))) return rc;
     if ((rc = grow(ctx, (void**)&hs.d_probs, &hs.probs_cap, (size_t)g.npr * g.npc * g.P * g.P * K * sizeof(float)))) return rc;
     unsigned char* const base = (unsigned char*)hs.d_out;
@@ -96,9 +99,6 @@ static int host_submit_impl(umx_ctx* ctx, int slot, bool sync_call, const void* 
         }
         return UMX_OK;
     };
-    // raw planes without an intensity rescale: the tile gather converts as it reads (the float64 image -- 8 bytes written and
-    // 14 read per pixel and channel -- is never made)
-    const bool raw_gather = src_bits != 0 && !rescale && gathers_raw(ctx);
     auto convert = [&](int r0, int r1) -> int {   // raw rows -> float64 rows (im2double [+ rescale])
         for (int c = 0; c < C_img && src_bits && !raw_gather && r1 > r0; ++c) {
             const size_t e0 = ((size_t)c * H + r0) * W;
@@ -142,7 +142,7 @@ static int host_submit_impl(umx_ctx* ctx, int slot, bool sync_call, const void* 
         }
         if (tcut[s + 1] > tcut[s]) {
             float* const pr = hs.d_probs + (size_t)tcut[s] * g.P * g.P * K;
-            if ((rc = tiles_range(ctx, hs.d_image, C_img, g, 0, H, mean, stdv, tcut[s], tcut[s + 1], pr, raw_gather ? d_raw : nullptr,
+            if ((rc = tiles_range(ctx, raw_gather ? nullptr : hs.d_image, C_img, g, 0, H, mean, stdv, tcut[s], tcut[s + 1], pr, raw_gather ? d_raw : nullptr,
                                   raw_gather ? src_bits : 0)))
                 return rc;
         }
