@@ -69,9 +69,11 @@ def parse_args(argv=None):
     ap.add_argument("--slabs", type=int, default=2, help="N>1 path: row slabs per band (stitch + async all-gather each)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N>1 code path (band halo exchange + slab all-gathers) even in a world of one rank")
-    ap.add_argument("--native-shard", action="store_true",
-                    help="N>1 path through the C ABI (umx_infer_image_sharded_dev: RCCL inside libumx) instead of "
-                         "unmicst_amd/sharding.py over torch.distributed; torch only hands the communicator id to the ranks")
+    ap.add_argument("--native-shard", action="store_true", help="(the default since round 4; kept for old command lines)")
+    ap.add_argument("--torch-shard", action="store_true",
+                    help="N>1 path through unmicst_amd/sharding.py over torch.distributed instead of the C ABI "
+                         "(umx_infer_image_sharded_dev: RCCL inside libumx, the default; torch only hands the communicator id to "
+                         "the ranks, and sharding.py checks the first slide)")
     ap.add_argument("--resident-only", action="store_true",
                     help="time only the HBM-resident slide (kernel-only; the line's value is then NOT the section-8(d) metric)")
     ap.add_argument("--master-port", type=int, default=29577)
@@ -332,22 +334,49 @@ def main():
             eng.infer_image_dev(band_f64.data_ptr(), C_img, H, W, mean, std, umx.MODE_ACCUMULATE, umx.STITCH_FP16_COMPAT,
                                 dev_out.data_ptr())
     else:
-        if args.native_shard:
-            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-            if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(umx.Engine.shard_unique_id()), dtype=torch.uint8))
-            dist.broadcast(idt, 0)
-            eng.shard_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
-            full_native = torch.empty((K, H, W), dtype=torch.float16, device=dev)
+        def torch_call(band):
+            return sharding.infer_image_sharded(eng, band, r0, H, W, mean, std, umx.MODE_ACCUMULATE,
+                                                umx.STITCH_FP16_COMPAT, nslabs=args.slabs, sync=False)
+        sharded_call = torch_call
+        shard_path = {"path": "unmicst_amd/sharding.py over torch.distributed", "native_checked_against_torch_path": None, "note": None}
+        if not args.torch_shard:
+            # the in-library schedule (RCCL inside libumx).  Every rank tries; the world agrees (MIN over the ranks) before anyone
+            # uses it, and its first slide is compared with sharding.py's on every rank: anything short of bit-equality and the
+            # whole world times the torch path instead, saying so in the line.
+            note = None
+            try:
+                idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(umx.Engine.shard_unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, 0)
+                eng.shard_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+                full_native = torch.empty((K, H, W), dtype=torch.float16, device=dev)
 
-            def sharded_call(band):
-                eng.infer_image_sharded_dev(band.data_ptr(), C_img, H, W, r0, band.shape[1], mean, std, umx.MODE_ACCUMULATE,
-                                            umx.STITCH_FP16_COMPAT, args.slabs, full_native.data_ptr())
-                return full_native
-        else:
-            def sharded_call(band):
-                return sharding.infer_image_sharded(eng, band, r0, H, W, mean, std, umx.MODE_ACCUMULATE,
-                                                    umx.STITCH_FP16_COMPAT, nslabs=args.slabs, sync=False)
+                def native_call(band):
+                    eng.infer_image_sharded_dev(band.data_ptr(), C_img, H, W, r0, band.shape[1], mean, std, umx.MODE_ACCUMULATE,
+                                                umx.STITCH_FP16_COMPAT, args.slabs, full_native.data_ptr())
+                    return full_native
+                okv = 1
+            except Exception as e:   # noqa: BLE001
+                okv, note = 0, "native init failed on rank %d: %s" % (rank, e)
+            flag = torch.tensor([okv], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                with torch.cuda.stream(work):
+                    a = native_call(band_f64).clone()
+                    b = torch_call(band_f64)
+                    same = torch.tensor([1 if torch.equal(a, b) else 0], dtype=torch.int32, device=dev)
+                work.synchronize()
+                dist.all_reduce(same, op=dist.ReduceOp.MIN)
+                if int(same.item()) == 1:
+                    sharded_call = native_call
+                    shard_path = {"path": "umx_infer_image_sharded_dev (RCCL inside libumx)", "native_checked_against_torch_path": True,
+                                  "note": None}
+                else:
+                    shard_path["native_checked_against_torch_path"] = False
+                    shard_path["note"] = "the native path's first slide differed from sharding.py's on some rank: torch path timed"
+            else:
+                shard_path["note"] = note or "native init failed on another rank: torch path timed"
         y0, y1 = sharding.owned_rows(pa, pb, npr, sub, margin, H)
         # slides are streamed: the band of slide i+1 goes up on `up` and the stitched band of slide i-1 comes down on `dn`
         # while slide i computes on `work` (two device input buffers, two pinned output buffers, events between the streams)
@@ -515,7 +544,7 @@ def main():
             "resident": {"value": round(tiles_total * args.steps / res_elapsed, 2), "unit": "tiles/s",
                          "ms_per_step": round(1e3 * res_elapsed / args.steps, 3),
                          "note": "same slide already in HBM as float64, result left in HBM (no H2D / D2H): kernel-only"},
-            "host_sync": host_sync, "weak_band": weak_band, "ranks": ranks,
+            "host_sync": host_sync, "weak_band": weak_band, "ranks": ranks, "shard_path": shard_path if sharded else None,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

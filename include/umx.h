@@ -185,6 +185,22 @@ UMX_API int umx_infer_image_wait(umx_ctx* ctx, int slot);
 typedef struct umx_unique_id { char internal[128]; } umx_unique_id;   /* == ncclUniqueId */
 UMX_API int umx_shard_unique_id(umx_unique_id* out);
 UMX_API int umx_shard_init(umx_ctx* ctx, const umx_unique_id* id, int rank, int world);
+/* The inter-rank operations of the schedule as a table: umx_shard_init fills it with RCCL; umx_shard_init_transport takes the
+ * caller's instead (MPI, sockets, a host-staged stand-in -- how tests/test_gpu_parity.py runs the band / halo / scatter code of
+ * umx_infer_image_sharded_dev in worlds of 2 and 3 on one GPU, where RCCL refuses to put two ranks on a device).  Semantics are
+ * RCCL's: `stream` is a hipStream_t; an operation takes effect in stream order (a blocking implementation synchronises the stream,
+ * moves the bytes and returns); send / recv between group_start and group_end may be matched in any order (either may be NULL);
+ * all_gather: every rank contributes bytes_per_rank at send_dev and receives world * bytes_per_rank at recv_dev, rank order;
+ * non-zero return = failure (UMX_ERR_HIP).  `peer` is a rank of the world given to the init call. */
+typedef struct umx_shard_transport {
+    void* user;
+    int (*send)(void* user, const void* dev, size_t bytes, int peer, void* stream);
+    int (*recv)(void* user, void* dev, size_t bytes, int peer, void* stream);
+    int (*all_gather)(void* user, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream);
+    int (*group_start)(void* user);
+    int (*group_end)(void* user);
+} umx_shard_transport;
+UMX_API int umx_shard_init_transport(umx_ctx* ctx, const umx_shard_transport* transport, int rank, int world);
 UMX_API int umx_shard_fini(umx_ctx* ctx);
 /* Geometry of rank `rank` of `world` for an H x W image cut into `nslabs` slabs per band (the count actually used --
  * no more than the smallest band's patch rows -- comes back in nslabs_used): its patch rows, the image rows its tiles read

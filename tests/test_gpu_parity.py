@@ -344,6 +344,81 @@ dist.destroy_process_group()
     assert r.returncode == 0 and r.stdout.count("equal=True") == world, (r.stdout[-2000:], r.stderr[-3000:])
 
 
+@pytest.mark.parametrize("world,nslabs", [(2, 2), (3, 1), (3, 3)])
+def test_native_sharded_entry_point_in_worlds_of_two_and_three(world, nslabs, tmp_path):
+    """umx_infer_image_sharded_dev -- the in-library band / halo / slab-gather / scatter schedule -- with its inter-rank operations
+    routed through umx_shard_init_transport: `world` processes on cuda:0, every send / recv / all-gather staged through host memory
+    over gloo behind the SAME function-pointer table umx_shard_init fills with RCCL (which refuses two ranks on one device).  Each
+    rank holds only its band; every rank's full result must equal the single-process umx_infer_image bit for bit, in both stitch
+    modes' element sizes (fp16-compat here, fp32 below), for two slides in a row (buffer reuse)."""
+    import subprocess
+    import sys
+    script = tmp_path / "worker.py"
+    script.write_text(r'''
+import ctypes, os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import helpers
+from unmicst_amd import model, sharding, umx
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+nslabs = int(sys.argv[1])
+hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+vp, sz = ctypes.c_void_p, ctypes.c_size_t
+def sync(stream): assert hip.hipStreamSynchronize(vp(stream)) == 0
+def d2h(ptr, n):
+    b = torch.empty(n, dtype=torch.uint8)
+    assert hip.hipMemcpy(vp(b.data_ptr()), vp(ptr), sz(n), 2) == 0
+    return b
+def h2d(ptr, b): assert hip.hipMemcpy(vp(ptr), vp(b.data_ptr()), sz(b.numel()), 1) == 0
+ops, calls = [], {"send": 0, "recv": 0, "all_gather": 0}
+def send(ptr, n, peer, stream):
+    sync(stream); b = d2h(ptr, n); ops.append((dist.isend(b, peer), None, b)); calls["send"] += 1
+def recv(ptr, n, peer, stream):
+    sync(stream); b = torch.empty(n, dtype=torch.uint8); ops.append((dist.irecv(b, peer), ptr, b)); calls["recv"] += 1
+def group_end():
+    for w, ptr, b in ops:
+        w.wait()
+        if ptr is not None: h2d(ptr, b)
+    ops.clear()
+def all_gather(sp, rp, n, stream):
+    sync(stream); b = d2h(sp, n); parts = [torch.empty(n, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(parts, b); h2d(rp, torch.cat(parts)); calls["all_gather"] += 1
+hp = helpers.small_hps()["v2_duo_like"]
+blob = model.random_blob(hp, seed=4)
+ok = True
+with umx.Engine(hp, blob, max_batch=8) as eng:
+    eng.shard_init_transport(send, recv, all_gather, rank, world, group_start=lambda: None, group_end=group_end)
+    for (H, W, stitch, dt) in ((233, 97, umx.STITCH_FP16_COMPAT, np.float16), (150, 120, umx.STITCH_FP32, np.float32)):
+        img = np.random.default_rng(H).random((2, H, W)) * 0.5
+        want = eng.infer_image(img, 0.2, 0.2, stitch=stitch)
+        pl = eng.shard_plan(H, W, rank, world, nslabs)
+        r0, r1 = pl["need_row0"], pl["need_row1"]
+        band = torch.from_numpy(np.ascontiguousarray(img[:, r0:max(r1, r0 + 1)])).cuda()     # only this rank's rows
+        full = torch.empty((hp.nClasses, H, W), dtype=torch.float16 if dt == np.float16 else torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        eng.infer_image_sharded_dev(band.data_ptr(), 2, H, W, r0, band.shape[1], 0.2, 0.2, umx.MODE_ACCUMULATE, stitch, nslabs,
+                                    full.data_ptr())
+        eng.synchronize()
+        torch.cuda.synchronize()
+        got = full.cpu().numpy()
+        same = np.array_equal(got.view(np.uint16 if dt == np.float16 else np.uint32), want.view(np.uint16 if dt == np.float16 else np.uint32))
+        ok = ok and same
+        print("rank %%d of %%d: %%d x %%d patch rows [%%d, %%d) equal=%%s calls=%%s" %% (rank, world, H, W, pl["patch_row0"], pl["patch_row1"], same, calls), flush=True)
+inner = 0 < rank < world - 1
+assert calls["send"] == (2 if rank < world - 1 else 0) and calls["recv"] == (2 if rank > 0 else 0), calls   # one halo row per slide
+assert calls["all_gather"] >= 2
+assert ok
+print("rank %%d native transport ok" %% rank, flush=True)
+dist.barrier()
+dist.destroy_process_group()
+''' % (helpers.ROOT, helpers.ROOT))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(29600 + 3 * world + nslabs), str(script), str(nslabs)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.count("native transport ok") == world, (r.stdout[-2000:], r.stderr[-3000:])
+
+
 @pytest.mark.parametrize("prec", PRECS)
 @pytest.mark.parametrize("key", ["nucleiDAPI1-5", "nucleiDAPILAMIN"])
 def test_forward_tiles_shipped_hyper_parameters(key, prec):

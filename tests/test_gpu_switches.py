@@ -33,6 +33,8 @@ SWITCHES = [
     {"UMX_NO_PACKED_TILE": "1"},            # last N-tile of <= 8 real channels as (hi, lo) images and 3 products instead of packed [hi | lo] and 2
     {"UMX_NO_PACKED_TILE": "convt"},        # ... in the fused-phase transposed convolutions only
     {"UMX_PLAN_OVERRIDE": "lu0.conv:3:2,ld1.conv:1:1:12"},   # forced (octets per chunk, k-steps per stage[, piece-index array])
+    {"UMX_PLAN_NT": "ld0.conv:1"},          # a first layer in two N-blocks: no dense-K kernel -> the graph is rebuilt without the raw-skip fold (not failed into fp32)
+    {"UMX_NO_D2S": "1", "UMX_NO_FUSED_CONVT": "1"},   # every transposed convolution one phase per workgroup, the top one with the raw-skip append
     {"UMX_PLAN_NT": "lu2.convT:4"},         # forced N-tiles per workgroup of one layer (here 8 padded N-tiles in two blocks instead of 7 in one)
     {"UMX_PRECISION": "f32"},               # default precision from the environment
     {"UMX_ACT_SHIFT": "2"},                 # activations stored times 4
@@ -133,6 +135,8 @@ def test_more_than_eight_input_channels(reference):
 # and R = Cout % 8 left-over channels per phase -- one block of four phases or two blocks by output-row parity, with and
 # without the remainder tile, with (1-2 input channels) and without (3) the raw-skip fold into the top layer's remainder tile
 D2S_SHAPES = [
+    (18, 2, 3, 16),    # 16-pixel tiles fold too (S2 >= 16), but neither the depth-to-space nor the fused-phase form takes a 16-pixel append: per-phase + append
+    (20, 1, 3, 16),
     (18, 1, 3, 32),    # top 36 -> 18: F 2, R 2, one block of 5 tiles + fold (one compact channel); below 72 -> 36: F 4, R 4, 9 tiles
     (20, 2, 3, 64),    # 20: F 2, R 4 (5 tiles, fold of two channels); 40: F 5 -> two blocks of 5
     (22, 3, 3, 32),    # 22: R 6 -> stays on the fused-phase kernel; 44: F 5, R 4 -> two blocks of 6 with a two-phase remainder tile

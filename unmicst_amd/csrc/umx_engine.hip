@@ -517,7 +517,8 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
     struct { std::vector<size_t> buf_floats; std::vector<std::pair<int, int>> buf_geom; size_t pos = 0; } b;
     // (the raw-skip fold of the split-precision plan: UMX_NO_FOLD=1 keeps the two-group top convolution, for A/B)
     // and only where the first layer takes the dense-K kernel: the input tiles are then stored once, in the compact form both read)
-    const bool fold = precision == UMX_PREC_F16X3 && conv_first_eligible(*hp) && !getenv("UMX_NO_FOLD");
+    static thread_local bool t_no_fold = false;   // (set for the one retry below)
+    const bool fold = precision == UMX_PREC_F16X3 && conv_first_eligible(*hp) && !getenv("UMX_NO_FOLD") && !t_no_fold;
     build_graph(*hp, weight_blob, &c->plan, &b.buf_floats, &b.buf_geom, &b.pos, fold);
     if (b.pos != blob_floats) { umx_destroy(ctx.release()); return fail(nullptr, UMX_ERR_BLOB, "internal blob walk mismatch"); }
     c->bufs.resize(b.buf_floats.size());
@@ -630,7 +631,16 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
     {   // compact input tiles: the graph folded the raw skip AND the first layer runs on the dense-K kernel
         bool folded = false, first = false;
         for (const Launch& L : c->plan) { folded = folded || L.app_src == 0; first = first || L.use_first; }
-        if (folded && !first) { c->err = "internal: raw-skip fold without the dense-K first layer"; return bail(UMX_ERR_INVALID); }
+        if (folded && !first) {
+            // The fold was decided from the hyper-parameters (conv_first_eligible), the dense-K first layer from the plan: where the
+            // two disagree (a forced N-tile count, a first layer the planner split into N-blocks) the graph is rebuilt ONCE with the
+            // two-group top convolution -- not failed into the 4 x slower exact-fp32 kernels
+            umx_destroy(ctx.release());
+            t_no_fold = true;
+            const int rc2 = umx_create_opts(hp, weight_blob, blob_floats, opts, out);
+            t_no_fold = false;
+            return rc2;
+        }
         if (folded) c->in_cw = c->hp.nChannels == 1 ? 1 : c->hp.nChannels == 2 ? 2 : 4;
     }
     *out = ctx.release();

@@ -72,8 +72,21 @@ Rccl* rccl() {
 
 struct Buf { void* d = nullptr; size_t cap = 0; };
 
+// Every inter-rank byte of the schedule below goes through this table -- the umx_shard_transport of include/umx.h.  umx_shard_init
+// fills it with RCCL (stream-ordered ncclSend / ncclRecv / ncclAllGather on the context's communicator); umx_shard_init_transport
+// takes the caller's: how the band / halo / scatter code runs in worlds of 2 and 3 on ONE GPU in the test-suite (RCCL refuses two
+// ranks on a device), with the messages staged through host memory.
+int rccl_send(void* user, const void* dev, size_t bytes, int peer, void* stream);
+int rccl_recv(void* user, void* dev, size_t bytes, int peer, void* stream);
+int rccl_all_gather(void* user, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream);
+int rccl_group_start(void* user);
+int rccl_group_end(void* user);
+
 struct Shard {
     ncclComm_t comm = nullptr;
+    umx_shard_transport tp = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ready = false;
+    std::string tp_err;           // message of the last failed transport call (RCCL: ncclGetErrorString)
     int rank = 0, world = 1;
     hipStream_t comm_stream = nullptr;
     std::vector<hipEvent_t> events;
@@ -112,6 +125,34 @@ void release(Shard& s) {
     for (auto e : s.events) hipEventDestroy(e);
     for (Buf* b : {&s.probs, &s.slab, &s.gathered}) if (b->d) hipFree(b->d);
     for (auto& b : s.send) if (b.d) hipFree(b.d);
+}
+
+int rccl_fail(Shard* s, ncclResult_t r, const char* what) {
+    s->tp_err = std::string(what) + " failed: " + rccl()->GetErrorString(r);
+    return 1;
+}
+int rccl_send(void* user, const void* dev, size_t bytes, int peer, void* stream) {
+    Shard* s = static_cast<Shard*>(user);
+    const ncclResult_t r = rccl()->Send(dev, bytes, ncclUint8, peer, s->comm, (hipStream_t)stream);
+    return r == ncclSuccess ? 0 : rccl_fail(s, r, "ncclSend");
+}
+int rccl_recv(void* user, void* dev, size_t bytes, int peer, void* stream) {
+    Shard* s = static_cast<Shard*>(user);
+    const ncclResult_t r = rccl()->Recv(dev, bytes, ncclUint8, peer, s->comm, (hipStream_t)stream);
+    return r == ncclSuccess ? 0 : rccl_fail(s, r, "ncclRecv");
+}
+int rccl_all_gather(void* user, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream) {
+    Shard* s = static_cast<Shard*>(user);
+    const ncclResult_t r = rccl()->AllGather(send_dev, recv_dev, bytes_per_rank, ncclUint8, s->comm, (hipStream_t)stream);
+    return r == ncclSuccess ? 0 : rccl_fail(s, r, "ncclAllGather");
+}
+int rccl_group_start(void* user) {
+    const ncclResult_t r = rccl()->GroupStart();
+    return r == ncclSuccess ? 0 : rccl_fail(static_cast<Shard*>(user), r, "ncclGroupStart");
+}
+int rccl_group_end(void* user) {
+    const ncclResult_t r = rccl()->GroupEnd();
+    return r == ncclSuccess ? 0 : rccl_fail(static_cast<Shard*>(user), r, "ncclGroupEnd");
 }
 
 void on_destroy(umx_ctx* ctx) {
@@ -188,12 +229,31 @@ int umx_shard_init(umx_ctx* ctx, const umx_unique_id* id, int rank, int world) {
     std::lock_guard<std::mutex> lk(g_mu);
     umx_internal_set_destroy_hook(on_destroy);
     Shard& s = g_shards[ctx];
-    if (s.comm) { release(s); s = Shard(); }
+    if (s.ready) { release(s); s = Shard(); }
     ncclUniqueId nid;
     memcpy(&nid, id, sizeof nid);
     S_NCCL(ctx, r->CommInitRank(&s.comm, world, nid, rank));
     s.rank = rank;
     s.world = world;
+    s.tp = umx_shard_transport{&s, rccl_send, rccl_recv, rccl_all_gather, rccl_group_start, rccl_group_end};   // (map nodes do not move)
+    s.ready = true;
+    S_HIP(ctx, hipStreamCreateWithFlags(&s.comm_stream, hipStreamNonBlocking));
+    return UMX_OK;
+}
+
+int umx_shard_init_transport(umx_ctx* ctx, const umx_shard_transport* tp, int rank, int world) {
+    if (!ctx || !tp) return umx_internal_fail(ctx, UMX_ERR_INVALID, "ctx / transport is NULL");
+    if (!tp->send || !tp->recv || !tp->all_gather) return umx_internal_fail(ctx, UMX_ERR_INVALID, "the transport lacks send / recv / all_gather");
+    if (world < 1 || rank < 0 || rank >= world) return umx_internal_fail(ctx, UMX_ERR_INVALID, "bad rank / world");
+    S_HIP(ctx, hipSetDevice(umx_internal_device(ctx)));
+    std::lock_guard<std::mutex> lk(g_mu);
+    umx_internal_set_destroy_hook(on_destroy);
+    Shard& s = g_shards[ctx];
+    if (s.ready) { release(s); s = Shard(); }
+    s.tp = *tp;
+    s.rank = rank;
+    s.world = world;
+    s.ready = true;
     S_HIP(ctx, hipStreamCreateWithFlags(&s.comm_stream, hipStreamNonBlocking));
     return UMX_OK;
 }
@@ -246,12 +306,17 @@ int umx_infer_image_sharded_dev(umx_ctx* ctx, const double* band_dev, int C_img,
     {
         std::lock_guard<std::mutex> lk(g_mu);
         auto it = g_shards.find(ctx);
-        if (it == g_shards.end() || !it->second.comm)
-            return umx_internal_fail(ctx, UMX_ERR_INVALID, "call umx_shard_init on this context first");
+        if (it == g_shards.end() || !it->second.ready)
+            return umx_internal_fail(ctx, UMX_ERR_INVALID, "call umx_shard_init (or umx_shard_init_transport) on this context first");
         sp = &it->second;
     }
     Shard& s = *sp;
-    Rccl* r = rccl();
+    const umx_shard_transport& tp = s.tp;
+#define S_TP(ctx, expr)                                                                                       \
+    do {                                                                                                      \
+        s.tp_err.clear();                                                                                     \
+        if ((expr) != 0) return fail(ctx, UMX_ERR_HIP, s.tp_err.empty() ? std::string(#expr " failed") : s.tp_err); \
+    } while (0)
     S_HIP(ctx, hipSetDevice(umx_internal_device(ctx)));
     hipStream_t cs = umx_internal_stream(ctx), ms = s.comm_stream;
     umx_hparams hp;
@@ -295,10 +360,10 @@ int umx_infer_image_sharded_dev(umx_ctx* ctx, const double* band_dev, int C_img,
     S_HIP(ctx, hipStreamWaitEvent(ms, ev_last, 0));
     if (has_next || has_prev) {
         const int me = (int)(std::find(active.begin(), active.end(), rank) - active.begin());
-        S_NCCL(ctx, r->GroupStart());
-        if (has_next) S_NCCL(ctx, r->Send(probs + (size_t)(pb - 1 - lo) * row_f, row_f * sizeof(float), ncclUint8, active[me + 1], s.comm, ms));
-        if (has_prev) S_NCCL(ctx, r->Recv(probs, row_f * sizeof(float), ncclUint8, active[me - 1], s.comm, ms));
-        S_NCCL(ctx, r->GroupEnd());
+        if (tp.group_start) S_TP(ctx, tp.group_start(tp.user));
+        if (has_next) S_TP(ctx, tp.send(tp.user, probs + (size_t)(pb - 1 - lo) * row_f, row_f * sizeof(float), active[me + 1], ms));
+        if (has_prev) S_TP(ctx, tp.recv(tp.user, probs, row_f * sizeof(float), active[me - 1], ms));
+        if (tp.group_end) S_TP(ctx, tp.group_end(tp.user));
     }
     S_HIP(ctx, hipEventRecord(ev_halo, ms));
     if ((int)s.send.size() < n) s.send.resize(n);
@@ -340,7 +405,7 @@ int umx_infer_image_sharded_dev(umx_ctx* ctx, const double* band_dev, int C_img,
         S_HIP(ctx, hipEventRecord(ev_s, cs));
         S_HIP(ctx, hipStreamWaitEvent(ms, ev_s, 0));
         // (one gather buffer, reused slab after slab: gather i+1 is queued behind the scatter copies of gather i)
-        S_NCCL(ctx, r->AllGather(s.send[i].d, s.gathered.d, send_b, ncclUint8, s.comm, ms));
+        S_TP(ctx, tp.all_gather(tp.user, s.send[i].d, s.gathered.d, send_b, ms));
         for (int q = 0; q < world; ++q)
             for (int k = 0; k < K && rb[q] > ra[q]; ++k)
                 S_HIP(ctx, hipMemcpyAsync((char*)out_full_dev + ((size_t)k * H + ra[q]) * W * el,
@@ -349,6 +414,7 @@ int umx_infer_image_sharded_dev(umx_ctx* ctx, const double* band_dev, int C_img,
     }
     S_HIP(ctx, hipEventRecord(ev_done, ms));
     S_HIP(ctx, hipStreamWaitEvent(cs, ev_done, 0));   // the result is complete for whatever the caller queues next
+#undef S_TP
     return UMX_OK;
 }
 

@@ -26,7 +26,7 @@ EXPORTS = [
     "umx_device_count", "umx_device_mem_info", "umx_create", "umx_create_opts", "umx_precision_of", "umx_destroy", "umx_last_error", "umx_set_stream", "umx_synchronize",
     "umx_forward_tiles", "umx_forward_tiles_dev", "umx_tile_grid", "umx_infer_image", "umx_infer_image_dev",
     "umx_infer_image_raw", "umx_infer_image_raw_scaled", "umx_infer_image_raw_outlier", "umx_infer_image_raw_submit", "umx_infer_image_wait", "umx_tiff_lzw_decode",
-    "umx_tiff_packbits_decode", "umx_shard_unique_id", "umx_shard_init", "umx_shard_fini", "umx_shard_plan",
+    "umx_tiff_packbits_decode", "umx_shard_unique_id", "umx_shard_init", "umx_shard_init_transport", "umx_shard_fini", "umx_shard_plan",
     "umx_infer_image_sharded_dev",
     "umx_band_tiles_dev", "umx_stitch_dev", "umx_profile_enable", "umx_profile_read", "umx_prof_entry_size", "umx_test_double_to_half",
     "umx_describe", "umx_describe_graph", "umx_version",
@@ -54,6 +54,17 @@ class ProfEntry(ctypes.Structure):
                 ("total_ms", ctypes.c_double), ("flops", ctypes.c_double), ("bytes", ctypes.c_double),
                 ("exec_flops", ctypes.c_double), ("launches_seen", ctypes.c_int64), ("xcd_order", ctypes.c_int32),
                 ("reserved", ctypes.c_int32)]
+
+
+_SEND_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p)
+_GATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+_GROUP_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)
+
+
+class ShardTransport(ctypes.Structure):
+    """umx_shard_transport (include/umx.h): the inter-rank operations of umx_infer_image_sharded_dev as a table of callbacks."""
+    _fields_ = [("user", ctypes.c_void_p), ("send", _SEND_FN), ("recv", _SEND_FN), ("all_gather", _GATHER_FN),
+                ("group_start", _GROUP_FN), ("group_end", _GROUP_FN)]
 
 
 _lib = None
@@ -142,6 +153,8 @@ def load(path: Optional[str] = None):
     L.umx_shard_init.argtypes = [c_void_p, c_void_p, c_int, c_int]
     L.umx_shard_fini.restype = c_int
     L.umx_shard_fini.argtypes = [c_void_p]
+    L.umx_shard_init_transport.restype = c_int
+    L.umx_shard_init_transport.argtypes = [c_void_p, ctypes.POINTER(ShardTransport), c_int, c_int]
     L.umx_shard_plan.restype = c_int
     L.umx_shard_plan.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int] + [c_void_p] * 9
     L.umx_infer_image_sharded_dev.restype = c_int
@@ -326,6 +339,24 @@ class Engine:
 
     def shard_init(self, unique_id: bytes, rank: int, world: int) -> None:
         self._check(self._L.umx_shard_init(self._ctx, ctypes.create_string_buffer(unique_id, 128), int(rank), int(world)))
+
+    def shard_init_transport(self, send, recv, all_gather, rank: int, world: int, group_start=None, group_end=None) -> None:
+        """umx_shard_init_transport with Python callables: send(dev_ptr, nbytes, peer, stream), recv(dev_ptr, nbytes, peer, stream),
+        all_gather(send_ptr, recv_ptr, nbytes_per_rank, stream), group_start() / group_end(); an exception = failure."""
+        def guard(fn):
+            def call(user, *a):
+                try:
+                    fn(*a)
+                    return 0
+                except Exception:   # noqa: BLE001  (nothing may propagate through the C frames)
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return call
+        t = ShardTransport(None, _SEND_FN(guard(send)), _SEND_FN(guard(recv)), _GATHER_FN(guard(all_gather)),
+                           _GROUP_FN(guard(group_start)) if group_start else _GROUP_FN(), _GROUP_FN(guard(group_end)) if group_end else _GROUP_FN())
+        self._transport = t   # (the callbacks must outlive the context's use of them)
+        self._check(self._L.umx_shard_init_transport(self._ctx, ctypes.byref(t), int(rank), int(world)))
 
     def shard_plan(self, H: int, W: int, rank: int, world: int, nslabs: int = 2, slab: int = 0) -> dict:
         return shard_plan(self.hp, H, W, rank, world, nslabs, slab)
