@@ -73,9 +73,17 @@ def _hp(name):
     return extra[name] if name in extra else helpers.small_hps()[name]
 
 
+# the forward / input-gradient convolutions run on conv_f16x3 (split precision, round 4); UMX_TRAIN_CONV_F32=1 keeps them on the
+# exact-fp32 MFMA kernel, UMX_TRAIN_NO_KSPLIT=1 runs every one as a single pass over K (no partial sums)
+ROUTES = [{}, {"UMX_TRAIN_CONV_F32": "1"}, {"UMX_TRAIN_NO_KSPLIT": "1"}, {"UMX_TRAIN_HSPLIT_WGS": "4096"}]
+
+
+@pytest.mark.parametrize("route", ROUTES, ids=lambda r: ",".join("%s=%s" % kv for kv in r.items()) or "f16x3")
 @pytest.mark.parametrize("name,B,regime", CASES)
-def test_loss_gradients_and_probabilities_match_oracle(name, B, regime):
+def test_loss_gradients_and_probabilities_match_oracle(name, B, regime, route, monkeypatch):
     from oracle import train_oracle as to
+    for k, v in route.items():
+        monkeypatch.setenv(k, v)
     hp = _hp(name)
     opts = trainer.solo_options() if regime == "solo" else trainer.duo_options()
     blob = model.random_blob(hp, seed=21)
@@ -259,6 +267,31 @@ def test_train_loop_end_to_end(tmp_path):
     with umx.Engine(art.hp, art.blob, max_batch=2) as eng:
         p = eng.forward_tiles(np.zeros((1, 32, 32, 1), np.float32))
     assert np.allclose(p.sum(-1), 1.0, atol=1e-5)
+
+
+def test_the_two_convolution_routes_agree_step_for_step(monkeypatch):
+    """Three Adam steps of the duo regime (dropout on) on the split-precision route and on the exact-fp32 route: same losses to
+    1e-6 relative, same parameters to 1e-5 of each tensor's scale (2^-22 per product against fp32 rounding -- and the routes must take
+    every LeakyReLU / pool / dropout decision alike on this batch for that to hold)."""
+    from oracle import train_oracle as to
+    hp = helpers.small_hps()["v2_wide"]
+    blob = model.random_blob(hp, seed=5)
+    data, labels, weights = _batch(hp, 2, 9)
+    out = []
+    for env in ({}, {"UMX_TRAIN_CONV_F32": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        tr = trainer.Trainer(hp, blob, trainer.duo_options(), batch=2)
+        losses = [tr.step(data, labels, weights)[0] for _ in range(3)]
+        out.append((losses, tr.blob()))
+        tr.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    (la, ba), (lb, bb) = out
+    assert np.allclose(la, lb, rtol=1e-6, atol=0), (la, lb)
+    A, Bv = to.split_blob(hp, ba), to.split_blob(hp, bb)
+    for name in A:
+        assert np.abs(A[name] - Bv[name]).max() <= 1e-5 * np.abs(Bv[name]).max() + 1e-7, name
 
 
 def test_baseline_config_256x256x2_batch8_against_the_oracle():

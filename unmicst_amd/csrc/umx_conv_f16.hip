@@ -97,8 +97,20 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
     const int ty_i = bid % p.tiles_y; bid /= p.tiles_y;
     const int img0 = bid * p.imgs;
     const int y0 = ty_i * TH, x0 = tx_i * TWm;
-    const int nblk = nblk_i;
     const HPhase& ph = p.ph[z_i];
+    // K split (the trainer's launches on small batches: a deep layer of 8 images is 16 - 64 workgroups walking 80 - 240 k-steps at
+    // memory latency): workgroup row y = split * nblocks + N-block runs the stages [ks0[split], ks0[split + 1]) of the list -- whole
+    // halo chunks -- and stores raw partial sums `split_stride` floats apart; launch_split_reduce adds them in order
+    int ph_stage0 = ph.stage0, ph_nstages = ph.nstages;
+    size_t split_off = 0;
+    if (p.ksplit > 1) {
+        const int ks = nblk_i / p.nblocks;
+        nblk_i -= ks * p.nblocks;
+        ph_stage0 += p.ks0[z_i][ks];
+        ph_nstages = p.ks0[z_i][ks + 1] - p.ks0[z_i][ks];
+        split_off = (size_t)ks * p.split_stride;
+    }
+    const int nblk = nblk_i;
     // diagnostic stamps (shader-clock cycles), wave 0 only: [0] prologue, [1] waiting for loads + barriers, [2] MFMA
     // blocks, [3] epilogue, [4] whole kernel
     long long t_in = 0, t_wait = 0, t_comp = 0, t_a = 0, t_b = 0, t_vm = 0, t_iss = 0;
@@ -255,9 +267,9 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
     };
     // stage s uses weight buffer (s + par0) & 1, with par0 such that the buffer the LAST stage frees -- where the epilogue
     // constants go -- is always buffer 1: the epilogue's transpose staging may then use everything below it
-    const int par0 = (ph.nstages + 1) & 1;
+    const int par0 = (ph_nstages + 1) & 1;
     const float* const ec = reinterpret_cast<const float*>(Bl + p.wbuf_bytes);
-    if (ph.nstages == 0) { issue_econst(1); issue_app(1); }
+    if (ph_nstages == 0) { issue_econst(1); issue_app(1); }
     // the stage table is read through the constant address space: a plain global pointer gets a VECTOR load and a full
     // s_waitcnt vmcnt(0) round trip at the top of every stage (the kernel stores and fences, so the compiler will not
     // prove the table unclobbered); the host writes it before the launch and nothing writes it afterwards
@@ -272,8 +284,8 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
         __builtin_memcpy(&st, &raw, sizeof(st));
         return st;
     };
-    HStage cur = load_stage(ph.stage0);
-    if (ph.nstages > 0) {
+    HStage cur = load_stage(ph_stage0);
+    if (ph_nstages > 0) {
         if (cur.group >= 0) issue_halo(cur);
         wq_begin(cur, par0);
         wq_drain(0);
@@ -284,13 +296,13 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
     // boundary, the next halo chunk into the other halo slot) are in flight while stage s runs its MFMAs.  One barrier
     // per stage: it orders "everyone's loads of stage s have landed" (each wave waits for its own first) and "everyone is
     // done computing stage s-1" (so the buffers stage s+1 loads into are free).
-    for (int s = 0; s < ph.nstages; ++s) {
-        const HStage nxt = load_stage(ph.stage0 + (s + 1 < ph.nstages ? s + 1 : s));
+    for (int s = 0; s < ph_nstages; ++s) {
+        const HStage nxt = load_stage(ph_stage0 + (s + 1 < ph_nstages ? s + 1 : s));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (DBG && p.dbg) { const long long t_v = __builtin_amdgcn_s_memtime(); t_vm += t_v - t_a; }
         __syncthreads();
         if (DBG && p.dbg) { t_b = __builtin_amdgcn_s_memtime(); t_wait += t_b - t_a; }
-        if (s + 1 < ph.nstages) {
+        if (s + 1 < ph_nstages) {
             if (nxt.group >= 0) issue_halo(nxt);
             wq_begin(nxt, (s + 1 + par0) & 1);
         } else {
@@ -424,10 +436,12 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
         // (different first instructions: otherwise the common head of the two copies is hoisted above the branch in one batch)
         if constexpr (post) asm volatile("; epilogue arithmetic, second affine");
         else asm volatile("; epilogue arithmetic");
+        // (trainer launches: the dynamic operand scales, two device scalars; 1 otherwise -- four multiplies per N-tile, no branch)
+        const float dyn = (p.dyn[0] ? *p.dyn[0] : 1.f) * (p.dyn[1] ? *p.dyn[1] : 1.f);
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const float4 ps = ec4[0 * NT * 4 + n * 4 + q], pb = ec4[1 * NT * 4 + n * 4 + q];
-            const float psa[4] = {ps.x, ps.y, ps.z, ps.w}, pba[4] = {pb.x, pb.y, pb.z, pb.w};
+            const float psa[4] = {ps.x * dyn, ps.y * dyn, ps.z * dyn, ps.w * dyn}, pba[4] = {pb.x, pb.y, pb.z, pb.w};
             float qsa[4] = {1.f, 1.f, 1.f, 1.f}, qba[4] = {0.f, 0.f, 0.f, 0.f};
             if constexpr (post) {
                 const float4 qs = ec4[2 * NT * 4 + n * 4 + q], qb = ec4[3 * NT * 4 + n * 4 + q];
@@ -552,7 +566,7 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
                 for (int n = 0; n < NT; ++n) {
                     const int c0 = nblk * (NT * 16) + n * 16 + 4 * q;
                     const float* const v = res[n];
-                    float* const d = p.dst_f32 + pix * p.Cout + c0;
+                    float* const d = p.dst_f32 + split_off + pix * p.Cout + c0;
                     if ((p.Cout & 3) == 0) {
                         if (c0 < p.Cout) *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
                     } else {
@@ -909,6 +923,10 @@ template <int NT, int KMT, int NPH, bool DBG, int MAXP, bool PK = false, bool D2
 static hipError_t launch_h_k(const HConvParams& p, hipStream_t stream) {
     const int img_groups = (p.B + p.imgs - 1) / p.imgs;
     dim3 grid((unsigned)(img_groups * p.tiles_y * p.tiles_x), (unsigned)p.nblocks, (unsigned)(NPH == 1 ? p.nphase : 1));
+    if (p.ksplit > 1) {   // (trainer: fp32 partial sums, one row of N-blocks per split)
+        if (p.xcd_order == 2 || !p.dst_f32 || p.head_K > 0 || p.ksplit > kMaxKSplit) return hipErrorInvalidValue;
+        grid.y *= (unsigned)p.ksplit;
+    }
     if (p.xcd_order == 2) {   // (the caller filled ntiles_grid / tiles_per_xcd)
         if (p.ntiles_grid != (int)grid.x || p.tiles_per_xcd * 8 < p.ntiles_grid) return hipErrorInvalidValue;
         grid = dim3((unsigned)(8 * p.tiles_per_xcd) * grid.y * grid.z, 1, 1);

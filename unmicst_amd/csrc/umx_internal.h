@@ -37,8 +37,23 @@ struct Group {           // one operand group of a launch, host description
     std::vector<float> packed[4];              // per phase: [ntaps][Cp][Np]
 };
 
+// Training (umx_train.hip): where one 16-byte unit of a packed weight image comes from.  The filters change every step, so the
+// planner records, instead of values, for every (k-step, N-tile, lane) unit of a launch's weight slab the 8 source elements of the
+// fp32 operand the trainer repacks on the device ([tap][Cp][Np], the layout Group::packed has on the host): element e of the unit =
+// arr[base + e * stride] for e < nvalid, else 0.
+struct HWRef {
+    int dst;                   // uint4 index of the unit's hi image inside the (phase list's) slab; its lo image is 64 units on
+    int base;                  // first source element
+    unsigned short nvalid;     // 1..8 real input channels in the octet
+    unsigned short arr;        // operand group the unit reads
+};
+
 struct Launch {
     std::string name;
+    bool train = false;        // split-precision plan for the trainer: plain / per-phase kernels only, fp32 output, weights by reference
+    std::vector<HWRef> wrefs[4];   // (train) per stage list
+    size_t slab_units[4] = {0, 0, 0, 0};   // (train) uint4 units of each list's weight slab (all N-blocks)
+    std::vector<HStage> stages_host;       // (train) the stage table as uploaded: the trainer cuts it between halo chunks (K split)
     bool head = false;
     int ngroups = 0;
     Group g[2];

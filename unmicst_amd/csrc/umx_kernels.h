@@ -63,6 +63,7 @@ constexpr int kHaloChunks = 16;  // 64-slot pieces of the LDS halo per plane (ha
 constexpr int kMaxNT16 = 9;      // N-tiles per workgroup of the split-precision kernel (144 output channels)
 constexpr int kStageK = 4;       // max k-steps (of 32 K-slots = 4 (tap, octet) pairs) per weight stage
 constexpr int kMaxLdsPerWG = 80 * 1024;   // two workgroups per CU share the 160 KiB
+constexpr int kMaxKSplit = 24;   // K-split rows of a trainer launch (HConvParams::ks0)
 
 struct HStage {      // one pipeline stage: optional halo chunk load + one weight block of nk k-steps
     int woff;        // offset (uint4 units) of this stage's weight block inside one (phase, N-block) slab; a block is
@@ -134,6 +135,12 @@ struct HConvParams {
                                  //    octet) relative to output pixel (2y, 2x) per stored octet of the N axis (< 0: padding), then the
                                  //    same for the remainder tile's 4 lane groups, then their sub-pixel codes oy * 2 + ox
     int pk;                      // 1: the last N-tile's weight image is [w_hi | w_lo] of its <= 8 real channels (conv_f16x3's PK form)
+    int ksplit;                  // > 1 (trainer, fp32 output): the stage list is cut into `ksplit` runs of whole halo chunks, run s by workgroup
+    short ks0[4][kMaxKSplit + 1];   //   rows [s * nblocks, (s + 1) * nblocks): stages [ks0[z][s], ks0[z][s + 1]) of phase z, relative to its
+    size_t split_stride;         //      stage0; partial sums of run s at dst_f32 + s * split_stride
+    const float* dyn[2];         // fp32 output only (the trainer's launches): non-NULL device scalars multiplied into pre_s when the
+                                 // epilogue runs -- the power-of-two scales of this step's repacked weights and of a gradient tensor's
+                                 // (hi, lo) planes, both chosen on the device
     int* overflow_flag;
     long long* dbg;              // diagnostic builds only (UMX_DEBUG_STAMPS): per-workgroup s_memtime segments, or NULL
 };
@@ -255,6 +262,20 @@ struct ActParams {          // y = dropout(act(z*scale + shift)) [-> 2x2 max-poo
 hipError_t launch_act_fwd(const ActParams& a, float* out, unsigned* omax /* max |out| word or NULL */, hipStream_t stream);
 // omax = max(omax, max |x|)  (float bits; integer atomicMax)
 hipError_t launch_absmax(const float* x, size_t n, unsigned* omax, hipStream_t stream);
+// ---- forward / input-gradient convolutions of the trainer on conv_f16x3: weight images rebuilt on the device every step, and
+// fp32 tensors turned into the (hi, lo) planes the kernel reads (umx_train_kernels.hip)
+struct HWRefDev { int dst; int base; unsigned short nvalid, arr; };   // == umx::HWRef (umx_internal.h)
+struct RepackDesc {
+    const HWRefDev* refs;
+    int n;                  // units to fill
+    const float* arr[2];    // fp32 operands of the launch's groups for this phase: [tap][Cp][Np]
+    int stride;             // Np: elements between consecutive input channels
+    float scale;            // 2^s applied to the weights (the launch's HConvParams::dyn[0] points at 2^-s)
+    uint4* slab;            // the phase list's weight slab (headers stay as the planner wrote them)
+};
+hipError_t launch_repack_f16x3(const RepackDesc* descs_dev, int ndesc, int max_n, int* overflow, hipStream_t stream);
+hipError_t launch_split_dyn(const float* x, size_t npix, int C, int Cs, const unsigned* maxw, float* inv_scale, _Float16* hi,
+                            _Float16* lo, int* overflow, unsigned* omax /* max |v| word or NULL */, hipStream_t stream);
 // backward of the same: g = d(loss)/d(BN output) written full-res [B,H,W,C]; part[blk][2][C] = (sum g, sum g*xhat)
 hipError_t launch_act_bwd(const ActParams& a, const float* dy0, const float* dy1, float* g, double* part, int nblk,
                           hipStream_t stream);

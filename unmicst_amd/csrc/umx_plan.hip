@@ -13,7 +13,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     // halo chunk next to 8 N-tiles of weights) fills its k-steps with 1 - 2 (tap, octet) pairs of 4 in the phases that have 1 - 2
     // taps: 640 executed k-steps for 360.  Narrower N-blocks leave LDS for two octets per chunk (400 k-steps; lu3.convT -16 %,
     // the solo step -1.6 %): dry-run the search for every N-tile count with the same padding and take a >= 20 % shorter K loop.
-    if (!dry && !L.force_nt16 && L.nphase == 4 && !L.d2s && !getenv("UMX_PLAN_NT") && !getenv("UMX_PLAN_OVERRIDE") &&
+    if (!dry && !L.force_nt16 && L.nphase == 4 && !L.d2s && !L.train && !getenv("UMX_PLAN_NT") && !getenv("UMX_PLAN_OVERRIDE") &&
         !getenv("UMX_NO_NT_TRIAL")) {
         const int t16 = (L.Cout + 15) / 16;
         int base_k = 0, base_nt = 0, best_k = 0, best_nt = 0;
@@ -34,7 +34,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     // stride-2 transposed convolution with few output channels: all four sub-pixel phases in one workgroup (the input
     // halo is read once instead of four times; 4 accumulator sets limit it to 5 N-tiles and 128 input pixels)
     const bool fused = L.nphase == 4 && L.o_mul == 2 && L.ngroups == 1 && !out_f32 && t16 <= 5 && L.H >= 8 && L.W >= 16 &&
-                       !getenv("UMX_NO_FUSED_CONVT");
+                       !L.train && !getenv("UMX_NO_FUSED_CONVT");
     h.fused_phases = fused ? 1 : 0;
     if (fused) {
         const int THg = 1 << g.th_log2, TWg = 1 << g.twm_log2;   // >= 8 and == 16 under the conditions above
@@ -76,7 +76,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     const bool pk_off = nopk && (!strcmp(nopk, "1") || (fused && !strcmp(nopk, "convt")));
     h.d2s = L.d2s;
     h.d2s_mix = L.d2s && L.d2s_R > 0;
-    h.pk = (!L.d2s && h.nblocks == 1 && nt16 >= 2 && nt16 <= 5 && last_real >= 1 && last_real <= 8 && !pk_off && !getenv("UMX_DEBUG_STAMPS")) ? 1 : 0;
+    h.pk = (!L.d2s && !L.train && h.nblocks == 1 && nt16 >= 2 && nt16 <= 5 && last_real >= 1 && last_real <= 8 && !pk_off && !getenv("UMX_DEBUG_STAMPS")) ? 1 : 0;
     h.outH = L.outH; h.outW = L.outW; h.pool = L.pool; h.act = L.act;
     if (h.nhalo > kHaloChunks * 64) { *why = "halo too large for the split-precision kernel"; return UMX_ERR_INVALID; }
     h.plane_slots = round_up(h.nhalo, 16);
@@ -87,8 +87,8 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     for (int ph = 0; ph < L.nphase; ++ph)
         for (int gi = 0; gi < L.ngroups; ++gi)
             for (float v : L.g[gi].packed[ph]) maxabs = std::max(maxabs, std::fabs(v));
-    L.wshift = 0;
-    if (maxabs > 0.f && std::isfinite(maxabs)) {
+    L.wshift = 0;   // (training plans: the weights' scale is applied when they are repacked, and undone through HConvParams::dyn)
+    if (maxabs > 0.f && std::isfinite(maxabs) && !L.train) {
         int e;
         std::frexp(maxabs, &e);           // maxabs = m * 2^e, m in [0.5, 1)
         L.wshift = std::max(-24, std::min(30, 14 - e));
@@ -157,7 +157,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     // the previous chunk's halo slot is still resident then (its reload is issued at the start of the next chunk's LAST
     // stage, so the next chunk must have >= 2 stages).  Not across the phases of the fused kernel (other accumulators).
     struct Pair { int gi, ph, tap, oct, slot, k; };   // slot: halo slot (0/1) of the chunk; k: octet inside the chunk
-    const bool carry_ok = !fused && !getenv("UMX_NO_KSTEP_CARRY");
+    const bool carry_ok = !fused && !L.train && !getenv("UMX_NO_KSTEP_CARRY");   // (training plans: every chunk stands alone -- the K split cuts between chunks)
     auto npairs_of = [&](const Chunk& k, int ph) { return (int)L.g[k.gi].taps[ph].size() * (k.o1 - k.o0); };
     auto plan_list = [&](int OC, int S, int list, std::vector<HStage>* stages_out,
                          std::vector<std::vector<Pair>>* steps_out, int* nchunks) {
@@ -324,6 +324,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         h.ph[list].wblk_stride = (int)(per_blk / 8);
         std::vector<_Float16>& W = wimg[list];
         W.assign(per_blk * h.nblocks, (_Float16)0.f);
+        if (L.train) { L.wrefs[list].clear(); L.slab_units[list] = per_blk * h.nblocks / 8; }
         for (int nb = 0; nb < h.nblocks; ++nb) {
             size_t ks = 0;
             for (int si = h.ph[list].stage0; si < (int)stages.size(); ++si) {
@@ -361,6 +362,13 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                             const int row = lane & 15;
                             const int co = nb * nt16 * 16 + n * 16 + (packed ? (row & 7) : row);
                             const size_t base = blk + 32 + (((size_t)j * nt16 + n) * 2) * 512 + (size_t)lane * 8;
+                            if (L.train) {   // by reference: the trainer fills this unit from its device-resident fp32 operand
+                                const int nv = std::min(8, G.C - pr2.oct * 8);
+                                if (nv > 0 && co < L.Cout)
+                                    L.wrefs[list].push_back(HWRef{(int)(base / 8), (int)(((size_t)pr2.tap * Cp + (size_t)pr2.oct * 8) * L.Np + co),
+                                                                  (unsigned short)nv, (unsigned short)pr2.gi});
+                                continue;
+                            }
                             for (int e = 0; e < 8; ++e) {
                                 const int c = pr2.oct * 8 + e;
                                 if (c >= G.C || co >= L.Cout) continue;
@@ -491,6 +499,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     }
     if ((rc = upload_raw(ctx, stages, &d_st))) return rc;
     h.stages = d_st;
+    if (L.train) L.stages_host = stages;
     for (int list = 0; list < nlists; ++list) {
         _Float16* d = nullptr;
         if ((rc = upload_raw(ctx, wimg[list], &d))) return rc;

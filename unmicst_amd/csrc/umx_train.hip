@@ -11,6 +11,7 @@
 //             stride-2 transposed conv: a 2x2-tap conv over the space-to-depth form of the output gradient)
 //   update    Adam / Momentum over the flat parameter vector
 #include "../../include/umx_train.h"
+#include "umx_internal.h"
 #include "umx_kernels.h"
 
 #include <algorithm>
@@ -28,11 +29,19 @@ namespace {
 
 thread_local std::string g_terr;
 
-struct TConv {                       // one launch of conv_mfma_f32 with device-packed operands
-    ConvParams cp;
-    int nt = 1, hpix = 2;
+struct TConv {                       // one convolution of the step: device-packed fp32 operands [tap][Cp][Np], rebuilt every step,
+    ConvParams cp;                   // run by conv_mfma_f32 -- or (hidx >= 0, the default since round 4) repacked into conv_f16x3's
+    int nt = 1, hpix = 2;            // weight images and run in split precision
     float* packed[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     double mac = 0.0;                // algorithmic multiply-accumulates per image
+    int hidx = -1;                   // index into umx_trainer::hls (split-precision plan), -1: fp32 kernel
+    float* winv = nullptr;           // device scalar 2^-s: undoes the scale of the repacked weights in the epilogue
+};
+
+struct H16 {                         // (hi, lo) binary16 NHWC planes of one tensor, channels padded to Cs (what conv_f16x3 reads)
+    _Float16* hi = nullptr;
+    _Float16* lo = nullptr;
+    int Cs = 0;
 };
 
 struct TapSet {
@@ -92,6 +101,17 @@ struct umx_trainer {
     float* d_ws = nullptr;  size_t ws_floats = 0;
     float* d_split = nullptr;  size_t split_floats = 0;   // partial outputs of K-split convolutions
     float* d_split2 = nullptr;                            // ... of those enqueued on the side stream
+    // forward / input-gradient convolutions on conv_f16x3 (UMX_TRAIN_CONV_F32=1: the exact-fp32 kernels of rounds 1-3)
+    bool hconv = true;
+    umx_ctx* pctx = nullptr;            // owner of the planner's device allocations (stage tables, weight slabs, constants)
+    const float* h_blob = nullptr;      // (during build) the initial parameters on the host: weight scales
+    std::vector<umx::Launch> hls;
+    std::vector<RepackDesc> rdescs;
+    RepackDesc* d_rdescs = nullptr;
+    int max_refs = 0;
+    std::vector<H16> h_ds, h_us, h_cv;  // planes of ds[i], us[idx], cv[idx]
+    H16 h_b, h_dz[2], h_gs[2];
+    float* d_xinv = nullptr;            // [4] inverse scales of the dz / gS slots' planes, written by split_dyn_kernel
     // launches
     std::vector<TConv> c_fwd_d, c_dg_d, c_T, c_fwd_u, c_dg_us, c_dg_skip, c_dg_T;
     TConv c_fwd_b, c_dg_b;
@@ -135,8 +155,6 @@ int tfail(umx_trainer* tr, int code, const char* fmt, ...) {
         if (rc_ != UMX_OK) return rc_; \
     } while (0)
 
-int round_up(int a, int b) { return (a + b - 1) / b * b; }
-
 template <typename T>
 int talloc(umx_trainer* tr, T** out, size_t count) {
     void* d = nullptr;
@@ -179,6 +197,102 @@ struct GroupSpec {
     int transpose, c_off, npar, Cblk;
     TapSet taps[4];
 };
+
+// The same convolution as a split-precision plan (conv_f16x3, fp32 output): stage tables and the LDS-image layout of the weights
+// come from plan_f16 once; the values are filled every step by repack_f16x3_kernel from the fp32 operands this TConv already
+// rebuilds on the device.  A shape the planner refuses stays on the fp32 kernel.
+int setup_hconv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int Cout, int act, int nphase, int o_mul, const int* oy,
+                const int* ox, int ngroups, GroupSpec* gs) {
+    if (!tr->hconv) return UMX_OK;
+    umx::Launch L;
+    L.name = what;
+    L.train = true;
+    L.ngroups = ngroups; L.nphase = nphase; L.o_mul = o_mul;
+    for (int ph = 0; ph < nphase; ++ph) { L.oy_off[ph] = oy ? oy[ph] : 0; L.ox_off[ph] = ox ? ox[ph] : 0; }
+    L.H = H; L.W = W; L.Cout = Cout; L.outH = H * o_mul; L.outW = W * o_mul; L.pool = 0; L.act = act; L.dst = -1;
+    L.Np = tc.cp.Np;
+    double wmax = 0.0;
+    for (int g = 0; g < ngroups; ++g) {
+        L.g[g].src = g;
+        L.g[g].C = gs[g].C;
+        for (int ph = 0; ph < nphase; ++ph) L.g[g].taps[ph] = gs[g].taps[ph].off;
+        // largest |w| the packed operand can hold now: the master tensor(s) this group reads (summed pair: the sum of the maxima)
+        int ntap_master = 0;
+        for (int ph = 0; ph < nphase; ++ph)
+            for (int m : gs[g].taps[ph].m) ntap_master = std::max(ntap_master, m + 1);
+        const size_t cnt = (size_t)ntap_master * gs[g].d2 * gs[g].d3;
+        double m1 = 0.0, m2 = 0.0;
+        for (size_t i = 0; i < cnt; ++i) m1 = std::max(m1, (double)std::fabs(tr->h_blob[gs[g].w_off + i]));
+        if (gs[g].w2_off != SIZE_MAX)
+            for (size_t i = 0; i < cnt; ++i) m2 = std::max(m2, (double)std::fabs(tr->h_blob[gs[g].w2_off + i]));
+        wmax = std::max(wmax, m1 + m2);
+    }
+    std::string why;
+    if (!umx::conv_geometry(L, &why) || umx::plan_f16(tr->pctx, L, 0, true, nullptr, &why) != UMX_OK) {
+        if (getenv("UMX_DEBUG_PLAN")) fprintf(stderr, "[umx train] %s stays on the fp32 kernel: %s\n", what, why.c_str());
+        return UMX_OK;
+    }
+    int sh = 0;
+    if (wmax > 0.0 && std::isfinite(wmax)) {
+        int e;
+        std::frexp(wmax, &e);              // wmax = m * 2^e, m in [0.5, 1)
+        sh = std::max(-24, std::min(40, 11 - e));
+    }
+    const float inv = std::ldexp(1.f, -sh);
+    T_TRY(talloc(tr, &tc.winv, 1));
+    T_HIP(tr, hipMemcpy(tc.winv, &inv, sizeof inv, hipMemcpyHostToDevice));
+    static_assert(sizeof(umx::HWRef) == sizeof(HWRefDev) && sizeof(HWRefDev) == 12, "reference record layout");
+    for (int ph = 0; ph < nphase; ++ph) {
+        const std::vector<umx::HWRef>& refs = L.wrefs[ph];
+        if (refs.empty()) continue;
+        HWRefDev* d = nullptr;
+        T_TRY(talloc(tr, &d, refs.size()));
+        T_HIP(tr, hipMemcpy(d, refs.data(), refs.size() * sizeof(HWRefDev), hipMemcpyHostToDevice));
+        RepackDesc rd;
+        memset(&rd, 0, sizeof rd);
+        rd.refs = d;
+        rd.n = (int)refs.size();
+        for (int g = 0; g < ngroups; ++g) rd.arr[g] = tc.packed[ph][g];
+        rd.stride = tc.cp.Np;
+        rd.scale = std::ldexp(1.f, sh);
+        rd.slab = const_cast<uint4*>(L.hcp.ph[ph].w);
+        tr->rdescs.push_back(rd);
+        tr->max_refs = std::max(tr->max_refs, rd.n);
+        std::vector<umx::HWRef>().swap(L.wrefs[ph]);
+    }
+    {   // K split: enough workgroups to occupy the chip (two per CU) where a batch of 8 leaves a deep layer a few dozen
+        HConvParams& h = L.hcp;
+        const long wgs = (long)((tr->B + h.imgs - 1) / h.imgs) * h.tiles_y * h.tiles_x * h.nblocks * nphase;
+        const char* e1 = getenv("UMX_TRAIN_HSPLIT_WGS");
+        // (one workgroup per CU: 512 / 768 / 1024 lose 3 / 7 / 10 % of the step to the ordered reduce over more partial sums, 128 / 192
+        // lose 1 % to idle CUs -- profiles/r04/train_ksplit_sweep.txt)
+        const long target = e1 ? atol(e1) : 256;
+        int S = (int)std::min<long>(kMaxKSplit, wgs > 0 ? (target + wgs - 1) / wgs : 1);
+        if (getenv("UMX_TRAIN_NO_KSPLIT") || wgs * 2 > target) S = 1;
+        std::vector<std::vector<int>> starts(nphase);   // per phase: stage indices (relative) where a halo chunk begins
+        for (int ph = 0; ph < nphase && S > 1; ++ph) {
+            for (int si = 0; si < h.ph[ph].nstages; ++si)
+                if (L.stages_host[h.ph[ph].stage0 + si].group >= 0) starts[ph].push_back(si);
+            S = std::min(S, (int)starts[ph].size());
+        }
+        if (S > 1) {
+            for (int ph = 0; ph < nphase; ++ph) {
+                const int nch = (int)starts[ph].size();
+                for (int k = 0; k < S; ++k) h.ks0[ph][k] = (short)starts[ph][(size_t)((long)nch * k / S)];
+                h.ks0[ph][S] = (short)h.ph[ph].nstages;
+            }
+            h.ksplit = S;
+            h.split_stride = (size_t)tr->B * L.outH * L.outW * Cout;
+            if (h.xcd_order == 2) h.xcd_order = 1;
+            tr->split_floats = std::max(tr->split_floats, (size_t)S * h.split_stride);
+        }
+        if (getenv("UMX_DEBUG_PLAN")) fprintf(stderr, "[umx train] %s: %ld workgroups, K split %d\n", what, wgs, S);
+    }
+    std::vector<HStage>().swap(L.stages_host);
+    tc.hidx = (int)tr->hls.size();
+    tr->hls.push_back(std::move(L));
+    return UMX_OK;
+}
 
 int setup_conv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int Cout, int act, int nphase, int o_mul,
                const int* oy, const int* ox, int ngroups, GroupSpec* gs) {
@@ -280,8 +394,53 @@ int setup_conv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int C
             tr->max_pack = std::max(tr->max_pack, elems);
             tc.mac += (double)H * W * nt * gs[g].C * Cout;
         }
+    T_TRY(setup_hconv(tr, tc, what, H, W, Cout, act, nphase, o_mul, oy, ox, ngroups, gs));
     return UMX_OK;
 }
+
+int alloc_h16(umx_trainer* tr, H16& h, size_t npix, int C) {
+    h.Cs = round_up(std::max(C, 1), 8);
+    T_TRY(tzero(tr, &h.hi, npix * h.Cs));
+    T_TRY(tzero(tr, &h.lo, npix * h.Cs));
+    return UMX_OK;
+}
+
+// fp32 NHWC tensor -> the (hi, lo) planes conv_f16x3 reads (maxw / inv: a gradient tensor's dynamic scale, else NULL)
+int to_h16(umx_trainer* tr, const float* x, size_t npix, int C, const H16& h, const unsigned* maxw, float* inv, hipStream_t st,
+           unsigned* omax = nullptr) {
+    if (!tr->hconv) return UMX_OK;
+    T_HIP(tr, launch_split_dyn(x, npix, C, h.Cs, maxw, inv, h.hi, h.lo, reinterpret_cast<int*>(tr->d_maxw + tr->n_maxw), omax, st));
+    return UMX_OK;
+}
+
+int run_hconv(umx_trainer* tr, TConv& tc, const H16& s0, const H16* s1, float* dst, const float* xinv, hipStream_t st) {
+    HConvParams p = tr->hls[tc.hidx].hcp;
+    p.B = tr->B;
+    p.overflow_flag = reinterpret_cast<int*>(tr->d_maxw + tr->n_maxw);
+    const H16* src[2] = {&s0, s1 ? s1 : &s0};
+    for (int gi = 0; gi < 2; ++gi) {
+        p.src_hi[gi] = gi == 0 || s1 ? src[gi]->hi : nullptr;
+        p.src_lo[gi] = gi == 0 || s1 ? src[gi]->lo : nullptr;
+        p.Cs[gi] = src[gi]->Cs;
+        p.srcA[gi] = src[gi]->Cs * 2;
+        p.srcB[gi] = 16;
+    }
+    p.dst_f32 = dst;
+    p.dyn[0] = tc.winv;
+    p.dyn[1] = xinv;
+    if (p.ksplit > 1) {   // raw partial sums, then the ordered reduce applies the activation
+        const int act = p.act;
+        p.act = ACT_NONE;
+        p.dst_f32 = tr->d_split;
+        T_HIP(tr, launch_conv_f16(p, st));
+        T_HIP(tr, launch_split_reduce(tr->d_split, p.ksplit, p.split_stride, p.split_stride, act, dst, st));
+        return UMX_OK;
+    }
+    T_HIP(tr, launch_conv_f16(p, st));
+    return UMX_OK;
+}
+
+int pack_all(umx_trainer* tr, hipStream_t st);
 
 int run_conv(umx_trainer* tr, TConv& tc, const float* src0, const float* src1, float* dst, bool on_side = false) {
     ConvParams p = tc.cp;
@@ -415,32 +574,47 @@ int forward_pass(umx_trainer* tr, const float* data, bool training, bool update)
     auto rate = [&](float r) { return training ? r : 0.f; };
     // (training: every activation that the backward pass feeds to the split-precision weight gradient gets its max |v|
     // tracked by the kernel that writes it -- the input batch and the transposed-conv outputs by a pass of their own)
+    // a convolution on whichever route its plan took: conv_f16x3 reads the (hi, lo) planes, conv_mfma_f32 the fp32 tensors
+    auto conv = [&](TConv& tc, const float* x0, const float* x1, const H16* h0, const H16* h1, float* dst) -> int {
+        if (tc.hidx >= 0) return run_hconv(tr, tc, *h0, h1, dst, nullptr, st);
+        return run_conv(tr, tc, x0, x1, dst);
+    };
+    const size_t Bz = (size_t)tr->B;
     tr->ds[0] = const_cast<float*>(data);
-    if (training) T_HIP(tr, launch_absmax(data, (size_t)tr->B * tr->P * tr->P * tr->n[0], tr->dsmax[0], st));
+    if (training && !tr->hconv) T_HIP(tr, launch_absmax(data, Bz * tr->P * tr->P * tr->n[0], tr->dsmax[0], st));
+    if (tr->hconv) T_TRY(to_h16(tr, data, Bz * tr->P * tr->P, tr->n[0], tr->h_ds[0], nullptr, nullptr, st, training ? tr->dsmax[0] : nullptr));
     int S = tr->P;
     for (int i = 0; i < L; ++i) {
         BnSite& s = tr->bn_d[i];
-        T_TRY(run_conv(tr, tr->c_fwd_d[i], tr->ds[i], nullptr, s.z));
+        T_TRY(conv(tr->c_fwd_d[i], tr->ds[i], nullptr, tr->hconv ? &tr->h_ds[i] : nullptr, nullptr, s.z));
         T_TRY(bn_forward_stats(tr, s, update, training));
         T_HIP(tr, launch_act_fwd(act_params(tr, s, 1, ACT_LEAKY, rate(down_rate(tr, i)), LAYER_DOWN + i), tr->ds[i + 1],
                                  training ? tr->dsmax[i + 1] : nullptr, st));
         S /= 2;
+        if (tr->hconv) T_TRY(to_h16(tr, tr->ds[i + 1], Bz * S * S, tr->n[i + 1], tr->h_ds[i + 1], nullptr, nullptr, st));
     }
-    T_TRY(run_conv(tr, tr->c_fwd_b, tr->ds[L], nullptr, tr->bn_b.z));
+    T_TRY(conv(tr->c_fwd_b, tr->ds[L], nullptr, tr->hconv ? &tr->h_ds[L] : nullptr, nullptr, tr->bn_b.z));
     T_TRY(bn_forward_stats(tr, tr->bn_b, update, training));
     T_HIP(tr, launch_act_fwd(act_params(tr, tr->bn_b, 0, ACT_LEAKY, rate(o.drop_bottom), LAYER_BOTTOM), tr->act_b,
                              training ? tr->bmax : nullptr, st));
+    if (tr->hconv) T_TRY(to_h16(tr, tr->act_b, Bz * S * S, tr->n[L + 1], tr->h_b, nullptr, nullptr, st));
     const float* cur = tr->act_b;
+    const H16* hcur = tr->hconv ? &tr->h_b : nullptr;
     for (int idx = L - 1; idx >= 0; --idx) {
         BnSite& s = tr->bn_u[idx];
         S *= 2;
-        T_TRY(run_conv(tr, tr->c_T[idx], cur, nullptr, tr->us[idx]));
-        if (training) T_HIP(tr, launch_absmax(tr->us[idx], (size_t)tr->B * S * S * tr->n[idx + 1], tr->usmax[idx], st));
-        T_TRY(run_conv(tr, tr->c_fwd_u[idx], tr->ds[idx], tr->us[idx], s.z));
+        T_TRY(conv(tr->c_T[idx], cur, nullptr, hcur, nullptr, tr->us[idx]));
+        // (max |us| for the split-precision weight gradient: tracked by the plane split where there is one)
+        if (training && !tr->hconv) T_HIP(tr, launch_absmax(tr->us[idx], Bz * S * S * tr->n[idx + 1], tr->usmax[idx], st));
+        if (tr->hconv) T_TRY(to_h16(tr, tr->us[idx], Bz * S * S, tr->n[idx + 1], tr->h_us[idx], nullptr, nullptr, st,
+                                    training ? tr->usmax[idx] : nullptr));
+        T_TRY(conv(tr->c_fwd_u[idx], tr->ds[idx], tr->us[idx], tr->hconv ? &tr->h_ds[idx] : nullptr, tr->hconv ? &tr->h_us[idx] : nullptr, s.z));
         T_TRY(bn_forward_stats(tr, s, update, training));
         T_HIP(tr, launch_act_fwd(act_params(tr, s, 0, ACT_LEAKY, rate(up_rate(tr, idx)), LAYER_UP + idx), tr->cv[idx],
                                  training ? tr->cvmax[idx] : nullptr, st));
+        if (tr->hconv && idx >= 1) T_TRY(to_h16(tr, tr->cv[idx], Bz * S * S, tr->n[idx + 1], tr->h_cv[idx], nullptr, nullptr, st));
         cur = tr->cv[idx];
+        hcur = tr->hconv && idx >= 1 ? &tr->h_cv[idx] : nullptr;
     }
     BnSite& t = tr->bn_t;
     T_HIP(tr, launch_head_fwd(tr->cv[0], (size_t)tr->B * tr->P * tr->P, tr->n[1], tr->K, tr->d_w + tr->o_lt, t.z, st));
@@ -456,7 +630,7 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
     if (tr->prof) T_HIP(tr, hipEventRecord(tr->ev[0], st));
     T_HIP(tr, hipMemsetAsync(tr->d_loss, 0, 2 * sizeof(double), st));
     T_HIP(tr, hipMemsetAsync(tr->d_maxw, 0, (tr->n_maxw + 1) * sizeof(unsigned), st));
-    T_HIP(tr, launch_pack_weights(tr->d_packs, (int)tr->packs.size(), tr->max_pack, st));
+    T_TRY(pack_all(tr, st));
 
     T_TRY(forward_pass(tr, data, true, update));
     BnSite& t = tr->bn_t;
@@ -501,6 +675,17 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         used[sl] = true;
         return UMX_OK;
     };
+    // the gradient w.r.t. a conv output as (hi, lo) planes, scaled by the power of two its max |v| word asks for (conv_f16x3's
+    // input-gradient launches; the fp32 tensor stays: the weight gradients stage from it)
+    auto dz_planes = [&](int sl, const float* dzp, size_t npix, int C, const unsigned* gmax) -> int {
+        if (!tr->hconv) return UMX_OK;
+        tr->h_dz[sl].Cs = round_up(C, 8);
+        return to_h16(tr, dzp, npix, C, tr->h_dz[sl], gmax, tr->d_xinv + sl, st);
+    };
+    auto dgrad = [&](TConv& tc, const float* x, const H16& h, const float* xinv, float* dst) -> int {
+        if (tc.hidx >= 0) return run_hconv(tr, tc, h, nullptr, dst, xinv, st);
+        return run_conv(tr, tc, x, nullptr, dst);
+    };
     int S = P;
     for (int idx = 0; idx < L; ++idx) {    // up layers, output side first
         BnSite& s = tr->bn_u[idx];
@@ -514,8 +699,9 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         T_TRY(dz_ready(slot));
         T_TRY(run_wgrad(tr, tr->wg_u0[idx], tr->ds[idx], dz, Cskip + Cup, 0, tr->o_w2[idx], o.reg_up, SIZE_MAX, tr->dsmax[idx], s.gmax, ws));
         T_TRY(run_wgrad(tr, tr->wg_u1[idx], tr->us[idx], dz, Cskip + Cup, Cskip, tr->o_w2[idx], o.reg_up, SIZE_MAX, tr->usmax[idx], s.gmax, ws));
-        T_TRY(run_conv(tr, tr->c_dg_us[idx], dz, nullptr, tr->DB));
-        if (idx >= 1) T_TRY(run_conv(tr, tr->c_dg_skip[idx], dz, nullptr, tr->dskip[idx]));   // (side stream: 2 % slower)
+        T_TRY(dz_planes(slot, dz, (size_t)B * S * S, Cup, s.gmax));
+        T_TRY(dgrad(tr->c_dg_us[idx], dz, tr->h_dz[slot], tr->d_xinv + slot, tr->DB));
+        if (idx >= 1) T_TRY(dgrad(tr->c_dg_skip[idx], dz, tr->h_dz[slot], tr->d_xinv + slot, tr->dskip[idx]));   // (side stream: 2 % slower)
         T_HIP(tr, launch_leaky_bwd_s2d_max(tr->DB, tr->us[idx], B, S / 2, Cup, gs, tr->smax[idx], st));
         if (tr->overlap) {
             T_HIP(tr, hipEventRecord(tr->ev_gs[slot], st));
@@ -524,7 +710,11 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         T_TRY(run_wgrad(tr, tr->wg_T[idx], gs, layer_in, Cup, 0, tr->o_wt[idx], o.reg_up, SIZE_MAX, tr->smax[idx],
                         idx == L - 1 ? tr->bmax : tr->cvmax[idx + 1], ws));
         T_TRY(side_done(slot));
-        T_TRY(run_conv(tr, tr->c_dg_T[idx], gs, nullptr, tr->DA));
+        if (tr->c_dg_T[idx].hidx >= 0) {
+            tr->h_gs[slot].Cs = round_up(4 * Cup, 8);
+            T_TRY(to_h16(tr, gs, (size_t)B * (S / 2) * (S / 2), 4 * Cup, tr->h_gs[slot], tr->smax[idx], tr->d_xinv + 2 + slot, st));
+        }
+        T_TRY(dgrad(tr->c_dg_T[idx], gs, tr->h_gs[slot], tr->d_xinv + 2 + slot, tr->DA));
         slot ^= 1;
         S /= 2;
     }
@@ -536,7 +726,8 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         T_TRY(dz_ready(slot));
         T_TRY(run_wgrad(tr, tr->wg_b, tr->ds[L], dz, tr->n[L], 0, tr->o_lb, o.reg_bottom, SIZE_MAX, tr->dsmax[L], tr->bn_b.gmax, ws));
         T_TRY(side_done(slot));
-        T_TRY(run_conv(tr, tr->c_dg_b, dz, nullptr, tr->DB));
+        T_TRY(dz_planes(slot, dz, (size_t)B * S * S, tr->n[L + 1], tr->bn_b.gmax));
+        T_TRY(dgrad(tr->c_dg_b, dz, tr->h_dz[slot], tr->d_xinv + slot, tr->DB));
         slot ^= 1;
     }
     for (int i = L - 1; i >= 0; --i) {     // down layers
@@ -550,7 +741,11 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         // c00 + shortcut = conv(x, W1 + Wshort): both filters receive the same data gradient (UnMicst1-5.py:102-114)
         T_TRY(run_wgrad(tr, tr->wg_d[i], tr->ds[i], dz, tr->n[i], 0, tr->o_ws[i], o.reg_down, tr->o_w1[i], tr->dsmax[i], s.gmax, ws));
         T_TRY(side_done(slot));
-        if (i >= 1) T_TRY(run_conv(tr, tr->c_dg_d[i], dz, nullptr, tr->DB));
+        S *= 2;
+        if (i >= 1) {
+            T_TRY(dz_planes(slot, dz, (size_t)B * S * S, tr->n[i + 1], s.gmax));
+            T_TRY(dgrad(tr->c_dg_d[i], dz, tr->h_dz[slot], tr->d_xinv + slot, tr->DB));
+        }
         slot ^= 1;
     }
     if (tr->overlap) {   // join: the optimiser (and the caller) see every gradient
@@ -700,6 +895,37 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
         tr->bmax = tr->d_maxw + k++;
     }
 
+    // ---- split-precision route of the forward / input-gradient convolutions: planes of every tensor they read
+    tr->hconv = !getenv("UMX_TRAIN_CONV_F32");
+    tr->h_blob = blob;
+    if (tr->hconv) {
+        tr->pctx = new umx_ctx();
+        tr->pctx->device = tr->device;
+        tr->pctx->hp = hp;
+        tr->h_ds.resize(L + 1); tr->h_us.resize(L); tr->h_cv.resize(L);
+        int S2 = P;
+        size_t max_dz = 0, max_gs = 0;
+        for (int i = 0; i <= L; ++i) {
+            T_TRY(alloc_h16(tr, tr->h_ds[i], (size_t)B * S2 * S2, n[i]));
+            if (i < L) max_dz = std::max(max_dz, (size_t)B * S2 * S2 * round_up(n[i + 1], 8));
+            if (i < L) S2 /= 2;
+        }
+        T_TRY(alloc_h16(tr, tr->h_b, (size_t)B * S2 * S2, n[L + 1]));
+        max_dz = std::max(max_dz, (size_t)B * S2 * S2 * round_up(n[L + 1], 8));
+        for (int idx = L - 1; idx >= 0; --idx) {
+            max_gs = std::max(max_gs, (size_t)B * S2 * S2 * round_up(4 * n[idx + 1], 8));
+            S2 *= 2;
+            T_TRY(alloc_h16(tr, tr->h_us[idx], (size_t)B * S2 * S2, n[idx + 1]));
+            if (idx >= 1) T_TRY(alloc_h16(tr, tr->h_cv[idx], (size_t)B * S2 * S2, n[idx + 1]));
+            max_dz = std::max(max_dz, (size_t)B * S2 * S2 * round_up(n[idx + 1], 8));
+        }
+        for (int sl = 0; sl < 2; ++sl) {   // gradient planes, one set per dz / gS slot; Cs is set per use
+            T_TRY(tzero(tr, &tr->h_dz[sl].hi, max_dz)); T_TRY(tzero(tr, &tr->h_dz[sl].lo, max_dz));
+            T_TRY(tzero(tr, &tr->h_gs[sl].hi, max_gs)); T_TRY(tzero(tr, &tr->h_gs[sl].lo, max_gs));
+        }
+        T_TRY(tzero(tr, &tr->d_xinv, 4));
+    }
+
     // ---- conv launches
     tr->c_fwd_d.resize(L); tr->c_dg_d.resize(L); tr->c_T.resize(L); tr->c_fwd_u.resize(L);
     tr->c_dg_us.resize(L); tr->c_dg_skip.resize(L); tr->c_dg_T.resize(L);
@@ -830,6 +1056,20 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
     }
     T_TRY(talloc(tr, &tr->d_packs, tr->packs.size()));
     T_HIP(tr, hipMemcpy(tr->d_packs, tr->packs.data(), tr->packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
+    if (!tr->rdescs.empty()) {
+        T_TRY(talloc(tr, &tr->d_rdescs, tr->rdescs.size()));
+        T_HIP(tr, hipMemcpy(tr->d_rdescs, tr->rdescs.data(), tr->rdescs.size() * sizeof(RepackDesc), hipMemcpyHostToDevice));
+    }
+    tr->h_blob = nullptr;
+    return UMX_OK;
+}
+
+// the step's weights -> the operands of every convolution: fp32 [tap][Cp][Np] (both routes), then conv_f16x3's weight images
+int pack_all(umx_trainer* tr, hipStream_t st) {
+    T_HIP(tr, launch_pack_weights(tr->d_packs, (int)tr->packs.size(), tr->max_pack, st));
+    if (!tr->rdescs.empty())
+        T_HIP(tr, launch_repack_f16x3(tr->d_rdescs, (int)tr->rdescs.size(), tr->max_refs,
+                                      reinterpret_cast<int*>(tr->d_maxw + tr->n_maxw), st));
     return UMX_OK;
 }
 
@@ -915,6 +1155,10 @@ void umx_trainer_destroy(umx_trainer* tr) {
     (void)hipSetDevice(tr->device);
     if (tr->stream) (void)hipStreamSynchronize(tr->stream);
     for (void* p : tr->allocs) (void)hipFree(p);
+    if (tr->pctx) {
+        for (void* p : tr->pctx->allocs) (void)hipFree(p);
+        delete tr->pctx;
+    }
     for (int i = 0; i < 4; ++i)
         if (tr->ev[i]) (void)hipEventDestroy(tr->ev[i]);
     if (tr->side) { (void)hipStreamSynchronize(tr->side); (void)hipStreamDestroy(tr->side); }
@@ -974,7 +1218,7 @@ int umx_trainer_eval(umx_trainer* tr, const float* data, float* probs_host) {
     const size_t npx = (size_t)tr->B * tr->P * tr->P;
     float* own = tr->ds[0];
     T_HIP(tr, hipMemcpyAsync(own, data, npx * tr->n[0] * sizeof(float), hipMemcpyHostToDevice, tr->stream));
-    T_HIP(tr, launch_pack_weights(tr->d_packs, (int)tr->packs.size(), tr->max_pack, tr->stream));
+    T_TRY(pack_all(tr, tr->stream));
     const int rc = forward_pass(tr, own, false, false);
     tr->ds[0] = own;
     T_TRY(rc);

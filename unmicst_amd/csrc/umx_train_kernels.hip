@@ -266,6 +266,109 @@ hipError_t launch_absmax(const float* x, size_t n, unsigned* omax, hipStream_t s
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Forward / input-gradient convolutions on conv_f16x3 (round 4).  The filters change every step: pack_weights_kernel rebuilds the
+// fp32 operands [tap][Cp][Np] from the masters as before, and this kernel gathers them into the LDS-image order the planner laid
+// out once (HWRef, umx_internal.h), scaled by the power of two that puts the layer's largest |w| of the START of training in
+// [2^10, 2^11) -- 32 x headroom; a weight that outgrows binary16 raises the range flag -- as (hi, lo) binary16 pairs.
+// One thread per 16-byte unit; consecutive lanes read consecutive output channels of the fp32 operand (coalesced per element).
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) repack_f16x3_kernel(const RepackDesc* __restrict__ descs, int* __restrict__ overflow) {
+    const RepackDesc d = descs[blockIdx.y];
+    bool bad = false;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += gridDim.x * 256) {
+        const HWRefDev r = d.refs[i];
+        const float* const src = d.arr[r.arr] + r.base;
+        union { _Float16 h[8]; uint4 u; } vh, vl;
+        vh.u = make_uint4(0, 0, 0, 0);
+        vl.u = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (e < (int)r.nvalid) {
+                const float v = src[(size_t)e * d.stride] * d.scale;
+                bad = bad || !(fabsf(v) < 60000.f);
+                vh.h[e] = (_Float16)v;
+                vl.h[e] = (_Float16)(v - (float)vh.h[e]);
+            }
+        }
+        d.slab[r.dst] = vh.u;
+        d.slab[r.dst + 64] = vl.u;
+    }
+    if (bad) atomicOr(overflow, 1);
+}
+
+hipError_t launch_repack_f16x3(const RepackDesc* descs_dev, int ndesc, int max_n, int* overflow, hipStream_t stream) {
+    if (ndesc <= 0) return hipSuccess;
+    const unsigned bx = (unsigned)std::min(512, (max_n + 255) / 256);
+    hipLaunchKernelGGL(repack_f16x3_kernel, dim3(bx ? bx : 1, (unsigned)ndesc), dim3(256), 0, stream, descs_dev, overflow);
+    return hipGetLastError();
+}
+
+// fp32 NHWC [npix, C] -> (hi, lo) binary16 NHWC [npix, Cs] (Cs = C rounded up to 8, pad channels zero) for conv_f16x3.  `maxw`
+// (nullable): the tensor's max |v| as float bits, written by its producer -- a gradient tensor is scaled by the power of two that
+// puts that maximum in [2^11, 2^12) (gradients would flush to zero otherwise) and the inverse factor goes to *inv_scale for the
+// consuming convolution's epilogue (HConvParams::dyn); without it the tensor is stored as it is.  Non-finite or out-of-range
+// values raise the flag.
+__global__ void __launch_bounds__(256) split_dyn_kernel(const float* __restrict__ x, size_t npix, int C, int Cs,
+                                                       const unsigned* __restrict__ maxw, float* __restrict__ inv_scale,
+                                                       _Float16* __restrict__ hi, _Float16* __restrict__ lo, int* __restrict__ overflow,
+                                                       unsigned* __restrict__ omax) {
+    float scale = 1.f, mx = 0.f;   // (omax: the tensor's max |v| for the weight-gradient kernel, one integer atomicMax per block)
+    if (maxw) {
+        const unsigned mb = *maxw;
+        const int e = (int)((mb >> 23) & 0xFFu);
+        if (mb != 0u && e > 0 && e < 255) {
+            const int sh = max(-100, min(100, 11 - (e - 127)));
+            scale = __uint_as_float((unsigned)(127 + sh) << 23);
+        }
+        if (inv_scale && blockIdx.x == 0 && threadIdx.x == 0) *inv_scale = 1.f / scale;
+    }
+    const size_t total = npix * (size_t)Cs;
+    bool bad = false;
+    if ((C & 3) == 0 && Cs == C) {   // whole float4 / 8-byte units
+        const size_t n4 = total / 4;
+        const float4* const x4 = reinterpret_cast<const float4*>(x);
+        uint2* const h2 = reinterpret_cast<uint2*>(hi);
+        uint2* const l2 = reinterpret_cast<uint2*>(lo);
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            const float4 v = x4[i];
+            const float f[4] = {v.x * scale, v.y * scale, v.z * scale, v.w * scale};
+            union { _Float16 h[4]; uint2 u; } a, b;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                mx = fmaxf(mx, fabsf(f[k]));
+                bad = bad || !(fabsf(f[k]) < 60000.f);
+                a.h[k] = (_Float16)f[k];
+                b.h[k] = (_Float16)(f[k] - (float)a.h[k]);
+            }
+            h2[i] = a.u;
+            l2[i] = b.u;
+        }
+    } else {
+        for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+            const size_t px = e / Cs;
+            const int c = (int)(e - px * Cs);
+            const float v = c < C ? x[px * C + c] * scale : 0.f;
+            mx = fmaxf(mx, fabsf(v));
+            bad = bad || !(fabsf(v) < 60000.f);
+            const _Float16 h = (_Float16)v;
+            hi[e] = h;
+            lo[e] = (_Float16)(v - (float)h);
+        }
+    }
+    if (bad) atomicOr(overflow, 1);
+    if (omax) block_absmax_to(omax, mx);   // (only asked for unscaled tensors: scale == 1)
+}
+
+hipError_t launch_split_dyn(const float* x, size_t npix, int C, int Cs, const unsigned* maxw, float* inv_scale, _Float16* hi,
+                            _Float16* lo, int* overflow, unsigned* omax, hipStream_t stream) {
+    if (npix == 0) return hipSuccess;
+    const size_t total = npix * (size_t)Cs;
+    const unsigned blocks = (unsigned)std::min<size_t>(4096, (total / 4 + 255) / 256 + 1);
+    hipLaunchKernelGGL(split_dyn_kernel, dim3(blocks), dim3(256), 0, stream, x, npix, C, Cs, maxw, inv_scale, hi, lo, overflow, omax);
+    return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(256) act_bwd_kernel(const ActParams a, const float* __restrict__ dy0,
                                                       const float* __restrict__ dy1, float* __restrict__ g, size_t Nrows,
                                                       int Cb, int k, double* __restrict__ part) {
