@@ -25,7 +25,17 @@ from collections import OrderedDict
 
 
 def short(name):
+    if name.startswith("_ZN3umx"):   # (rocprofv3 leaves names with _Float16 parameters mangled: _ZN3umx16split_dyn_kernelE...)
+        import re
+        m = re.match(r"_ZN3umx(\d+)", name)
+        if m:
+            n = int(m.group(1))
+            return "umx::" + name[len(m.group(0)):len(m.group(0)) + n]
     return name.replace("void ", "").split("(")[0]
+
+
+def ours(name):
+    return "umx::" in name or name.startswith("_ZN3umx")
 
 
 def rows_from_csv(path):
@@ -73,7 +83,7 @@ def pmc_from_db(path, marker):
         if did != last:
             pos = cyc.step(kn)
             last = did
-        if "umx::" not in kn:
+        if not ours(kn):
             continue
         e = out.setdefault(cn, {}).setdefault((pos, short(kn), gx, gy, gz), [0.0, 0])
         e[0] += v
@@ -95,7 +105,7 @@ def main():
     cyc = Cycle(a.cycle)
     for name, gx, gy, gz, lds, vg, d in src:
         pos = cyc.step(name)
-        if "umx::" not in name and not a.all:
+        if not ours(name) and not a.all:
             continue
         e = rows.setdefault((pos, short(name), gx, gy, gz, lds, vg), [0, 0, 1 << 62, 0])
         e[0] += 1

@@ -437,11 +437,18 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
         if constexpr (post) asm volatile("; epilogue arithmetic, second affine");
         else asm volatile("; epilogue arithmetic");
         // (trainer launches: the dynamic operand scales, two device scalars; 1 otherwise -- four multiplies per N-tile, no branch)
-        const float dyn = (p.dyn[0] ? *p.dyn[0] : 1.f) * (p.dyn[1] ? *p.dyn[1] : 1.f);
+        // (compiled into the fp32-output instance of this function only: the fused head is the other, range-tracked one)
+        float dyn = 1.f;
+        if constexpr (!track) dyn = (p.dyn[0] ? *p.dyn[0] : 1.f) * (p.dyn[1] ? *p.dyn[1] : 1.f);
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const float4 ps = ec4[0 * NT * 4 + n * 4 + q], pb = ec4[1 * NT * 4 + n * 4 + q];
-            const float psa[4] = {ps.x * dyn, ps.y * dyn, ps.z * dyn, ps.w * dyn}, pba[4] = {pb.x, pb.y, pb.z, pb.w};
+            float psa[4] = {ps.x, ps.y, ps.z, ps.w};
+            const float pba[4] = {pb.x, pb.y, pb.z, pb.w};
+            if constexpr (!track) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) psa[r] *= dyn;
+            }
             float qsa[4] = {1.f, 1.f, 1.f, 1.f}, qba[4] = {0.f, 0.f, 0.f, 0.f};
             if constexpr (post) {
                 const float4 qs = ec4[2 * NT * 4 + n * 4 + q], qb = ec4[3 * NT * 4 + n * 4 + q];

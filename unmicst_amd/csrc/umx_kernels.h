@@ -233,6 +233,7 @@ struct PackDesc {
     int d2, d3;            // master tensor [taps][d2][d3]
     int transpose, c_off;
     int npar, Cblk;
+    int bwd;               // (host bookkeeping) an operand only the backward pass reads: packed on the side stream under the forward pass
     short mtap[4 * kMaxPackTaps];
 };
 hipError_t launch_pack_weights(const PackDesc* descs_dev, int ndesc, size_t max_elems, hipStream_t stream);
@@ -272,6 +273,7 @@ struct RepackDesc {
     int stride;             // Np: elements between consecutive input channels
     float scale;            // 2^s applied to the weights (the launch's HConvParams::dyn[0] points at 2^-s)
     uint4* slab;            // the phase list's weight slab (headers stay as the planner wrote them)
+    int bwd;                // (host bookkeeping) as PackDesc::bwd
 };
 hipError_t launch_repack_f16x3(const RepackDesc* descs_dev, int ndesc, int max_n, int* overflow, hipStream_t stream);
 hipError_t launch_split_dyn(const float* x, size_t npix, int C, int Cs, const unsigned* maxw, float* inv_scale, _Float16* hi,

@@ -93,6 +93,7 @@ struct umx_trainer {
     hipEvent_t ev_dz[2] = {nullptr, nullptr}, ev_gs[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr}, ev_join = nullptr;
     bool overlap = true;
     double* d_part = nullptr;  size_t part_doubles = 0;
+    double* d_part2 = nullptr;          // the side stream's own partial sums (regularisation loss under the forward pass)
     double* d_loss = nullptr;           // [0] data term, [1] regularisation
     unsigned* d_maxw = nullptr;  int n_maxw = 0;   // per-tensor max |gradient| words, then the binary16 range flag
     std::vector<unsigned*> smax;        // max |gS| per up layer
@@ -109,6 +110,9 @@ struct umx_trainer {
     std::vector<RepackDesc> rdescs;
     RepackDesc* d_rdescs = nullptr;
     int max_refs = 0;
+    bool cur_bwd = false;               // (during build) the convolution being set up belongs to the backward pass
+    int n_fwd_packs = 0, n_fwd_rdescs = 0;   // descriptors [0, n_fwd) serve the forward pass, the rest the backward pass only
+    hipEvent_t ev_begin = nullptr, ev_packed = nullptr;
     std::vector<H16> h_ds, h_us, h_cv;  // planes of ds[i], us[idx], cv[idx]
     H16 h_b, h_dz[2], h_gs[2];
     float* d_xinv = nullptr;            // [4] inverse scales of the dz / gS slots' planes, written by split_dyn_kernel
@@ -256,6 +260,7 @@ int setup_hconv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int 
         rd.stride = tc.cp.Np;
         rd.scale = std::ldexp(1.f, sh);
         rd.slab = const_cast<uint4*>(L.hcp.ph[ph].w);
+        rd.bwd = tr->cur_bwd ? 1 : 0;
         tr->rdescs.push_back(rd);
         tr->max_refs = std::max(tr->max_refs, rd.n);
         std::vector<umx::HWRef>().swap(L.wrefs[ph]);
@@ -390,6 +395,7 @@ int setup_conv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int C
             d.transpose = gs[g].transpose; d.c_off = gs[g].c_off;
             d.npar = gs[g].npar; d.Cblk = gs[g].Cblk;
             for (size_t i = 0; i < ts.m.size(); ++i) d.mtap[i] = (short)ts.m[i];
+            d.bwd = tr->cur_bwd ? 1 : 0;
             tr->packs.push_back(d);
             tr->max_pack = std::max(tr->max_pack, elems);
             tc.mac += (double)H * W * nt * gs[g].C * Cout;
@@ -440,7 +446,7 @@ int run_hconv(umx_trainer* tr, TConv& tc, const H16& s0, const H16* s1, float* d
     return UMX_OK;
 }
 
-int pack_all(umx_trainer* tr, hipStream_t st);
+int pack_all(umx_trainer* tr, hipStream_t st, int part);
 
 int run_conv(umx_trainer* tr, TConv& tc, const float* src0, const float* src1, float* dst, bool on_side = false) {
     ConvParams p = tc.cp;
@@ -630,7 +636,19 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
     if (tr->prof) T_HIP(tr, hipEventRecord(tr->ev[0], st));
     T_HIP(tr, hipMemsetAsync(tr->d_loss, 0, 2 * sizeof(double), st));
     T_HIP(tr, hipMemsetAsync(tr->d_maxw, 0, (tr->n_maxw + 1) * sizeof(unsigned), st));
-    T_TRY(pack_all(tr, st));
+    if (tr->overlap) {
+        // the side stream is idle until the first weight gradient: it packs the backward pass's operands and sums the regularisation
+        // loss (both need nothing but this step's weights) while the main stream runs the forward pass
+        T_HIP(tr, hipEventRecord(tr->ev_begin, st));
+        T_HIP(tr, hipStreamWaitEvent(tr->side, tr->ev_begin, 0));
+        T_TRY(pack_all(tr, st, 0));
+        T_TRY(pack_all(tr, tr->side, 1));
+        if (o.reg_kind != UMX_REG_NONE)
+            T_HIP(tr, launch_reg_loss(tr->d_regsegs, tr->n_regsegs, o.reg_kind, tr->d_part2, tr->d_loss, 1, tr->side));
+        T_HIP(tr, hipEventRecord(tr->ev_packed, tr->side));
+    } else {
+        T_TRY(pack_all(tr, st, 2));
+    }
 
     T_TRY(forward_pass(tr, data, true, update));
     BnSite& t = tr->bn_t;
@@ -640,8 +658,9 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
                                       nblk, st));
         T_HIP(tr, launch_sum_to_scalar(tr->d_part, nblk, 1.0 / (double)Npix, tr->d_loss, 0, 0, st));
     }
-    if (o.reg_kind != UMX_REG_NONE)
+    if (o.reg_kind != UMX_REG_NONE && !tr->overlap)
         T_HIP(tr, launch_reg_loss(tr->d_regsegs, tr->n_regsegs, o.reg_kind, tr->d_part, tr->d_loss, 1, st));
+    if (tr->overlap) T_HIP(tr, hipStreamWaitEvent(st, tr->ev_packed, 0));   // the backward pass's operands are in place
     if (tr->prof) T_HIP(tr, hipEventRecord(tr->ev[1], st));
 
     // ------------------------------------------------------------------ backward
@@ -877,6 +896,7 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
     for (int v : n) maxC = std::max(maxC, v);
     tr->part_doubles = std::max<size_t>((size_t)1024 * 2 * maxC, (size_t)1024 * n[1] * K) + 1024;
     T_TRY(talloc(tr, &tr->d_part, tr->part_doubles));
+    T_TRY(talloc(tr, &tr->d_part2, tr->part_doubles));
     T_TRY(tzero(tr, &tr->d_loss, 2));
     {   // max-|gradient| words: one per batch-normalised tensor and per up layer, + the range flag
         tr->n_maxw = 6 * L + 4;
@@ -947,7 +967,7 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
         mac_total += tr->c_fwd_d[i].mac;
         if (i >= 1) {
             GroupSpec gd = group(n[i + 1], tr->o_w1[i], tr->o_ws[i], n[i], n[i + 1], 1, 0, flp);
-            T_TRY(setup_conv(tr, tr->c_dg_d[i], nm, S, S, n[i], ACT_NONE, 1, 1, nullptr, nullptr, 1, &gd));
+            tr->cur_bwd = true; T_TRY(setup_conv(tr, tr->c_dg_d[i], nm, S, S, n[i], ACT_NONE, 1, 1, nullptr, nullptr, 1, &gd)); tr->cur_bwd = false;
             mac_total += tr->c_dg_d[i].mac;
         }
         T_TRY(setup_wgrad(tr, tr->wg_d[i], nm, S, n[i], n[i], n[i + 1], fwd, {}));
@@ -958,7 +978,7 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
         GroupSpec g = group(n[L], tr->o_lb, SIZE_MAX, n[L], n[L + 1], 0, 0, fwd);
         T_TRY(setup_conv(tr, tr->c_fwd_b, "lb", S, S, n[L + 1], ACT_NONE, 1, 1, nullptr, nullptr, 1, &g));
         GroupSpec gd = group(n[L + 1], tr->o_lb, SIZE_MAX, n[L], n[L + 1], 1, 0, flp);
-        T_TRY(setup_conv(tr, tr->c_dg_b, "lb", S, S, n[L], ACT_NONE, 1, 1, nullptr, nullptr, 1, &gd));
+        tr->cur_bwd = true; T_TRY(setup_conv(tr, tr->c_dg_b, "lb", S, S, n[L], ACT_NONE, 1, 1, nullptr, nullptr, 1, &gd)); tr->cur_bwd = false;
         T_TRY(setup_wgrad(tr, tr->wg_b, "lb", S, n[L], n[L], n[L + 1], fwd, {}));
         mac_total += tr->c_fwd_b.mac + tr->c_dg_b.mac + (double)S * S * ks * ks * n[L] * n[L + 1];
     }
@@ -1018,7 +1038,7 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
                         slabs.m.push_back(a * ks + b);
                         coff.push_back(par * Cup);
                     }
-            T_TRY(setup_conv(tr, tr->c_dg_T[idx], nm, S, S, Cin, ACT_NONE, 1, 1, nullptr, nullptr, 1, &g));
+            tr->cur_bwd = true; T_TRY(setup_conv(tr, tr->c_dg_T[idx], nm, S, S, Cin, ACT_NONE, 1, 1, nullptr, nullptr, 1, &g)); tr->cur_bwd = false;
             T_TRY(setup_wgrad(tr, tr->wg_T[idx], nm, S, 4 * Cup, Cup, Cin, slabs, coff));
             mac_total += 2.0 * S * S * ks * ks * Cin * Cup;
         }
@@ -1029,11 +1049,11 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
             T_TRY(setup_conv(tr, tr->c_fwd_u[idx], nm, S, S, Cup, ACT_NONE, 1, 1, nullptr, nullptr, 2, g2));
             mac_total += tr->c_fwd_u[idx].mac;
             GroupSpec gu = group(Cup, tr->o_w2[idx], SIZE_MAX, Cskip + Cup, Cup, 1, Cskip, flp);
-            T_TRY(setup_conv(tr, tr->c_dg_us[idx], nm, S, S, Cup, ACT_NONE, 1, 1, nullptr, nullptr, 1, &gu));
+            tr->cur_bwd = true; T_TRY(setup_conv(tr, tr->c_dg_us[idx], nm, S, S, Cup, ACT_NONE, 1, 1, nullptr, nullptr, 1, &gu)); tr->cur_bwd = false;
             mac_total += tr->c_dg_us[idx].mac;
             if (idx >= 1) {
                 GroupSpec gk = group(Cup, tr->o_w2[idx], SIZE_MAX, Cskip + Cup, Cup, 1, 0, flp);
-                T_TRY(setup_conv(tr, tr->c_dg_skip[idx], nm, S, S, Cskip, ACT_NONE, 1, 1, nullptr, nullptr, 1, &gk));
+                tr->cur_bwd = true; T_TRY(setup_conv(tr, tr->c_dg_skip[idx], nm, S, S, Cskip, ACT_NONE, 1, 1, nullptr, nullptr, 1, &gk)); tr->cur_bwd = false;
                 mac_total += tr->c_dg_skip[idx].mac;
             }
             T_TRY(setup_wgrad(tr, tr->wg_u0[idx], nm, S, Cskip, Cskip, Cup, fwd, {}));
@@ -1054,6 +1074,11 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
         T_TRY(talloc(tr, &tr->d_regsegs, rs.size()));
         if (!rs.empty()) T_HIP(tr, hipMemcpy(tr->d_regsegs, rs.data(), rs.size() * sizeof(RegSeg), hipMemcpyHostToDevice));
     }
+    // forward operands first: the backward-only ones are packed on the side stream while the forward pass runs
+    std::stable_partition(tr->packs.begin(), tr->packs.end(), [](const PackDesc& d) { return d.bwd == 0; });
+    std::stable_partition(tr->rdescs.begin(), tr->rdescs.end(), [](const RepackDesc& d) { return d.bwd == 0; });
+    tr->n_fwd_packs = (int)std::count_if(tr->packs.begin(), tr->packs.end(), [](const PackDesc& d) { return d.bwd == 0; });
+    tr->n_fwd_rdescs = (int)std::count_if(tr->rdescs.begin(), tr->rdescs.end(), [](const RepackDesc& d) { return d.bwd == 0; });
     T_TRY(talloc(tr, &tr->d_packs, tr->packs.size()));
     T_HIP(tr, hipMemcpy(tr->d_packs, tr->packs.data(), tr->packs.size() * sizeof(PackDesc), hipMemcpyHostToDevice));
     if (!tr->rdescs.empty()) {
@@ -1065,11 +1090,13 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
 }
 
 // the step's weights -> the operands of every convolution: fp32 [tap][Cp][Np] (both routes), then conv_f16x3's weight images
-int pack_all(umx_trainer* tr, hipStream_t st) {
-    T_HIP(tr, launch_pack_weights(tr->d_packs, (int)tr->packs.size(), tr->max_pack, st));
-    if (!tr->rdescs.empty())
-        T_HIP(tr, launch_repack_f16x3(tr->d_rdescs, (int)tr->rdescs.size(), tr->max_refs,
-                                      reinterpret_cast<int*>(tr->d_maxw + tr->n_maxw), st));
+// (part 0: the forward pass's operands, 1: the backward-only ones, 2: all)
+int pack_all(umx_trainer* tr, hipStream_t st, int part) {
+    const int p0 = part == 1 ? tr->n_fwd_packs : 0, p1 = part == 0 ? tr->n_fwd_packs : (int)tr->packs.size();
+    const int r0 = part == 1 ? tr->n_fwd_rdescs : 0, r1 = part == 0 ? tr->n_fwd_rdescs : (int)tr->rdescs.size();
+    if (p1 > p0) T_HIP(tr, launch_pack_weights(tr->d_packs + p0, p1 - p0, tr->max_pack, st));
+    if (r1 > r0)
+        T_HIP(tr, launch_repack_f16x3(tr->d_rdescs + r0, r1 - r0, tr->max_refs, reinterpret_cast<int*>(tr->d_maxw + tr->n_maxw), st));
     return UMX_OK;
 }
 
@@ -1136,7 +1163,8 @@ int umx_trainer_create(const umx_hparams* hp, const float* weight_blob, size_t b
     if (rc == UMX_OK) {
         tr->overlap = !getenv("UMX_TRAIN_NO_OVERLAP");
         if (hipStreamCreateWithFlags(&tr->side, hipStreamNonBlocking) != hipSuccess) rc = tfail(tr, UMX_ERR_HIP, "hipStreamCreate failed");
-        hipEvent_t* evs[] = {&tr->ev_dz[0], &tr->ev_dz[1], &tr->ev_gs[0], &tr->ev_gs[1], &tr->ev_side[0], &tr->ev_side[1], &tr->ev_join};
+        hipEvent_t* evs[] = {&tr->ev_dz[0], &tr->ev_dz[1], &tr->ev_gs[0], &tr->ev_gs[1], &tr->ev_side[0], &tr->ev_side[1], &tr->ev_join,
+                             &tr->ev_begin, &tr->ev_packed};
         for (hipEvent_t* e : evs)
             if (rc == UMX_OK && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess)
                 rc = tfail(tr, UMX_ERR_HIP, "hipEventCreate failed");
@@ -1162,7 +1190,8 @@ void umx_trainer_destroy(umx_trainer* tr) {
     for (int i = 0; i < 4; ++i)
         if (tr->ev[i]) (void)hipEventDestroy(tr->ev[i]);
     if (tr->side) { (void)hipStreamSynchronize(tr->side); (void)hipStreamDestroy(tr->side); }
-    for (hipEvent_t e : {tr->ev_dz[0], tr->ev_dz[1], tr->ev_gs[0], tr->ev_gs[1], tr->ev_side[0], tr->ev_side[1], tr->ev_join})
+    for (hipEvent_t e : {tr->ev_dz[0], tr->ev_dz[1], tr->ev_gs[0], tr->ev_gs[1], tr->ev_side[0], tr->ev_side[1], tr->ev_join, tr->ev_begin,
+                         tr->ev_packed})
         if (e) (void)hipEventDestroy(e);
     if (tr->stream) (void)hipStreamDestroy(tr->stream);
     delete tr;
@@ -1218,7 +1247,7 @@ int umx_trainer_eval(umx_trainer* tr, const float* data, float* probs_host) {
     const size_t npx = (size_t)tr->B * tr->P * tr->P;
     float* own = tr->ds[0];
     T_HIP(tr, hipMemcpyAsync(own, data, npx * tr->n[0] * sizeof(float), hipMemcpyHostToDevice, tr->stream));
-    T_TRY(pack_all(tr, tr->stream));
+    T_TRY(pack_all(tr, tr->stream, 0));
     const int rc = forward_pass(tr, own, false, false);
     tr->ds[0] = own;
     T_TRY(rc);
