@@ -75,7 +75,10 @@ def _hp(name):
 
 # the forward / input-gradient convolutions run on conv_f16x3 (split precision, round 4); UMX_TRAIN_CONV_F32=1 keeps them on the
 # exact-fp32 MFMA kernel, UMX_TRAIN_NO_KSPLIT=1 runs every one as a single pass over K (no partial sums)
-ROUTES = [{}, {"UMX_TRAIN_CONV_F32": "1"}, {"UMX_TRAIN_NO_KSPLIT": "1"}, {"UMX_TRAIN_HSPLIT_WGS": "4096"}]
+ROUTES = [{}, {"UMX_TRAIN_CONV_F32": "1"}, {"UMX_TRAIN_NO_KSPLIT": "1"}, {"UMX_TRAIN_HSPLIT_WGS": "4096"},
+          # the remaining switches of the trainer: one stream instead of two; fp32 weight-gradient kernel; the fp32 route's own K split
+          {"UMX_TRAIN_NO_OVERLAP": "1"}, {"UMX_TRAIN_WGRAD_F32": "1"},
+          {"UMX_TRAIN_CONV_F32": "1", "UMX_TRAIN_KSPLIT_WGS": "4096", "UMX_TRAIN_KSPLIT_MAX": "3"}]
 
 
 @pytest.mark.parametrize("route", ROUTES, ids=lambda r: ",".join("%s=%s" % kv for kv in r.items()) or "f16x3")
