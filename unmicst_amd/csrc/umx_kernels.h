@@ -243,8 +243,9 @@ int chan_blocks(size_t N, int C);
 hipError_t launch_chan_stats(const float* x, size_t N, int C, double* part, int nblk, hipStream_t stream);
 // batch statistics -> stat[4][C] = mean | rstd | scale = gamma*rstd | shift = beta - mean*scale; moving statistics
 // updated in place (momentum; the unbiased variance feeds the moving variance, like TF's fused kernel)
+// (smax, nullable: max_c |gamma * rstd| as float bits, atomicMax)
 hipError_t launch_bn_finalize(const double* part, int nblk, size_t N, int C, const float* gamma, const float* beta,
-                              float* mov_mean, float* mov_var, float momentum, float* stat, hipStream_t stream);
+                              float* mov_mean, float* mov_var, float momentum, float* stat, unsigned* smax, hipStream_t stream);
 
 // inference-mode statistics: stat from the moving averages (tf.layers.batch_normalization(training=False))
 hipError_t launch_bn_stat_from_moving(int C, const float* gamma, const float* beta, const float* mov_mean,
@@ -260,7 +261,9 @@ struct ActParams {          // y = dropout(act(z*scale + shift)) [-> 2x2 max-poo
     float drop_rate;
     unsigned long long drop_key;
 };
-hipError_t launch_act_fwd(const ActParams& a, float* out, unsigned* omax /* max |out| word or NULL */, hipStream_t stream);
+// (hi / lo / Cs, nullable: the output also as (hi, lo) binary16 NHWC planes with Cs stored channels; overflow: range flag)
+hipError_t launch_act_fwd(const ActParams& a, float* out, unsigned* omax /* max |out| word or NULL */, _Float16* hi, _Float16* lo,
+                          int Cs, int* overflow, hipStream_t stream);
 // omax = max(omax, max |x|)  (float bits; integer atomicMax)
 hipError_t launch_absmax(const float* x, size_t n, unsigned* omax, hipStream_t stream);
 // ---- forward / input-gradient convolutions of the trainer on conv_f16x3: weight images rebuilt on the device every step, and
@@ -279,8 +282,9 @@ hipError_t launch_repack_f16x3(const RepackDesc* descs_dev, int ndesc, int max_n
 hipError_t launch_split_dyn(const float* x, size_t npix, int C, int Cs, const unsigned* maxw, float* inv_scale, _Float16* hi,
                             _Float16* lo, int* overflow, unsigned* omax /* max |v| word or NULL */, hipStream_t stream);
 // backward of the same: g = d(loss)/d(BN output) written full-res [B,H,W,C]; part[blk][2][C] = (sum g, sum g*xhat)
+// (gx, nullable: two words, max |g| and max |xhat| as float bits)
 hipError_t launch_act_bwd(const ActParams& a, const float* dy0, const float* dy1, float* g, double* part, int nblk,
-                          hipStream_t stream);
+                          unsigned* gx, hipStream_t stream);
 // sums -> m12[2][C] = (mean g, mean g*xhat); dgamma = sum g*xhat, dbeta = sum g
 hipError_t launch_bn_bwd_finalize(const double* part, int nblk, size_t N, int C, float* dgamma, float* dbeta, float* m12,
                                   hipStream_t stream);
@@ -335,8 +339,11 @@ struct WgradParams {
 // BN input gradient g <- scale * (g - m1 - xhat*m2) (in place) and LeakyReLU backward + space-to-depth of the transposed
 // conv's output gradient; both track max |v| of what they write (bit pattern of a non-negative float, atomicMax on uint;
 // gmax may be NULL)
+// (hi != NULL: dz also as (hi, lo) planes scaled by the power of two the bound bw[0] * bw[1] * (2 + bw[2]) -- max |gamma rstd|,
+//  max |g|, max |xhat| -- asks for; *inv_scale receives the inverse factor)
 hipError_t launch_bn_bwd_apply_max(float* g, const float* z, const float* stat, const float* m12, size_t N, int C,
-                                   unsigned* gmax, hipStream_t stream);
+                                   unsigned* gmax, const unsigned* bw, float* inv_scale, _Float16* hi, _Float16* lo, int Cs,
+                                   int* overflow, hipStream_t stream);
 hipError_t launch_leaky_bwd_s2d_max(const float* d_us, const float* us, int B, int S, int C, float* gS, unsigned* gmax,
                                     hipStream_t stream);
 bool wgrad_setup(WgradParams* p, std::string* why);   // fills geometry, slab groups and slices from B,H,W,Cx,Cg,nslab,dy,dx,coff

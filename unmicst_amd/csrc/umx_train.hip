@@ -56,6 +56,8 @@ struct BnSite {            // one batch-normalised tensor
     float* stat = nullptr; // [4][C]
     float* m12 = nullptr;  // [2][C]
     unsigned* gmax = nullptr;   // max |dz| of the current step (float bits), for the split-precision weight gradient
+    unsigned* bw = nullptr;     // three words: max_c |gamma rstd| (bn_finalize), max |g| and max |xhat| (act_bwd) -- the bound on |dz|
+                                // that scales its (hi, lo) planes before the tensor exists (bn_bwd_apply)
 };
 
 struct Seg { std::string name; size_t off, n; float reg; };
@@ -526,7 +528,7 @@ int bn_forward_stats(umx_trainer* tr, BnSite& s, bool update, bool training = tr
     const int nblk = chan_blocks(N, s.C);
     T_HIP(tr, launch_chan_stats(s.z, N, s.C, tr->d_part, nblk, tr->stream));
     T_HIP(tr, launch_bn_finalize(tr->d_part, nblk, N, s.C, tr->d_w + s.gamma, tr->d_w + s.beta, tr->d_w + s.mean,
-                                 tr->d_w + s.var, update ? tr->o.bn_momentum : 1.0f, s.stat, tr->stream));
+                                 tr->d_w + s.var, update ? tr->o.bn_momentum : 1.0f, s.stat, s.bw, tr->stream));
     return UMX_OK;
 }
 
@@ -541,13 +543,17 @@ ActParams act_params(const umx_trainer* tr, const BnSite& s, int pool, int act, 
 }
 
 // dy (+dy1) -> gradient w.r.t. z in tr->DZ ; BN parameter gradients into the gradient vector
-int bn_backward(umx_trainer* tr, BnSite& s, const ActParams& a, const float* dy0, const float* dy1, float* dz) {
+// (planes / inv: where an input-gradient convolution on conv_f16x3 reads dz, its (hi, lo) planes are written in the same pass)
+int bn_backward(umx_trainer* tr, BnSite& s, const ActParams& a, const float* dy0, const float* dy1, float* dz,
+                const H16* planes = nullptr, float* inv = nullptr) {
     const size_t N = (size_t)tr->B * s.H * s.W;
     const size_t rows = a.pool ? N / 4 : N;
     const int nblk = chan_blocks(rows, s.C);
-    T_HIP(tr, launch_act_bwd(a, dy0, dy1, dz, tr->d_part, nblk, tr->stream));
+    T_HIP(tr, launch_act_bwd(a, dy0, dy1, dz, tr->d_part, nblk, planes ? s.bw + 1 : nullptr, tr->stream));
     T_HIP(tr, launch_bn_bwd_finalize(tr->d_part, nblk, N, s.C, tr->d_g + s.gamma, tr->d_g + s.beta, s.m12, tr->stream));
-    T_HIP(tr, launch_bn_bwd_apply_max(dz, s.z, s.stat, s.m12, N, s.C, s.gmax, tr->stream));
+    T_HIP(tr, launch_bn_bwd_apply_max(dz, s.z, s.stat, s.m12, N, s.C, s.gmax, s.bw, inv, planes ? planes->hi : nullptr,
+                                      planes ? planes->lo : nullptr, planes ? planes->Cs : 0,
+                                      reinterpret_cast<int*>(tr->d_maxw + tr->n_maxw), tr->stream));
     return UMX_OK;
 }
 
@@ -586,6 +592,10 @@ int forward_pass(umx_trainer* tr, const float* data, bool training, bool update)
         return run_conv(tr, tc, x0, x1, dst);
     };
     const size_t Bz = (size_t)tr->B;
+    int* const flagp = reinterpret_cast<int*>(tr->d_maxw + tr->n_maxw);
+    // (the (hi, lo) planes of an activation are written by the kernel that produces it)
+    static const H16 kNoPlanes;   // (the exact-fp32 route has no plane buffers: the vectors below are empty then)
+#define PL(h) (tr->hconv ? (h) : kNoPlanes).hi, (tr->hconv ? (h) : kNoPlanes).lo, (tr->hconv ? (h) : kNoPlanes).Cs, flagp
     tr->ds[0] = const_cast<float*>(data);
     if (training && !tr->hconv) T_HIP(tr, launch_absmax(data, Bz * tr->P * tr->P * tr->n[0], tr->dsmax[0], st));
     if (tr->hconv) T_TRY(to_h16(tr, data, Bz * tr->P * tr->P, tr->n[0], tr->h_ds[0], nullptr, nullptr, st, training ? tr->dsmax[0] : nullptr));
@@ -595,15 +605,13 @@ int forward_pass(umx_trainer* tr, const float* data, bool training, bool update)
         T_TRY(conv(tr->c_fwd_d[i], tr->ds[i], nullptr, tr->hconv ? &tr->h_ds[i] : nullptr, nullptr, s.z));
         T_TRY(bn_forward_stats(tr, s, update, training));
         T_HIP(tr, launch_act_fwd(act_params(tr, s, 1, ACT_LEAKY, rate(down_rate(tr, i)), LAYER_DOWN + i), tr->ds[i + 1],
-                                 training ? tr->dsmax[i + 1] : nullptr, st));
+                                 training ? tr->dsmax[i + 1] : nullptr, PL(tr->h_ds[i + 1]), st));
         S /= 2;
-        if (tr->hconv) T_TRY(to_h16(tr, tr->ds[i + 1], Bz * S * S, tr->n[i + 1], tr->h_ds[i + 1], nullptr, nullptr, st));
     }
     T_TRY(conv(tr->c_fwd_b, tr->ds[L], nullptr, tr->hconv ? &tr->h_ds[L] : nullptr, nullptr, tr->bn_b.z));
     T_TRY(bn_forward_stats(tr, tr->bn_b, update, training));
     T_HIP(tr, launch_act_fwd(act_params(tr, tr->bn_b, 0, ACT_LEAKY, rate(o.drop_bottom), LAYER_BOTTOM), tr->act_b,
-                             training ? tr->bmax : nullptr, st));
-    if (tr->hconv) T_TRY(to_h16(tr, tr->act_b, Bz * S * S, tr->n[L + 1], tr->h_b, nullptr, nullptr, st));
+                             training ? tr->bmax : nullptr, PL(tr->h_b), st));
     const float* cur = tr->act_b;
     const H16* hcur = tr->hconv ? &tr->h_b : nullptr;
     for (int idx = L - 1; idx >= 0; --idx) {
@@ -616,12 +624,17 @@ int forward_pass(umx_trainer* tr, const float* data, bool training, bool update)
                                     training ? tr->usmax[idx] : nullptr));
         T_TRY(conv(tr->c_fwd_u[idx], tr->ds[idx], tr->us[idx], tr->hconv ? &tr->h_ds[idx] : nullptr, tr->hconv ? &tr->h_us[idx] : nullptr, s.z));
         T_TRY(bn_forward_stats(tr, s, update, training));
-        T_HIP(tr, launch_act_fwd(act_params(tr, s, 0, ACT_LEAKY, rate(up_rate(tr, idx)), LAYER_UP + idx), tr->cv[idx],
-                                 training ? tr->cvmax[idx] : nullptr, st));
-        if (tr->hconv && idx >= 1) T_TRY(to_h16(tr, tr->cv[idx], Bz * S * S, tr->n[idx + 1], tr->h_cv[idx], nullptr, nullptr, st));
+        if (tr->hconv && idx >= 1) {
+            T_HIP(tr, launch_act_fwd(act_params(tr, s, 0, ACT_LEAKY, rate(up_rate(tr, idx)), LAYER_UP + idx), tr->cv[idx],
+                                     training ? tr->cvmax[idx] : nullptr, PL(tr->h_cv[idx]), st));
+        } else {
+            T_HIP(tr, launch_act_fwd(act_params(tr, s, 0, ACT_LEAKY, rate(up_rate(tr, idx)), LAYER_UP + idx), tr->cv[idx],
+                                     training ? tr->cvmax[idx] : nullptr, nullptr, nullptr, 0, flagp, st));
+        }
         cur = tr->cv[idx];
         hcur = tr->hconv && idx >= 1 ? &tr->h_cv[idx] : nullptr;
     }
+#undef PL
     BnSite& t = tr->bn_t;
     T_HIP(tr, launch_head_fwd(tr->cv[0], (size_t)tr->B * tr->P * tr->P, tr->n[1], tr->K, tr->d_w + tr->o_lt, t.z, st));
     T_TRY(bn_forward_stats(tr, t, update, training));
@@ -694,13 +707,6 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         used[sl] = true;
         return UMX_OK;
     };
-    // the gradient w.r.t. a conv output as (hi, lo) planes, scaled by the power of two its max |v| word asks for (conv_f16x3's
-    // input-gradient launches; the fp32 tensor stays: the weight gradients stage from it)
-    auto dz_planes = [&](int sl, const float* dzp, size_t npix, int C, const unsigned* gmax) -> int {
-        if (!tr->hconv) return UMX_OK;
-        tr->h_dz[sl].Cs = round_up(C, 8);
-        return to_h16(tr, dzp, npix, C, tr->h_dz[sl], gmax, tr->d_xinv + sl, st);
-    };
     auto dgrad = [&](TConv& tc, const float* x, const H16& h, const float* xinv, float* dst) -> int {
         if (tc.hidx >= 0) return run_hconv(tr, tc, h, nullptr, dst, xinv, st);
         return run_conv(tr, tc, x, nullptr, dst);
@@ -714,11 +720,11 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         float* gs = tr->GS2[slot];
         ActParams a = act_params(tr, s, 0, ACT_LEAKY, up_rate(tr, idx), LAYER_UP + idx);
         T_TRY(dz_begin(slot));
-        T_TRY(bn_backward(tr, s, a, tr->DA, nullptr, dz));
+        tr->h_dz[slot].Cs = round_up(Cup, 8);
+        T_TRY(bn_backward(tr, s, a, tr->DA, nullptr, dz, tr->hconv ? &tr->h_dz[slot] : nullptr, tr->d_xinv + slot));
         T_TRY(dz_ready(slot));
         T_TRY(run_wgrad(tr, tr->wg_u0[idx], tr->ds[idx], dz, Cskip + Cup, 0, tr->o_w2[idx], o.reg_up, SIZE_MAX, tr->dsmax[idx], s.gmax, ws));
         T_TRY(run_wgrad(tr, tr->wg_u1[idx], tr->us[idx], dz, Cskip + Cup, Cskip, tr->o_w2[idx], o.reg_up, SIZE_MAX, tr->usmax[idx], s.gmax, ws));
-        T_TRY(dz_planes(slot, dz, (size_t)B * S * S, Cup, s.gmax));
         T_TRY(dgrad(tr->c_dg_us[idx], dz, tr->h_dz[slot], tr->d_xinv + slot, tr->DB));
         if (idx >= 1) T_TRY(dgrad(tr->c_dg_skip[idx], dz, tr->h_dz[slot], tr->d_xinv + slot, tr->dskip[idx]));   // (side stream: 2 % slower)
         T_HIP(tr, launch_leaky_bwd_s2d_max(tr->DB, tr->us[idx], B, S / 2, Cup, gs, tr->smax[idx], st));
@@ -741,11 +747,11 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         float* dz = tr->DZ2[slot];
         ActParams a = act_params(tr, tr->bn_b, 0, ACT_LEAKY, o.drop_bottom, LAYER_BOTTOM);
         T_TRY(dz_begin(slot));
-        T_TRY(bn_backward(tr, tr->bn_b, a, tr->DA, nullptr, dz));
+        tr->h_dz[slot].Cs = round_up(tr->n[L + 1], 8);
+        T_TRY(bn_backward(tr, tr->bn_b, a, tr->DA, nullptr, dz, tr->hconv ? &tr->h_dz[slot] : nullptr, tr->d_xinv + slot));
         T_TRY(dz_ready(slot));
         T_TRY(run_wgrad(tr, tr->wg_b, tr->ds[L], dz, tr->n[L], 0, tr->o_lb, o.reg_bottom, SIZE_MAX, tr->dsmax[L], tr->bn_b.gmax, ws));
         T_TRY(side_done(slot));
-        T_TRY(dz_planes(slot, dz, (size_t)B * S * S, tr->n[L + 1], tr->bn_b.gmax));
         T_TRY(dgrad(tr->c_dg_b, dz, tr->h_dz[slot], tr->d_xinv + slot, tr->DB));
         slot ^= 1;
     }
@@ -755,16 +761,14 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         ActParams a = act_params(tr, s, 1, ACT_LEAKY, down_rate(tr, i), LAYER_DOWN + i);
         const float* dy1 = (i + 1 <= L - 1) ? tr->dskip[i + 1] : nullptr;
         T_TRY(dz_begin(slot));
-        T_TRY(bn_backward(tr, s, a, tr->DB, dy1, dz));
+        tr->h_dz[slot].Cs = round_up(tr->n[i + 1], 8);
+        T_TRY(bn_backward(tr, s, a, tr->DB, dy1, dz, tr->hconv && i >= 1 ? &tr->h_dz[slot] : nullptr, tr->d_xinv + slot));
         T_TRY(dz_ready(slot));
         // c00 + shortcut = conv(x, W1 + Wshort): both filters receive the same data gradient (UnMicst1-5.py:102-114)
         T_TRY(run_wgrad(tr, tr->wg_d[i], tr->ds[i], dz, tr->n[i], 0, tr->o_ws[i], o.reg_down, tr->o_w1[i], tr->dsmax[i], s.gmax, ws));
         T_TRY(side_done(slot));
         S *= 2;
-        if (i >= 1) {
-            T_TRY(dz_planes(slot, dz, (size_t)B * S * S, tr->n[i + 1], s.gmax));
-            T_TRY(dgrad(tr->c_dg_d[i], dz, tr->h_dz[slot], tr->d_xinv + slot, tr->DB));
-        }
+        if (i >= 1) T_TRY(dgrad(tr->c_dg_d[i], dz, tr->h_dz[slot], tr->d_xinv + slot, tr->DB));
         slot ^= 1;
     }
     if (tr->overlap) {   // join: the optimiser (and the caller) see every gradient
@@ -899,7 +903,7 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
     T_TRY(talloc(tr, &tr->d_part2, tr->part_doubles));
     T_TRY(tzero(tr, &tr->d_loss, 2));
     {   // max-|gradient| words: one per batch-normalised tensor and per up layer, + the range flag
-        tr->n_maxw = 6 * L + 4;
+        tr->n_maxw = 6 * L + 4 + 3 * (2 * L + 2);
         T_TRY(tzero(tr, &tr->d_maxw, (size_t)tr->n_maxw + 1));
         int k = 0;
         for (int i = 0; i < L; ++i) tr->bn_d[i].gmax = tr->d_maxw + k++;
@@ -913,6 +917,10 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
         for (int i = 0; i < L; ++i) tr->usmax[i] = tr->d_maxw + k++;
         for (int i = 0; i < L; ++i) tr->cvmax[i] = tr->d_maxw + k++;
         tr->bmax = tr->d_maxw + k++;
+        for (int i = 0; i < L; ++i) { tr->bn_d[i].bw = tr->d_maxw + k; k += 3; }
+        for (int i = 0; i < L; ++i) { tr->bn_u[i].bw = tr->d_maxw + k; k += 3; }
+        tr->bn_b.bw = tr->d_maxw + k; k += 3;
+        tr->bn_t.bw = tr->d_maxw + k; k += 3;
     }
 
     // ---- split-precision route of the forward / input-gradient convolutions: planes of every tensor they read

@@ -118,7 +118,7 @@ __device__ __forceinline__ void block64_sum2(double& a, double& b, double (*sm)[
 __global__ void __launch_bounds__(64) bn_finalize_kernel(const double* __restrict__ part, int nblk, double N, int C,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* mov_mean, float* mov_var, float momentum,
-                                                         float* __restrict__ stat) {
+                                                         float* __restrict__ stat, unsigned* smax) {
     __shared__ double sm[2][64];
     const int c = blockIdx.x;
     double s = 0.0, q = 0.0;
@@ -137,6 +137,7 @@ __global__ void __launch_bounds__(64) bn_finalize_kernel(const double* __restric
     stat[C + c] = (float)rstd;
     stat[2 * C + c] = (float)scale;
     stat[3 * C + c] = (float)((double)beta[c] - mean * scale);
+    if (smax) atomicMax(smax, __float_as_uint(fabsf((float)scale)));   // max_c |gamma * rstd|: bounds the BN input gradient (bn_bwd_apply)
     const double mom = (double)momentum;
     const double unbiased = N > 1.0 ? var * (N / (N - 1.0)) : var;
     mov_mean[c] = (float)((double)mov_mean[c] * mom + mean * (1.0 - mom));
@@ -144,9 +145,9 @@ __global__ void __launch_bounds__(64) bn_finalize_kernel(const double* __restric
 }
 
 hipError_t launch_bn_finalize(const double* part, int nblk, size_t N, int C, const float* gamma, const float* beta,
-                              float* mov_mean, float* mov_var, float momentum, float* stat, hipStream_t stream) {
+                              float* mov_mean, float* mov_var, float momentum, float* stat, unsigned* smax, hipStream_t stream) {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)C), dim3(64), 0, stream, part, nblk, (double)N, C, gamma, beta,
-                       mov_mean, mov_var, momentum, stat);
+                       mov_mean, mov_var, momentum, stat, smax);
     return hipGetLastError();
 }
 
@@ -215,8 +216,10 @@ __device__ __forceinline__ void block_absmax_to(unsigned* dst, float v) {
 
 // (grid-stride; the block's max |output| goes to the tensor's max word with at most one atomic)
 __global__ void __launch_bounds__(256) act_fwd_kernel(const ActParams a, float* __restrict__ out, size_t nout,
-                                                      unsigned* omax) {
+                                                      unsigned* omax, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int Cs,
+                                                      int* __restrict__ overflow) {
     const int C = a.C;
+    bool bad = false;   // (hi != NULL: the output also as the (hi, lo) planes the next convolution reads, unscaled)
     const float ks = 1.0f / (1.0f - a.drop_rate);
     const int OW = a.W >> 1, OH = a.H >> 1;
     float mx = 0.f;
@@ -243,14 +246,23 @@ __global__ void __launch_bounds__(256) act_fwd_kernel(const ActParams a, float* 
         }
         out[e] = y;
         mx = fmaxf(mx, fabsf(y));
+        if (hi) {
+            const size_t at = (e / C) * Cs + c;
+            bad = bad || !(fabsf(y) < 60000.f);
+            const _Float16 h = (_Float16)y;
+            hi[at] = h;
+            lo[at] = (_Float16)(y - (float)h);
+        }
     }
+    if (bad) atomicOr(overflow, 1);
     if (omax) block_absmax_to(omax, mx);
 }
 
-hipError_t launch_act_fwd(const ActParams& a, float* out, unsigned* omax, hipStream_t stream) {
+hipError_t launch_act_fwd(const ActParams& a, float* out, unsigned* omax, _Float16* hi, _Float16* lo, int Cs, int* overflow,
+                          hipStream_t stream) {
     const size_t nout = (size_t)a.B * (a.pool ? a.H / 2 : a.H) * (a.pool ? a.W / 2 : a.W) * a.C;
     const unsigned blocks = (unsigned)std::min<size_t>(2048, (nout + 255) / 256);
-    hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, a, out, nout, omax);
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, a, out, nout, omax, hi, lo, Cs, overflow);
     return hipGetLastError();
 }
 
@@ -371,8 +383,10 @@ hipError_t launch_split_dyn(const float* x, size_t npix, int C, int Cs, const un
 
 __global__ void __launch_bounds__(256) act_bwd_kernel(const ActParams a, const float* __restrict__ dy0,
                                                       const float* __restrict__ dy1, float* __restrict__ g, size_t Nrows,
-                                                      int Cb, int k, double* __restrict__ part) {
+                                                      int Cb, int k, double* __restrict__ part, unsigned* gx) {
     __shared__ double sm[2][256];
+    __shared__ unsigned smx[2][256];
+    float mg = 0.f, mxh = 0.f;   // max |g| and max |xhat| seen by this thread: with max |gamma rstd| they bound |dz| (bn_bwd_apply)
     const int tid = threadIdx.x;
     const int r = tid / Cb, cl = tid - r * Cb;
     const int C = a.C;
@@ -393,8 +407,11 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(const ActParams a, const f
                 const float v = zz * sc + sh;
                 const float gg = d * drop_mul(a.drop_key, e, a.drop_rate, ks) * dact_of(v, a.act);
                 g[e] = gg;
+                const float xh = (zz - mean) * rstd;
                 s1 += (double)gg;
-                s2 += (double)gg * (double)((zz - mean) * rstd);
+                s2 += (double)gg * (double)xh;
+                mg = fmaxf(mg, fabsf(gg));
+                mxh = fmaxf(mxh, fabsf(xh));
             } else {
                 size_t q = row;
                 const int ox = (int)(q % OW); q /= OW;
@@ -417,9 +434,12 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(const ActParams a, const f
                 for (int j = 0; j < 4; ++j) {
                     const float gg = j == arg ? d * dm[j] * dact_of(vv[j], a.act) : 0.f;
                     g[idx[j]] = gg;
+                    const float xh = (zz[j] - mean) * rstd;
+                    mxh = fmaxf(mxh, fabsf(xh));
                     if (j == arg) {
                         s1 += (double)gg;
-                        s2 += (double)gg * (double)((zz[j] - mean) * rstd);
+                        s2 += (double)gg * (double)xh;
+                        mg = fmaxf(mg, fabsf(gg));
                     }
                 }
             }
@@ -427,20 +447,27 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(const ActParams a, const f
     }
     sm[0][tid] = s1;
     sm[1][tid] = s2;
+    smx[0][tid] = __float_as_uint(mg);
+    smx[1][tid] = __float_as_uint(mxh);
     __syncthreads();
     if (r == 0 && c < C) {
         for (int j = 1; j < k; ++j) { s1 += sm[0][j * Cb + cl]; s2 += sm[1][j * Cb + cl]; }
         part[((size_t)blockIdx.x * 2 + 0) * C + c] = s1;
         part[((size_t)blockIdx.x * 2 + 1) * C + c] = s2;
     }
+    if (gx && tid < 2) {   // (integer max of non-negative float bits: order-independent)
+        unsigned m = 0u;
+        for (int j = 0; j < (int)blockDim.x; ++j) m = max(m, smx[tid][j]);
+        if (m > *reinterpret_cast<volatile unsigned*>(gx + tid)) atomicMax(gx + tid, m);
+    }
 }
 
 hipError_t launch_act_bwd(const ActParams& a, const float* dy0, const float* dy1, float* g, double* part, int nblk,
-                          hipStream_t stream) {
+                          unsigned* gx, hipStream_t stream) {
     const ChanLayout l = chan_layout(a.C);
     const size_t rows = (size_t)a.B * (a.pool ? a.H / 2 : a.H) * (a.pool ? a.W / 2 : a.W);
     hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)nblk, (unsigned)l.cblocks), dim3((unsigned)l.threads), 0, stream, a,
-                       dy0, dy1, g, rows, l.Cb, l.k, part);
+                       dy0, dy1, g, rows, l.Cb, l.k, part, gx);
     return hipGetLastError();
 }
 
@@ -483,10 +510,96 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(float* __restrict__ g
     if (gmax) block_absmax_to(gmax, mx);
 }
 
+// The same with the (hi, lo) planes conv_f16x3's input-gradient launches read written in the same pass (round 4; no second trip
+// through the tensor).  Their power-of-two scale has to be known before the first element: |dz| <= max_c|gamma rstd| * (|g| +
+// |mean g| + |xhat| |mean g xhat|) <= smax * gmax * (2 + xhmax)  (|mean g| <= gmax, |mean g xhat| <= gmax * E|xhat| <= gmax), the
+// three maxima tracked by bn_finalize / act_bwd -- a true bound, 2^2 .. 2^3 above the real maximum, placed at 2^14.
+template <bool VEC>
+__global__ void __launch_bounds__(256) bn_bwd_apply_planes_kernel(float* __restrict__ g, const float* __restrict__ z,
+                                                                  const float* __restrict__ stat, const float* __restrict__ m12,
+                                                                  unsigned n, int C, int Cs, unsigned* gmax, const unsigned* __restrict__ bw,
+                                                                  float* __restrict__ inv_scale, _Float16* __restrict__ hi,
+                                                                  _Float16* __restrict__ lo, int* __restrict__ overflow) {
+    float scale = 1.f;
+    {
+        const float bound = __uint_as_float(bw[0]) * __uint_as_float(bw[1]) * (2.f + __uint_as_float(bw[2]));
+        const unsigned bb = __float_as_uint(bound);
+        const int e = (int)((bb >> 23) & 0xFFu);
+        if (bb != 0u && e > 0 && e < 255) {
+            const int sh = max(-100, min(100, 14 - (e - 127)));   // bound -> [2^14, 2^15)
+            scale = __uint_as_float((unsigned)(127 + sh) << 23);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) *inv_scale = 1.f / scale;
+    }
+    float mx = 0.f;
+    bool bad = false;
+    if constexpr (VEC) {   // C % 4 == 0: four channels of one pixel per thread
+        const unsigned n4 = n / 4;
+        for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+            const unsigned e = i * 4, px = e / (unsigned)C, c = e - px * (unsigned)C;
+            const float4 gv = reinterpret_cast<const float4*>(g)[i], zv = reinterpret_cast<const float4*>(z)[i];
+            const float4 mean = *reinterpret_cast<const float4*>(stat + c), rstd = *reinterpret_cast<const float4*>(stat + C + c);
+            const float4 sc = *reinterpret_cast<const float4*>(stat + 2 * C + c);
+            const float4 m1 = *reinterpret_cast<const float4*>(m12 + c), m2 = *reinterpret_cast<const float4*>(m12 + C + c);
+            float v[4];
+            v[0] = sc.x * (gv.x - m1.x - (zv.x - mean.x) * rstd.x * m2.x);
+            v[1] = sc.y * (gv.y - m1.y - (zv.y - mean.y) * rstd.y * m2.y);
+            v[2] = sc.z * (gv.z - m1.z - (zv.z - mean.z) * rstd.z * m2.z);
+            v[3] = sc.w * (gv.w - m1.w - (zv.w - mean.w) * rstd.w * m2.w);
+            reinterpret_cast<float4*>(g)[i] = make_float4(v[0], v[1], v[2], v[3]);
+            union { _Float16 h[4]; uint2 u; } a, b;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                mx = fmaxf(mx, fabsf(v[k]));
+                const float f = v[k] * scale;
+                bad = bad || !(fabsf(f) < 60000.f);
+                a.h[k] = (_Float16)f;
+                b.h[k] = (_Float16)(f - (float)a.h[k]);
+            }
+            const size_t at = (size_t)px * Cs + c;
+            *reinterpret_cast<uint2*>(hi + at) = a.u;
+            *reinterpret_cast<uint2*>(lo + at) = b.u;
+            if (c + 4 == (unsigned)C && Cs > C) {   // the pad channels of the pixel's last octet (the slot is shared between layers)
+                *reinterpret_cast<uint2*>(hi + at + 4) = make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(lo + at + 4) = make_uint2(0u, 0u);
+            }
+        }
+    } else {
+        for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+            const unsigned px = e / (unsigned)C, c = e - px * (unsigned)C;
+            const float xh = (z[e] - stat[c]) * stat[C + c];
+            const float v = stat[2 * C + c] * (g[e] - m12[c] - xh * m12[C + c]);
+            g[e] = v;
+            mx = fmaxf(mx, fabsf(v));
+            const float f = v * scale;
+            bad = bad || !(fabsf(f) < 60000.f);
+            const _Float16 h = (_Float16)f;
+            hi[(size_t)px * Cs + c] = h;
+            lo[(size_t)px * Cs + c] = (_Float16)(f - (float)h);
+            if (c + 1 == (unsigned)C)
+                for (int k = C; k < Cs; ++k) { hi[(size_t)px * Cs + k] = (_Float16)0.f; lo[(size_t)px * Cs + k] = (_Float16)0.f; }
+        }
+    }
+    if (bad) atomicOr(overflow, 1);
+    if (gmax) block_absmax_to(gmax, mx);
+}
+
+// (hi == NULL: the fp32 tensor only -- the top layer, the first down layer, the exact-fp32 route)
 hipError_t launch_bn_bwd_apply_max(float* g, const float* z, const float* stat, const float* m12, size_t N, int C,
-                                   unsigned* gmax, hipStream_t stream) {
+                                   unsigned* gmax, const unsigned* bw, float* inv_scale, _Float16* hi, _Float16* lo, int Cs,
+                                   int* overflow, hipStream_t stream) {
     const size_t n = N * C;
     const unsigned blocks = (unsigned)std::min<size_t>(1024, (n + 255) / 256);
+    if (hi && n < 0xFFFFFFF0ull) {
+        const unsigned bv = (unsigned)std::min<size_t>(2048, (n / 4 + 255) / 256 + 1);
+        if (C % 4 == 0 && Cs % 4 == 0)
+            hipLaunchKernelGGL(bn_bwd_apply_planes_kernel<true>, dim3(bv), dim3(256), 0, stream, g, z, stat, m12, (unsigned)n, C, Cs, gmax,
+                               bw, inv_scale, hi, lo, overflow);
+        else
+            hipLaunchKernelGGL(bn_bwd_apply_planes_kernel<false>, dim3(blocks ? blocks : 1), dim3(256), 0, stream, g, z, stat, m12,
+                               (unsigned)n, C, Cs, gmax, bw, inv_scale, hi, lo, overflow);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, g, z, stat, m12, n, C, gmax);
     return hipGetLastError();
 }
