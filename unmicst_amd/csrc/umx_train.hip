@@ -92,6 +92,8 @@ struct umx_trainer {
     float* DZ2[2] = {nullptr, nullptr};   // gradient w.r.t. a conv output, double-buffered: the weight gradients of layer l
     float* GS2[2] = {nullptr, nullptr};   // run on the side stream while the main stream moves on to layer l+1
     hipStream_t side = nullptr;
+    hipStream_t side2 = nullptr;          // a second side stream: the dz / gS slots alternate between the two (UMX_TRAIN_ONE_SIDE=1: one)
+    hipEvent_t ev_join2 = nullptr;
     hipEvent_t ev_dz[2] = {nullptr, nullptr}, ev_gs[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr}, ev_join = nullptr;
     bool overlap = true;
     double* d_part = nullptr;  size_t part_doubles = 0;
@@ -102,6 +104,7 @@ struct umx_trainer {
     std::vector<unsigned*> dsmax, usmax, cvmax;   // max |activation| of ds[i], us[idx], cv[idx]
     unsigned* bmax = nullptr;           // ... of the bottom layer's output
     float* d_ws = nullptr;  size_t ws_floats = 0;
+    float* d_ws2 = nullptr;             // ... of the second side stream
     float* d_split = nullptr;  size_t split_floats = 0;   // partial outputs of K-split convolutions
     float* d_split2 = nullptr;                            // ... of those enqueued on the side stream
     // forward / input-gradient convolutions on conv_f16x3 (UMX_TRAIN_CONV_F32=1: the exact-fp32 kernels of rounds 1-3)
@@ -562,7 +565,7 @@ int run_wgrad(umx_trainer* tr, WgradParams& w, const float* X, const float* G, i
               hipStream_t stream) {
     w.X = X;
     w.G = G;
-    w.ws = tr->d_ws;
+    w.ws = stream == tr->side2 ? tr->d_ws2 : tr->d_ws;   // (each side stream has its own slice workspace)
     w.xmax = xmax;
     w.gmax = gmax;
     w.overflow = reinterpret_cast<int*>(tr->d_maxw + tr->n_maxw);
@@ -688,7 +691,10 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
     // The weight gradients hang off the critical path (gradient w.r.t. conv output -> input gradient -> next layer):
     // they run on a side stream against double-buffered dz / gS while the main stream continues.  Ordering is by events
     // only; every kernel still has a fixed summation order, so the step stays bit-reproducible.
-    hipStream_t ws = tr->overlap ? tr->side : st;
+    // (two side streams, one per dz / gS slot: consecutive layers' weight gradients -- small grids that leave most CUs idle at a batch
+    // of 8 -- run next to each other as well as next to the main stream)
+    hipStream_t wss[2] = {tr->overlap ? tr->side : st, tr->overlap ? (tr->side2 ? tr->side2 : tr->side) : st};
+#define ws wss[slot]
     int slot = 0;
     bool used[2] = {false, false};
     auto dz_begin = [&](int sl) -> int {      // main: the slot's previous consumers on the side stream are done
@@ -698,12 +704,12 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
     auto dz_ready = [&](int sl) -> int {      // main has written DZ2[sl]; the side stream may read it
         if (tr->overlap) {
             T_HIP(tr, hipEventRecord(tr->ev_dz[sl], st));
-            T_HIP(tr, hipStreamWaitEvent(ws, tr->ev_dz[sl], 0));
+            T_HIP(tr, hipStreamWaitEvent(wss[sl], tr->ev_dz[sl], 0));
         }
         return UMX_OK;
     };
     auto side_done = [&](int sl) -> int {
-        if (tr->overlap) T_HIP(tr, hipEventRecord(tr->ev_side[sl], ws));
+        if (tr->overlap) T_HIP(tr, hipEventRecord(tr->ev_side[sl], wss[sl]));
         used[sl] = true;
         return UMX_OK;
     };
@@ -771,9 +777,14 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         if (i >= 1) T_TRY(dgrad(tr->c_dg_d[i], dz, tr->h_dz[slot], tr->d_xinv + slot, tr->DB));
         slot ^= 1;
     }
+#undef ws
     if (tr->overlap) {   // join: the optimiser (and the caller) see every gradient
-        T_HIP(tr, hipEventRecord(tr->ev_join, ws));
+        T_HIP(tr, hipEventRecord(tr->ev_join, wss[0]));
         T_HIP(tr, hipStreamWaitEvent(st, tr->ev_join, 0));
+        if (wss[1] != wss[0]) {
+            T_HIP(tr, hipEventRecord(tr->ev_join2, wss[1]));
+            T_HIP(tr, hipStreamWaitEvent(st, tr->ev_join2, 0));
+        }
     }
     if (tr->prof) T_HIP(tr, hipEventRecord(tr->ev[2], st));
 
@@ -1072,6 +1083,7 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
     mac_total += 3.0 * P * P * n[1] * K;
     tr->flops_per_image = 2.0 * mac_total;
     T_TRY(talloc(tr, &tr->d_ws, tr->ws_floats));
+    T_TRY(talloc(tr, &tr->d_ws2, tr->ws_floats));
     T_TRY(talloc(tr, &tr->d_split, tr->split_floats));
     T_TRY(talloc(tr, &tr->d_split2, tr->split_floats));
     {
@@ -1171,8 +1183,10 @@ int umx_trainer_create(const umx_hparams* hp, const float* weight_blob, size_t b
     if (rc == UMX_OK) {
         tr->overlap = !getenv("UMX_TRAIN_NO_OVERLAP");
         if (hipStreamCreateWithFlags(&tr->side, hipStreamNonBlocking) != hipSuccess) rc = tfail(tr, UMX_ERR_HIP, "hipStreamCreate failed");
+        if (!getenv("UMX_TRAIN_ONE_SIDE") && hipStreamCreateWithFlags(&tr->side2, hipStreamNonBlocking) != hipSuccess)
+            rc = tfail(tr, UMX_ERR_HIP, "hipStreamCreate failed");
         hipEvent_t* evs[] = {&tr->ev_dz[0], &tr->ev_dz[1], &tr->ev_gs[0], &tr->ev_gs[1], &tr->ev_side[0], &tr->ev_side[1], &tr->ev_join,
-                             &tr->ev_begin, &tr->ev_packed};
+                             &tr->ev_begin, &tr->ev_packed, &tr->ev_join2};
         for (hipEvent_t* e : evs)
             if (rc == UMX_OK && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess)
                 rc = tfail(tr, UMX_ERR_HIP, "hipEventCreate failed");
@@ -1198,8 +1212,9 @@ void umx_trainer_destroy(umx_trainer* tr) {
     for (int i = 0; i < 4; ++i)
         if (tr->ev[i]) (void)hipEventDestroy(tr->ev[i]);
     if (tr->side) { (void)hipStreamSynchronize(tr->side); (void)hipStreamDestroy(tr->side); }
+    if (tr->side2) { (void)hipStreamSynchronize(tr->side2); (void)hipStreamDestroy(tr->side2); }
     for (hipEvent_t e : {tr->ev_dz[0], tr->ev_dz[1], tr->ev_gs[0], tr->ev_gs[1], tr->ev_side[0], tr->ev_side[1], tr->ev_join, tr->ev_begin,
-                         tr->ev_packed})
+                         tr->ev_packed, tr->ev_join2})
         if (e) (void)hipEventDestroy(e);
     if (tr->stream) (void)hipStreamDestroy(tr->stream);
     delete tr;
