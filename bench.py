@@ -362,11 +362,15 @@ def main():
             flag = torch.tensor([okv], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
-                with torch.cuda.stream(work):
-                    a = native_call(band_f64).clone()
-                    b = torch_call(band_f64)
-                    same = torch.tensor([1 if torch.equal(a, b) else 0], dtype=torch.int32, device=dev)
-                work.synchronize()
+                try:
+                    with torch.cuda.stream(work):
+                        a = native_call(band_f64).clone()
+                        b = torch_call(band_f64)
+                        same = torch.tensor([1 if torch.equal(a, b) else 0], dtype=torch.int32, device=dev)
+                    work.synchronize()
+                except Exception as e:   # noqa: BLE001  (an error the library reports, not a hang: the world still agrees below)
+                    same = torch.tensor([0], dtype=torch.int32, device=dev)
+                    shard_path["note"] = "native first slide failed on rank %d: %s" % (rank, e)
                 dist.all_reduce(same, op=dist.ReduceOp.MIN)
                 if int(same.item()) == 1:
                     sharded_call = native_call
@@ -374,7 +378,7 @@ def main():
                                   "note": None}
                 else:
                     shard_path["native_checked_against_torch_path"] = False
-                    shard_path["note"] = "the native path's first slide differed from sharding.py's on some rank: torch path timed"
+                    shard_path["note"] = shard_path["note"] or "the native path's first slide differed from sharding.py's on some rank: torch path timed"
             else:
                 shard_path["note"] = note or "native init failed on another rank: torch path timed"
         y0, y1 = sharding.owned_rows(pa, pb, npr, sub, margin, H)
