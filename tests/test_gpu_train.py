@@ -272,6 +272,23 @@ def test_train_loop_end_to_end(tmp_path):
     assert np.allclose(p.sum(-1), 1.0, atol=1e-5)
 
 
+def test_weight_scale_refresh_does_not_change_a_result(monkeypatch):
+    """UMX_TRAIN_WSCALE_EVERY: the power-of-two scale of each layer's repacked weights is re-derived from the parameters every N steps
+    (default 256: a long run cannot grow a filter out of the 32 x headroom the scale of step 0 left it).  Refreshing before every
+    step must give bit-identical losses to never refreshing: a scale is a power of two and is undone exactly in the epilogue."""
+    hp = helpers.small_hps()["v2_wide"]
+    blob = model.random_blob(hp, seed=5)
+    data, labels, weights = _batch(hp, 2, 9)
+    losses = []
+    for every in ("0", "1"):
+        monkeypatch.setenv("UMX_TRAIN_WSCALE_EVERY", every)
+        tr = trainer.Trainer(hp, blob, trainer.duo_options(), batch=2)
+        losses.append([tr.step(data, labels, weights)[0] for _ in range(4)])
+        tr.close()
+        monkeypatch.delenv("UMX_TRAIN_WSCALE_EVERY")
+    assert losses[0] == losses[1], losses
+
+
 def test_the_two_convolution_routes_agree_step_for_step(monkeypatch):
     """Three Adam steps of the duo regime (dropout on) on the split-precision route and on the exact-fp32 route: same losses to
     1e-6 relative, same parameters to 1e-5 of each tensor's scale (2^-22 per product against fp32 rounding -- and the routes must take

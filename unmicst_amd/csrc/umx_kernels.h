@@ -277,6 +277,7 @@ struct RepackDesc {
     float scale;            // 2^s applied to the weights (the launch's HConvParams::dyn[0] points at 2^-s)
     uint4* slab;            // the phase list's weight slab (headers stay as the planner wrote them)
     int bwd;                // (host bookkeeping) as PackDesc::bwd
+    int owner;              // (host bookkeeping) the trainer's convolution this slab belongs to: whose scale `scale` follows
 };
 hipError_t launch_repack_f16x3(const RepackDesc* descs_dev, int ndesc, int max_n, int* overflow, hipStream_t stream);
 hipError_t launch_split_dyn(const float* x, size_t npix, int C, int Cs, const unsigned* maxw, float* inv_scale, _Float16* hi,

@@ -36,6 +36,9 @@ struct TConv {                       // one convolution of the step: device-pack
     double mac = 0.0;                // algorithmic multiply-accumulates per image
     int hidx = -1;                   // index into umx_trainer::hls (split-precision plan), -1: fp32 kernel
     float* winv = nullptr;           // device scalar 2^-s: undoes the scale of the repacked weights in the epilogue
+    int wsh = 0;                     // s
+    struct WSrc { size_t off, off2, cnt; };
+    std::vector<WSrc> wsrc;          // master tensor(s) each operand group reads: where the scale is re-derived from (refresh_wscales)
 };
 
 struct H16 {                         // (hi, lo) binary16 NHWC planes of one tensor, channels padded to Cs (what conv_f16x3 reads)
@@ -112,6 +115,9 @@ struct umx_trainer {
     umx_ctx* pctx = nullptr;            // owner of the planner's device allocations (stage tables, weight slabs, constants)
     const float* h_blob = nullptr;      // (during build) the initial parameters on the host: weight scales
     std::vector<umx::Launch> hls;
+    std::vector<TConv*> hconvs;         // the convolutions that took the split-precision route, index = RepackDesc::owner
+    int wscale_every = 256;             // steps between two refreshes of the weight scales (UMX_TRAIN_WSCALE_EVERY)
+    std::vector<float> h_params;        // (refresh) host copy of the parameters
     std::vector<RepackDesc> rdescs;
     RepackDesc* d_rdescs = nullptr;
     int max_refs = 0;
@@ -207,6 +213,26 @@ struct GroupSpec {
     TapSet taps[4];
 };
 
+// largest |w| a convolution's packed operand can hold: the master tensor(s) each group reads (a summed pair: the sum of the maxima)
+double operand_wmax(const TConv& tc, const float* params) {
+    double wmax = 0.0;
+    for (const TConv::WSrc& w : tc.wsrc) {
+        double m1 = 0.0, m2 = 0.0;
+        for (size_t i = 0; i < w.cnt; ++i) m1 = std::max(m1, (double)std::fabs(params[w.off + i]));
+        if (w.off2 != SIZE_MAX)
+            for (size_t i = 0; i < w.cnt; ++i) m2 = std::max(m2, (double)std::fabs(params[w.off2 + i]));
+        wmax = std::max(wmax, m1 + m2);
+    }
+    return wmax;
+}
+// s such that wmax * 2^s is in [2^10, 2^11): 32 x headroom below binary16's largest finite value for the weights to grow into
+int wscale_shift(double wmax) {
+    if (!(wmax > 0.0) || !std::isfinite(wmax)) return 0;
+    int e;
+    std::frexp(wmax, &e);              // wmax = m * 2^e, m in [0.5, 1)
+    return std::max(-24, std::min(40, 11 - e));
+}
+
 // The same convolution as a split-precision plan (conv_f16x3, fp32 output): stage tables and the LDS-image layout of the weights
 // come from plan_f16 once; the values are filled every step by repack_f16x3_kernel from the fp32 operands this TConv already
 // rebuilds on the device.  A shape the planner refuses stays on the fp32 kernel.
@@ -230,23 +256,16 @@ int setup_hconv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int 
         for (int ph = 0; ph < nphase; ++ph)
             for (int m : gs[g].taps[ph].m) ntap_master = std::max(ntap_master, m + 1);
         const size_t cnt = (size_t)ntap_master * gs[g].d2 * gs[g].d3;
-        double m1 = 0.0, m2 = 0.0;
-        for (size_t i = 0; i < cnt; ++i) m1 = std::max(m1, (double)std::fabs(tr->h_blob[gs[g].w_off + i]));
-        if (gs[g].w2_off != SIZE_MAX)
-            for (size_t i = 0; i < cnt; ++i) m2 = std::max(m2, (double)std::fabs(tr->h_blob[gs[g].w2_off + i]));
-        wmax = std::max(wmax, m1 + m2);
+        tc.wsrc.push_back({gs[g].w_off, gs[g].w2_off, cnt});
     }
+    wmax = operand_wmax(tc, tr->h_blob);
     std::string why;
     if (!umx::conv_geometry(L, &why) || umx::plan_f16(tr->pctx, L, 0, true, nullptr, &why) != UMX_OK) {
         if (getenv("UMX_DEBUG_PLAN")) fprintf(stderr, "[umx train] %s stays on the fp32 kernel: %s\n", what, why.c_str());
         return UMX_OK;
     }
-    int sh = 0;
-    if (wmax > 0.0 && std::isfinite(wmax)) {
-        int e;
-        std::frexp(wmax, &e);              // wmax = m * 2^e, m in [0.5, 1)
-        sh = std::max(-24, std::min(40, 11 - e));
-    }
+    const int sh = wscale_shift(wmax);
+    tc.wsh = sh;
     const float inv = std::ldexp(1.f, -sh);
     T_TRY(talloc(tr, &tc.winv, 1));
     T_HIP(tr, hipMemcpy(tc.winv, &inv, sizeof inv, hipMemcpyHostToDevice));
@@ -266,6 +285,7 @@ int setup_hconv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int 
         rd.scale = std::ldexp(1.f, sh);
         rd.slab = const_cast<uint4*>(L.hcp.ph[ph].w);
         rd.bwd = tr->cur_bwd ? 1 : 0;
+        rd.owner = (int)tr->hconvs.size();
         tr->rdescs.push_back(rd);
         tr->max_refs = std::max(tr->max_refs, rd.n);
         std::vector<umx::HWRef>().swap(L.wrefs[ph]);
@@ -301,6 +321,7 @@ int setup_hconv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int 
     std::vector<HStage>().swap(L.stages_host);
     tc.hidx = (int)tr->hls.size();
     tr->hls.push_back(std::move(L));
+    tr->hconvs.push_back(&tc);
     return UMX_OK;
 }
 
@@ -452,6 +473,7 @@ int run_hconv(umx_trainer* tr, TConv& tc, const H16& s0, const H16* s1, float* d
 }
 
 int pack_all(umx_trainer* tr, hipStream_t st, int part);
+int refresh_wscales(umx_trainer* tr);
 
 int run_conv(umx_trainer* tr, TConv& tc, const float* src0, const float* src1, float* dst, bool on_side = false) {
     ConvParams p = tc.cp;
@@ -649,6 +671,7 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
     hipStream_t st = tr->stream;
     const umx_train_options& o = tr->o;
     const size_t Npix = (size_t)B * P * P;
+    if (update && tr->step > 0 && tr->wscale_every > 0 && tr->step % tr->wscale_every == 0) T_TRY(refresh_wscales(tr));
     if (tr->prof) T_HIP(tr, hipEventRecord(tr->ev[0], st));
     T_HIP(tr, hipMemsetAsync(tr->d_loss, 0, 2 * sizeof(double), st));
     T_HIP(tr, hipMemsetAsync(tr->d_maxw, 0, (tr->n_maxw + 1) * sizeof(unsigned), st));
@@ -936,6 +959,7 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
 
     // ---- split-precision route of the forward / input-gradient convolutions: planes of every tensor they read
     tr->hconv = !getenv("UMX_TRAIN_CONV_F32");
+    if (const char* e = getenv("UMX_TRAIN_WSCALE_EVERY")) tr->wscale_every = atoi(e);
     tr->h_blob = blob;
     if (tr->hconv) {
         tr->pctx = new umx_ctx();
@@ -1111,6 +1135,31 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
 
 // the step's weights -> the operands of every convolution: fp32 [tap][Cp][Np] (both routes), then conv_f16x3's weight images
 // (part 0: the forward pass's operands, 1: the backward-only ones, 2: all)
+// Every `wscale_every` steps the per-layer weight scales are re-derived from the parameters as they are now (one copy of the vector
+// to the host: 124 MB for the synthetic-256 graph, < 1 % of 256 steps), so that a long run cannot grow a filter out of the
+// 32 x headroom the scale of step 0 left it.  Called with nothing in flight that reads the scales.
+int refresh_wscales(umx_trainer* tr) {
+    if (tr->hconvs.empty()) return UMX_OK;
+    T_HIP(tr, hipStreamSynchronize(tr->stream));
+    tr->h_params.resize(tr->nparams);
+    T_HIP(tr, hipMemcpy(tr->h_params.data(), tr->d_w, tr->nparams * sizeof(float), hipMemcpyDeviceToHost));
+    bool changed = false;
+    for (size_t k = 0; k < tr->hconvs.size(); ++k) {
+        TConv& tc = *tr->hconvs[k];
+        const int sh = wscale_shift(operand_wmax(tc, tr->h_params.data()));
+        if (sh == tc.wsh) continue;
+        tc.wsh = sh;
+        const float inv = std::ldexp(1.f, -sh);
+        T_HIP(tr, hipMemcpy(tc.winv, &inv, sizeof inv, hipMemcpyHostToDevice));
+        for (RepackDesc& rd : tr->rdescs)
+            if (rd.owner == (int)k) rd.scale = std::ldexp(1.f, sh);
+        changed = true;
+    }
+    if (changed)
+        T_HIP(tr, hipMemcpy(tr->d_rdescs, tr->rdescs.data(), tr->rdescs.size() * sizeof(RepackDesc), hipMemcpyHostToDevice));
+    return UMX_OK;
+}
+
 int pack_all(umx_trainer* tr, hipStream_t st, int part) {
     const int p0 = part == 1 ? tr->n_fwd_packs : 0, p1 = part == 0 ? tr->n_fwd_packs : (int)tr->packs.size();
     const int r0 = part == 1 ? tr->n_fwd_rdescs : 0, r1 = part == 0 ? tr->n_fwd_rdescs : (int)tr->rdescs.size();
@@ -1240,8 +1289,10 @@ int umx_trainer_loss(umx_trainer* tr, double* loss3) {
     T_HIP(tr, hipMemcpyAsync(&flag, tr->d_maxw + tr->n_maxw, sizeof flag, hipMemcpyDeviceToHost, tr->stream));
     T_HIP(tr, hipStreamSynchronize(tr->stream));
     if (flag)
-        return tfail(tr, UMX_ERR_RANGE, "an operand of the split-precision weight gradient left the binary16 range "
-                                        "(|v| >= 6e4 after scaling or not finite); set UMX_TRAIN_WGRAD_F32=1");
+        return tfail(tr, UMX_ERR_RANGE, "an operand of a split-precision convolution or weight gradient left the binary16 range "
+                                        "(|v| >= 6e4 after scaling or not finite): a diverging run, or a filter that outgrew its scale "
+                                        "between two refreshes (UMX_TRAIN_WSCALE_EVERY); UMX_TRAIN_CONV_F32=1 / UMX_TRAIN_WGRAD_F32=1 "
+                                        "select the exact-fp32 kernels");
     loss3[0] = h[0] + h[1];
     loss3[1] = h[0];
     loss3[2] = h[1];
