@@ -20,17 +20,17 @@ import helpers  # noqa: E402
 from unmicst_amd import model, tiffio  # noqa: E402
 
 
-def one(tree, path, out, env_extra, label, n):
+def one(tree, path, out, env_extra, label, n, script="UnMicst.py", what="legacy nucleiDAPI"):
     e = dict(os.environ, UMX_CLI_TIMING="1", **env_extra)
     e["UMX_CLI_T0"] = repr(time.time())
     t = time.perf_counter()
-    r = subprocess.run([sys.executable, os.path.join(tree, "UnMicst.py"), path, "--stackOutput", "--outputPath", out], env=e,
+    r = subprocess.run([sys.executable, os.path.join(tree, script), path, "--stackOutput", "--outputPath", out], env=e,
                        capture_output=True, text=True)
     dt = time.perf_counter() - t
     assert r.returncode == 0, r.stderr[-2000:]
     stages = [l[len("umx-cli-timing "):] for l in r.stderr.splitlines() if l.startswith("umx-cli-timing ")]
-    print("%d x %d uint16, legacy nucleiDAPI, --stackOutput: %-44s %.2f s wall (process start to exit)  %s" % (
-        n, n, label, dt, stages[-1] if stages else ""), flush=True)
+    print("%d x %d uint16, %s, --stackOutput: %-44s %.2f s wall (process start to exit)  %s" % (
+        n, n, what, label, dt, stages[-1] if stages else ""), flush=True)
     return dt
 
 
@@ -52,6 +52,12 @@ def main():
             for i, tree in enumerate(others):
                 one(tree, path, os.path.join(d, "out_o%d_%d" % (i, rep)), env, "%s, run %d" % (os.path.basename(tree.rstrip("/")), rep + 1), n)
         one(ROOT, path, os.path.join(d, "out_host"), dict(env, UMX_NO_RAW_PATH="1"), "this tree, host pre/post (UMX_NO_RAW_PATH=1)", n)
+        # the default tool (UnMicst1-5.py, solo hyper-parameters: 116 964 tiles of 64 x 64 on this slide; the reference downloads its
+        # weights at image-build time, so seeded weights stand in -- timing only) from the repo's own models/ directory
+        solo_env = {"UMX_SYNTHETIC_WEIGHTS": "1"}
+        for rep in range(2):
+            one(ROOT, path, os.path.join(d, "out_solo%d" % rep), solo_env, "this tree, run %d" % (rep + 1), n, "UnMicst1-5.py",
+                "solo hp (seeded weights)")
         # the pages of the two trees must be the same bytes
         a = os.path.join(d, "out_new0")
         for i in range(len(others)):

@@ -3,6 +3,8 @@
 #include "umx_internal.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 
 namespace umx {
 
@@ -325,9 +327,20 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         std::vector<_Float16>& W = wimg[list];
         W.assign(per_blk * h.nblocks, (_Float16)0.f);
         if (L.train) { L.wrefs[list].clear(); L.slab_units[list] = per_blk * h.nblocks / 8; }
-        for (int nb = 0; nb < h.nblocks; ++nb) {
-            size_t ks = 0;
-            for (int si = h.ph[list].stage0; si < (int)stages.size(); ++si) {
+        // one task per (N-block, stage): disjoint ranges of W, so the tasks are spread over host threads (the solo model's 117 MB of
+        // filters took 0.5 s of a 3 s command-line run on one core); training plans record references and stay on one thread
+        std::vector<size_t> ks_of;   // first k-step of each stage of this list
+        {
+            size_t k0 = 0;
+            for (int si = h.ph[list].stage0; si < (int)stages.size(); ++si) { ks_of.push_back(k0); k0 += (size_t)stages[si].nk; }
+        }
+        const bool d2s_skip = L.d2s && L.d2s_npb == 4 && !getenv("UMX_NO_D2S_SKIP");
+        std::atomic<bool> bad_slot{false};
+        const int nst = (int)stages.size() - h.ph[list].stage0;
+        auto fill_task = [&](int task) {
+            const int nb = task / nst, si = h.ph[list].stage0 + task % nst;
+            size_t ks = ks_of[(size_t)(task % nst)];
+            {
                 const size_t blk = nb * per_blk + (size_t)stages[si].woff * 8;
                 unsigned short* const hdr = reinterpret_cast<unsigned short*>(&W[blk]);
                 for (int j = 0; j < stages[si].nk; ++j, ++ks) {
@@ -336,13 +349,10 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                         const auto& tp = L.g[pr2.gi].taps[pr2.ph][pr2.tap < 0 ? 0 : pr2.tap];
                         // 16-byte LDS slot of (halo pixel at this tap, octet k) in the pixel-major image of halo slot `slot`
                         const int slot = pr2.slot * (h.plane_slots * OC) + ((tp.first - g.ymin) * h.hw + (tp.second - g.xmin)) * OC + pr2.k;
-                        if (slot < 0 || slot >= bestSlots * h.plane_slots * OC || slot > 65535) {
-                            *why = "internal: k-map slot out of range";
-                            return UMX_ERR_INVALID;
-                        }
+                        if (slot < 0 || slot >= bestSlots * h.plane_slots * OC || slot > 65535) { bad_slot = true; return; }
                         hdr[j * 4 + qq] = (unsigned short)slot;
                     }
-                    if (L.d2s && L.d2s_npb == 4 && !getenv("UMX_NO_D2S_SKIP")) {
+                    if (d2s_skip) {
                         // depth-to-space form, one block of four phases: a k-step made only of taps the odd output rows (phase slots
                         // 2, 3) do not have leaves their N-tiles without weights -- the kernel skips them (flag byte j behind the k-map)
                         bool dead = true;
@@ -381,7 +391,23 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                         }
                 }
             }
+        };
+        const int ntasks = h.nblocks * nst;
+        const size_t work = per_blk * (size_t)h.nblocks;
+        int nthr = L.train || work < (1u << 20) ? 1 : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char* e = getenv("UMX_PLAN_THREADS")) nthr = std::max(1, atoi(e));
+        if (L.train) nthr = 1;
+        nthr = std::min(nthr, std::max(1, ntasks));
+        if (nthr <= 1) {
+            for (int t = 0; t < ntasks; ++t) fill_task(t);
+        } else {
+            std::atomic<int> next{0};
+            std::vector<std::thread> pool;
+            for (int i = 0; i < nthr; ++i)
+                pool.emplace_back([&] { for (int t; (t = next.fetch_add(1)) < ntasks;) fill_task(t); });
+            for (auto& th : pool) th.join();
         }
+        if (bad_slot) { *why = "internal: k-map slot out of range"; return UMX_ERR_INVALID; }
     }
 
     // epilogue constants per N-block: pre_s absorbs 2^-(weight shift + input activation shift), post_* the output's
