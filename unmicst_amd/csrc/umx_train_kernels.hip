@@ -462,10 +462,125 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(const ActParams a, const f
     }
 }
 
+// The same for C % 4 == 0 (every layer of the shipped widths): a thread owns FOUR consecutive channels of the rows it walks -- 16-byte
+// loads and stores, the per-channel constants in registers, no division in the row loop (the scalar kernel above spends most of
+// its time on 4-byte accesses and 64-bit index arithmetic: lu0, 19 M elements, 149 us against 50 us of memory time).  Same partial-sum
+// layout (part[block][2][C], fp64, fixed order), so the finalize kernel does not change.
+__global__ void __launch_bounds__(256) act_bwd_v4_kernel(const ActParams a, const float* __restrict__ dy0,
+                                                         const float* __restrict__ dy1, float* __restrict__ g, unsigned Nrows,
+                                                         int Qb, int R, double* __restrict__ part, unsigned* gx) {
+    __shared__ double sm[2][256][4];
+    __shared__ unsigned smx[2][256];
+    const int tid = threadIdx.x;
+    const int r = tid / Qb, ql = tid - r * Qb;
+    const int C = a.C, Q = C >> 2;
+    const int q = ql + blockIdx.y * 256;            // channel quad
+    const unsigned rpb = (Nrows + gridDim.x - 1) / gridDim.x;
+    const unsigned r0 = blockIdx.x * rpb, r1 = min(Nrows, r0 + rpb);
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    float mg = 0.f, mxh = 0.f;
+    const bool on = r < R && q < Q;
+    if (on) {
+        const int c = 4 * q;
+        const float4 mean4 = *reinterpret_cast<const float4*>(a.stat + c), rstd4 = *reinterpret_cast<const float4*>(a.stat + C + c);
+        const float4 sc4 = *reinterpret_cast<const float4*>(a.stat + 2 * C + c), sh4 = *reinterpret_cast<const float4*>(a.stat + 3 * C + c);
+        const float mean[4] = {mean4.x, mean4.y, mean4.z, mean4.w}, rstd[4] = {rstd4.x, rstd4.y, rstd4.z, rstd4.w};
+        const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+        const float ks = 1.0f / (1.0f - a.drop_rate);
+        const unsigned OW = a.W >> 1, OH = a.H >> 1;
+        for (unsigned row = r0 + r; row < r1; row += R) {
+            float4 d4 = reinterpret_cast<const float4*>(dy0)[(size_t)row * Q + q];
+            if (dy1) {
+                const float4 e4 = reinterpret_cast<const float4*>(dy1)[(size_t)row * Q + q];
+                d4.x += e4.x; d4.y += e4.y; d4.z += e4.z; d4.w += e4.w;
+            }
+            const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+            if (!a.pool) {
+                const size_t e = (size_t)row * C + c;
+                const float4 z4 = reinterpret_cast<const float4*>(a.z)[(size_t)row * Q + q];
+                const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+                float gg[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = zz[k] * sc[k] + sh[k];
+                    gg[k] = d[k] * drop_mul(a.drop_key, e + k, a.drop_rate, ks) * dact_of(v, a.act);
+                    const float xh = (zz[k] - mean[k]) * rstd[k];
+                    s1[k] += (double)gg[k];
+                    s2[k] += (double)gg[k] * (double)xh;
+                    mg = fmaxf(mg, fabsf(gg[k]));
+                    mxh = fmaxf(mxh, fabsf(xh));
+                }
+                reinterpret_cast<float4*>(g)[(size_t)row * Q + q] = make_float4(gg[0], gg[1], gg[2], gg[3]);
+            } else {
+                const unsigned ox = row % OW, t = row / OW, oy = t % OH, b = t / OH;
+                size_t px[4];
+                float zz[4][4], vv[4][4], dm[4][4];
+                int arg[4] = {0, 0, 0, 0};
+                float best[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    px[j] = ((size_t)b * a.H + 2 * oy + (j >> 1)) * a.W + 2 * ox + (j & 1);
+                    const float4 z4 = reinterpret_cast<const float4*>(a.z)[px[j] * Q + q];
+                    const float zj[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        zz[j][k] = zj[k];
+                        vv[j][k] = zj[k] * sc[k] + sh[k];
+                        dm[j][k] = drop_mul(a.drop_key, px[j] * C + c + k, a.drop_rate, ks);
+                        const float y = act_of(vv[j][k], a.act) * dm[j][k];
+                        if (j == 0 || y > best[k]) { best[k] = y; arg[k] = j; }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float gg[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        gg[k] = j == arg[k] ? d[k] * dm[j][k] * dact_of(vv[j][k], a.act) : 0.f;
+                        const float xh = (zz[j][k] - mean[k]) * rstd[k];
+                        mxh = fmaxf(mxh, fabsf(xh));
+                        if (j == arg[k]) {
+                            s1[k] += (double)gg[k];
+                            s2[k] += (double)gg[k] * (double)xh;
+                            mg = fmaxf(mg, fabsf(gg[k]));
+                        }
+                    }
+                    reinterpret_cast<float4*>(g)[px[j] * Q + q] = make_float4(gg[0], gg[1], gg[2], gg[3]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sm[0][tid][k] = s1[k]; sm[1][tid][k] = s2[k]; }
+    smx[0][tid] = __float_as_uint(mg);
+    smx[1][tid] = __float_as_uint(mxh);
+    __syncthreads();
+    if (r == 0 && q < Q) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double t1 = s1[k], t2 = s2[k];
+            for (int j = 1; j < R; ++j) { t1 += sm[0][j * Qb + ql][k]; t2 += sm[1][j * Qb + ql][k]; }
+            part[((size_t)blockIdx.x * 2 + 0) * C + 4 * q + k] = t1;
+            part[((size_t)blockIdx.x * 2 + 1) * C + 4 * q + k] = t2;
+        }
+    }
+    if (gx && tid < 2) {
+        unsigned m = 0u;
+        for (int j = 0; j < 256; ++j) m = max(m, smx[tid][j]);
+        if (m > *reinterpret_cast<volatile unsigned*>(gx + tid)) atomicMax(gx + tid, m);
+    }
+}
+
 hipError_t launch_act_bwd(const ActParams& a, const float* dy0, const float* dy1, float* g, double* part, int nblk,
                           unsigned* gx, hipStream_t stream) {
     const ChanLayout l = chan_layout(a.C);
     const size_t rows = (size_t)a.B * (a.pool ? a.H / 2 : a.H) * (a.pool ? a.W / 2 : a.W);
+    if (a.C % 4 == 0 && rows < 0x7fffffffull && !getenv("UMX_TRAIN_ACT_SCALAR")) {
+        const int Q = a.C / 4, Qb = std::min(Q, 256), R = std::max(1, 256 / Qb), cbl = (Q + 255) / 256;
+        hipLaunchKernelGGL(act_bwd_v4_kernel, dim3((unsigned)nblk, (unsigned)cbl), dim3(256), 0, stream, a, dy0, dy1, g, (unsigned)rows,
+                           Qb, R, part, gx);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)nblk, (unsigned)l.cblocks), dim3((unsigned)l.threads), 0, stream, a,
                        dy0, dy1, g, rows, l.Cb, l.k, part, gx);
     return hipGetLastError();
