@@ -77,7 +77,7 @@ def _hp(name):
 # exact-fp32 MFMA kernel, UMX_TRAIN_NO_KSPLIT=1 runs every one as a single pass over K (no partial sums)
 ROUTES = [{}, {"UMX_TRAIN_CONV_F32": "1"}, {"UMX_TRAIN_NO_KSPLIT": "1"}, {"UMX_TRAIN_HSPLIT_WGS": "4096"},
           # the remaining switches of the trainer: one stream instead of two; fp32 weight-gradient kernel; the fp32 route's own K split
-          {"UMX_TRAIN_NO_OVERLAP": "1"}, {"UMX_TRAIN_ONE_SIDE": "1"}, {"UMX_TRAIN_WGRAD_F32": "1"},
+          {"UMX_TRAIN_NO_OVERLAP": "1"}, {"UMX_TRAIN_ONE_SIDE": "1"}, {"UMX_TRAIN_WGRAD_F32": "1"}, {"UMX_TRAIN_ACT_SCALAR": "1"},
           {"UMX_TRAIN_CONV_F32": "1", "UMX_TRAIN_KSPLIT_WGS": "4096", "UMX_TRAIN_KSPLIT_MAX": "3"}]
 
 

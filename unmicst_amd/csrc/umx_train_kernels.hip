@@ -93,7 +93,43 @@ __global__ void __launch_bounds__(256) chan_stats_kernel(const float* __restrict
     }
 }
 
+// (C % 4 == 0: four channels per thread, 16-byte loads; same partial-sum layout)
+__global__ void __launch_bounds__(256) chan_stats_v4_kernel(const float* __restrict__ x, unsigned N, int C, int Qb, int R,
+                                                            double* __restrict__ part) {
+    __shared__ double sm[2][256][4];
+    const int tid = threadIdx.x;
+    const int r = tid / Qb, ql = tid - r * Qb;
+    const int Q = C >> 2, q = ql + blockIdx.y * 256;
+    const unsigned rpb = (N + gridDim.x - 1) / gridDim.x;
+    const unsigned r0 = blockIdx.x * rpb, r1 = min(N, r0 + rpb);
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, w[4] = {0.0, 0.0, 0.0, 0.0};
+    if (r < R && q < Q)
+        for (unsigned row = r0 + r; row < r1; row += R) {
+            const float4 v4 = reinterpret_cast<const float4*>(x)[(size_t)row * Q + q];
+            const double v[4] = {(double)v4.x, (double)v4.y, (double)v4.z, (double)v4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s[k] += v[k]; w[k] += v[k] * v[k]; }
+        }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sm[0][tid][k] = s[k]; sm[1][tid][k] = w[k]; }
+    __syncthreads();
+    if (r == 0 && q < Q) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double t1 = s[k], t2 = w[k];
+            for (int j = 1; j < R; ++j) { t1 += sm[0][j * Qb + ql][k]; t2 += sm[1][j * Qb + ql][k]; }
+            part[((size_t)blockIdx.x * 2 + 0) * C + 4 * q + k] = t1;
+            part[((size_t)blockIdx.x * 2 + 1) * C + 4 * q + k] = t2;
+        }
+    }
+}
+
 hipError_t launch_chan_stats(const float* x, size_t N, int C, double* part, int nblk, hipStream_t stream) {
+    if (C % 4 == 0 && N < 0x7fffffffull && !getenv("UMX_TRAIN_ACT_SCALAR")) {
+        const int Q = C / 4, Qb = std::min(Q, 256), R = std::max(1, 256 / Qb), cbl = (Q + 255) / 256;
+        hipLaunchKernelGGL(chan_stats_v4_kernel, dim3((unsigned)nblk, (unsigned)cbl), dim3(256), 0, stream, x, (unsigned)N, C, Qb, R, part);
+        return hipGetLastError();
+    }
     const ChanLayout l = chan_layout(C);
     hipLaunchKernelGGL(chan_stats_kernel, dim3((unsigned)nblk, (unsigned)l.cblocks), dim3((unsigned)l.threads), 0, stream,
                        x, N, C, l.Cb, l.k, part);
@@ -258,9 +294,71 @@ __global__ void __launch_bounds__(256) act_fwd_kernel(const ActParams a, float* 
     if (omax) block_absmax_to(omax, mx);
 }
 
+// (C % 4 == 0: four channels of one output pixel per thread -- 16-byte accesses, 32-bit index arithmetic)
+__global__ void __launch_bounds__(256) act_fwd_v4_kernel(const ActParams a, float* __restrict__ out, unsigned nq, unsigned* omax,
+                                                         _Float16* __restrict__ hi, _Float16* __restrict__ lo, int Cs,
+                                                         int* __restrict__ overflow) {
+    const int C = a.C;
+    const unsigned Q = (unsigned)C >> 2;
+    const float ks = 1.0f / (1.0f - a.drop_rate);
+    const unsigned OW = a.W >> 1, OH = a.H >> 1;
+    float mx = 0.f;
+    bool bad = false;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) {
+        const unsigned row = i / Q, q = i - row * Q;
+        const int c = 4 * (int)q;
+        const float4 sc4 = *reinterpret_cast<const float4*>(a.stat + 2 * C + c), sh4 = *reinterpret_cast<const float4*>(a.stat + 3 * C + c);
+        const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+        float y[4];
+        if (!a.pool) {
+            const float4 z4 = reinterpret_cast<const float4*>(a.z)[i];
+            const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+            const size_t e = (size_t)row * C + c;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[k] = act_of(zz[k] * sc[k] + sh[k], a.act) * drop_mul(a.drop_key, e + k, a.drop_rate, ks);
+        } else {
+            const unsigned ox = row % OW, t = row / OW, oy = t % OH, b = t / OH;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const size_t px = ((size_t)b * a.H + 2 * oy + (j >> 1)) * a.W + 2 * ox + (j & 1);
+                const float4 z4 = reinterpret_cast<const float4*>(a.z)[px * Q + q];
+                const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float yj = act_of(zz[k] * sc[k] + sh[k], a.act) * drop_mul(a.drop_key, px * C + c + k, a.drop_rate, ks);
+                    if (j == 0 || yj > y[k]) y[k] = yj;
+                }
+            }
+        }
+        reinterpret_cast<float4*>(out)[i] = make_float4(y[0], y[1], y[2], y[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mx = fmaxf(mx, fabsf(y[k]));
+        if (hi) {
+            union { _Float16 h[4]; uint2 u; } va, vb;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                bad = bad || !(fabsf(y[k]) < 60000.f);
+                va.h[k] = (_Float16)y[k];
+                vb.h[k] = (_Float16)(y[k] - (float)va.h[k]);
+            }
+            const size_t at = (size_t)row * Cs + c;
+            *reinterpret_cast<uint2*>(hi + at) = va.u;
+            *reinterpret_cast<uint2*>(lo + at) = vb.u;
+        }
+    }
+    if (bad) atomicOr(overflow, 1);
+    if (omax) block_absmax_to(omax, mx);
+}
+
 hipError_t launch_act_fwd(const ActParams& a, float* out, unsigned* omax, _Float16* hi, _Float16* lo, int Cs, int* overflow,
                           hipStream_t stream) {
     const size_t nout = (size_t)a.B * (a.pool ? a.H / 2 : a.H) * (a.pool ? a.W / 2 : a.W) * a.C;
+    if (a.C % 4 == 0 && (!hi || Cs % 4 == 0) && nout < 0xfffffff0ull && !getenv("UMX_TRAIN_ACT_SCALAR")) {
+        const unsigned nq = (unsigned)(nout / 4);
+        const unsigned blocks = std::min<unsigned>(4096, (nq + 255) / 256);
+        hipLaunchKernelGGL(act_fwd_v4_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, a, out, nq, omax, hi, lo, Cs, overflow);
+        return hipGetLastError();
+    }
     const unsigned blocks = (unsigned)std::min<size_t>(2048, (nout + 255) / 256);
     hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, a, out, nout, omax, hi, lo, Cs, overflow);
     return hipGetLastError();
