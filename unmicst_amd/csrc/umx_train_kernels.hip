@@ -1337,6 +1337,9 @@ __global__ void __launch_bounds__(256, 2) wgrad_f16x3(const WgradParams p) {
 
     const int prow = (p.hw + 1) >> 1;                       // pixel pairs per halo row
     const int nxt = p.imgs * p.hh * prow * (kHwC / 4);      // X staging tasks: (halo row, pixel pair, channel quad)
+    // e / prow and r / hh by reciprocal multiplication (e < kHwXT * 256 = 1280, divisors < 32: exact) -- three runtime integer
+    // divisions per staging task, twice per tile, were ~35 instructions each
+    const unsigned inv_prow = 65536u / (unsigned)prow + 1u, inv_hh = 65536u / (unsigned)p.hh + 1u;
     float4 xr[kHwXT][2], gr[kHwGT][2];
     auto load_tile = [&](int t) {
         const int tx = t % p.tiles_x;
@@ -1350,10 +1353,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_f16x3(const WgradParams p) {
             const int e = tid_o + i * 256;
             float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
             if (e < nxt) {
-                const int pr = e % prow;                      // pixel pair fastest: conflict-free LDS stores
-                int r = e / prow;
+                int r = (int)(((unsigned)e * inv_prow) >> 16);
+                const int pr = e - r * prow;                  // pixel pair fastest: conflict-free LDS stores
                 const int q = r % (kHwC / 4); r /= (kHwC / 4);
-                const int il = r / p.hh, hy = r - il * p.hh;
+                const int il = (int)(((unsigned)r * inv_hh) >> 16), hy = r - il * p.hh;
                 const int gy = y0 + p.ymin + hy, gx = x0 + p.xmin + 2 * pr, img = img0 + il;
                 const int c = ci0 + 4 * q;
                 if (img < p.B && gy >= 0 && gy < p.H && c < p.Cx) {
@@ -1431,8 +1434,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_f16x3(const WgradParams p) {
         for (int i = 0; i < kHwXT; ++i) {
             const int e = tid_o + i * 256;
             if (e < nxt) {
-                const int pr = e % prow;
-                int r = e / prow;
+                int r = (int)(((unsigned)e * inv_prow) >> 16);
+                const int pr = e - r * prow;
                 const int q = r % (kHwC / 4); r /= (kHwC / 4);   // r = il * hh + hy
                 split_store(Xh + (4 * q) * p.xs, kHwC * p.xs, p.xs, r * p.hp + 2 * pr, xr[i][0], xr[i][1], sx);
             }
