@@ -336,6 +336,12 @@ struct WgradParams {
     const unsigned* xmax;         // device word holding max|X| as float bits, written by the tensor's producer
     const unsigned* gmax;         // same for G
     int* overflow;                // set when a scaled operand leaves the binary16 range
+    // plane-staged variant (planes = 1, f16 only): the operands as (hi, lo) binary16 NHWC planes with XCs / GCs stored channels
+    // (multiples of 8, pad channels zero) and the inverse of the power-of-two scale each was stored with (NULL: unscaled)
+    int planes;
+    const _Float16 *Xhi, *Xlo, *Ghi, *Glo;
+    int XCs, GCs;
+    const float *xinv, *ginv;
 };
 // BN input gradient g <- scale * (g - m1 - xhat*m2) (in place) and LeakyReLU backward + space-to-depth of the transposed
 // conv's output gradient; both track max |v| of what they write (bit pattern of a non-negative float, atomicMax on uint;

@@ -112,6 +112,7 @@ struct umx_trainer {
     float* d_split2 = nullptr;                            // ... of those enqueued on the side stream
     // forward / input-gradient convolutions on conv_f16x3 (UMX_TRAIN_CONV_F32=1: the exact-fp32 kernels of rounds 1-3)
     bool hconv = true;
+    bool wg_planes = true;              // the split-precision weight gradient stages from the planes (UMX_TRAIN_WGRAD_FP32_STAGE=1: from fp32)
     umx_ctx* pctx = nullptr;            // owner of the planner's device allocations (stage tables, weight slabs, constants)
     const float* h_blob = nullptr;      // (during build) the initial parameters on the host: weight scales
     std::vector<umx::Launch> hls;
@@ -582,11 +583,21 @@ int bn_backward(umx_trainer* tr, BnSite& s, const ActParams& a, const float* dy0
     return UMX_OK;
 }
 
+// (xp / gp: the operands' (hi, lo) planes and xi / gi the inverse scales they were stored with, where they exist: the split-precision
+// kernel then stages from them -- half the bytes, no conversion)
 int run_wgrad(umx_trainer* tr, WgradParams& w, const float* X, const float* G, int Ctot, int c_off, size_t w_off,
               float reg, size_t pair_off /* SIZE_MAX: none */, const unsigned* xmax, const unsigned* gmax,
-              hipStream_t stream) {
+              hipStream_t stream, const H16* xp = nullptr, const float* xi = nullptr, const H16* gp = nullptr,
+              const float* gi = nullptr) {
     w.X = X;
     w.G = G;
+    w.planes = 0;
+    if (w.f16 && tr->wg_planes && xp && gp && xp->hi && gp->hi && w.Cxt <= xp->Cs && w.Cg <= gp->Cs) {
+        w.planes = 1;
+        w.Xhi = xp->hi; w.Xlo = xp->lo; w.XCs = xp->Cs;
+        w.Ghi = gp->hi; w.Glo = gp->lo; w.GCs = gp->Cs;
+        w.xinv = xi; w.ginv = gi;
+    }
     w.ws = stream == tr->side2 ? tr->d_ws2 : tr->d_ws;   // (each side stream has its own slice workspace)
     w.xmax = xmax;
     w.gmax = gmax;
@@ -752,22 +763,30 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         tr->h_dz[slot].Cs = round_up(Cup, 8);
         T_TRY(bn_backward(tr, s, a, tr->DA, nullptr, dz, tr->hconv ? &tr->h_dz[slot] : nullptr, tr->d_xinv + slot));
         T_TRY(dz_ready(slot));
-        T_TRY(run_wgrad(tr, tr->wg_u0[idx], tr->ds[idx], dz, Cskip + Cup, 0, tr->o_w2[idx], o.reg_up, SIZE_MAX, tr->dsmax[idx], s.gmax, ws));
-        T_TRY(run_wgrad(tr, tr->wg_u1[idx], tr->us[idx], dz, Cskip + Cup, Cskip, tr->o_w2[idx], o.reg_up, SIZE_MAX, tr->usmax[idx], s.gmax, ws));
+        const H16* const pdz = tr->hconv ? &tr->h_dz[slot] : nullptr;
+        T_TRY(run_wgrad(tr, tr->wg_u0[idx], tr->ds[idx], dz, Cskip + Cup, 0, tr->o_w2[idx], o.reg_up, SIZE_MAX, tr->dsmax[idx], s.gmax, ws,
+                        tr->hconv ? &tr->h_ds[idx] : nullptr, nullptr, pdz, tr->d_xinv + slot));
+        T_TRY(run_wgrad(tr, tr->wg_u1[idx], tr->us[idx], dz, Cskip + Cup, Cskip, tr->o_w2[idx], o.reg_up, SIZE_MAX, tr->usmax[idx], s.gmax, ws,
+                        tr->hconv ? &tr->h_us[idx] : nullptr, nullptr, pdz, tr->d_xinv + slot));
         T_TRY(dgrad(tr->c_dg_us[idx], dz, tr->h_dz[slot], tr->d_xinv + slot, tr->DB));
         if (idx >= 1) T_TRY(dgrad(tr->c_dg_skip[idx], dz, tr->h_dz[slot], tr->d_xinv + slot, tr->dskip[idx]));   // (side stream: 2 % slower)
         T_HIP(tr, launch_leaky_bwd_s2d_max(tr->DB, tr->us[idx], B, S / 2, Cup, gs, tr->smax[idx], st));
+        const bool gs_planes = tr->hconv && (tr->c_dg_T[idx].hidx >= 0 || tr->wg_planes);
+        if (gs_planes) {   // (in front of the event: the transposed convolution's weight gradient stages from these planes too)
+            tr->h_gs[slot].Cs = round_up(4 * Cup, 8);
+            T_TRY(to_h16(tr, gs, (size_t)B * (S / 2) * (S / 2), 4 * Cup, tr->h_gs[slot], tr->smax[idx], tr->d_xinv + 2 + slot, st));
+        }
         if (tr->overlap) {
             T_HIP(tr, hipEventRecord(tr->ev_gs[slot], st));
             T_HIP(tr, hipStreamWaitEvent(ws, tr->ev_gs[slot], 0));
         }
-        T_TRY(run_wgrad(tr, tr->wg_T[idx], gs, layer_in, Cup, 0, tr->o_wt[idx], o.reg_up, SIZE_MAX, tr->smax[idx],
-                        idx == L - 1 ? tr->bmax : tr->cvmax[idx + 1], ws));
-        T_TRY(side_done(slot));
-        if (tr->c_dg_T[idx].hidx >= 0) {
-            tr->h_gs[slot].Cs = round_up(4 * Cup, 8);
-            T_TRY(to_h16(tr, gs, (size_t)B * (S / 2) * (S / 2), 4 * Cup, tr->h_gs[slot], tr->smax[idx], tr->d_xinv + 2 + slot, st));
+        {
+            const H16* const pin = !tr->hconv ? nullptr : idx == L - 1 ? &tr->h_b : &tr->h_cv[idx + 1];
+            T_TRY(run_wgrad(tr, tr->wg_T[idx], gs, layer_in, Cup, 0, tr->o_wt[idx], o.reg_up, SIZE_MAX, tr->smax[idx],
+                            idx == L - 1 ? tr->bmax : tr->cvmax[idx + 1], ws, gs_planes ? &tr->h_gs[slot] : nullptr, tr->d_xinv + 2 + slot, pin,
+                            nullptr));
         }
+        T_TRY(side_done(slot));
         T_TRY(dgrad(tr->c_dg_T[idx], gs, tr->h_gs[slot], tr->d_xinv + 2 + slot, tr->DA));
         slot ^= 1;
         S /= 2;
@@ -779,7 +798,8 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         tr->h_dz[slot].Cs = round_up(tr->n[L + 1], 8);
         T_TRY(bn_backward(tr, tr->bn_b, a, tr->DA, nullptr, dz, tr->hconv ? &tr->h_dz[slot] : nullptr, tr->d_xinv + slot));
         T_TRY(dz_ready(slot));
-        T_TRY(run_wgrad(tr, tr->wg_b, tr->ds[L], dz, tr->n[L], 0, tr->o_lb, o.reg_bottom, SIZE_MAX, tr->dsmax[L], tr->bn_b.gmax, ws));
+        T_TRY(run_wgrad(tr, tr->wg_b, tr->ds[L], dz, tr->n[L], 0, tr->o_lb, o.reg_bottom, SIZE_MAX, tr->dsmax[L], tr->bn_b.gmax, ws,
+                        tr->hconv ? &tr->h_ds[L] : nullptr, nullptr, tr->hconv ? &tr->h_dz[slot] : nullptr, tr->d_xinv + slot));
         T_TRY(side_done(slot));
         T_TRY(dgrad(tr->c_dg_b, dz, tr->h_dz[slot], tr->d_xinv + slot, tr->DB));
         slot ^= 1;
@@ -794,7 +814,9 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         T_TRY(bn_backward(tr, s, a, tr->DB, dy1, dz, tr->hconv && i >= 1 ? &tr->h_dz[slot] : nullptr, tr->d_xinv + slot));
         T_TRY(dz_ready(slot));
         // c00 + shortcut = conv(x, W1 + Wshort): both filters receive the same data gradient (UnMicst1-5.py:102-114)
-        T_TRY(run_wgrad(tr, tr->wg_d[i], tr->ds[i], dz, tr->n[i], 0, tr->o_ws[i], o.reg_down, tr->o_w1[i], tr->dsmax[i], s.gmax, ws));
+        T_TRY(run_wgrad(tr, tr->wg_d[i], tr->ds[i], dz, tr->n[i], 0, tr->o_ws[i], o.reg_down, tr->o_w1[i], tr->dsmax[i], s.gmax, ws,
+                        tr->hconv && i >= 1 ? &tr->h_ds[i] : nullptr, nullptr, tr->hconv && i >= 1 ? &tr->h_dz[slot] : nullptr,
+                        tr->d_xinv + slot));
         T_TRY(side_done(slot));
         S *= 2;
         if (i >= 1) T_TRY(dgrad(tr->c_dg_d[i], dz, tr->h_dz[slot], tr->d_xinv + slot, tr->DB));
@@ -960,6 +982,7 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
     // ---- split-precision route of the forward / input-gradient convolutions: planes of every tensor they read
     tr->hconv = !getenv("UMX_TRAIN_CONV_F32");
     if (const char* e = getenv("UMX_TRAIN_WSCALE_EVERY")) tr->wscale_every = atoi(e);
+    tr->wg_planes = tr->hconv && !getenv("UMX_TRAIN_WGRAD_FP32_STAGE");
     tr->h_blob = blob;
     if (tr->hconv) {
         tr->pctx = new umx_ctx();

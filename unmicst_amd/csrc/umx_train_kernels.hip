@@ -1299,6 +1299,10 @@ __device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
     return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
 }
 
+// PL = true (round 4): the operands are staged from the (hi, lo) binary16 NHWC planes their producers already wrote for conv_f16x3
+// (WgradParams::Xhi ..): half the bytes, no conversion, and a staging task is 16 bit operations instead of ~56 conversions and
+// subtractions.  X planes are unscaled, G planes carry the power of two of their tensor (undone by the reduce through *ginv).
+template <bool PL>
 __global__ void __launch_bounds__(256, 2) wgrad_f16x3(const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     _Float16* const Xh = reinterpret_cast<_Float16*>(smem_b);   // [2][48][xs]
@@ -1315,7 +1319,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_f16x3(const WgradParams p) {
     const int ci0 = (blockIdx.y / nco) * kHwC, co0 = (blockIdx.y % nco) * kHwC;
     const int slab0 = p.gstart[blockIdx.z], ns = p.gcount[blockIdx.z];
     const int coff = p.coff[slab0];
-    const float sx = wg_scale(p.xmax), sg = wg_scale(p.gmax);
+    const float sx = PL ? 1.f : wg_scale(p.xmax), sg = PL ? 1.f : wg_scale(p.gmax);
 
     // this wave's (slab, channel tile) pairs
     const int npairs = ns * 3, pair0 = wave * kHwPW;
@@ -1359,7 +1363,21 @@ __global__ void __launch_bounds__(256, 2) wgrad_f16x3(const WgradParams p) {
                 const int il = (int)(((unsigned)r * inv_hh) >> 16), hy = r - il * p.hh;
                 const int gy = y0 + p.ymin + hy, gx = x0 + p.xmin + 2 * pr, img = img0 + il;
                 const int c = ci0 + 4 * q;
-                if (img < p.B && gy >= 0 && gy < p.H && c < p.Cx) {
+                if (PL && img < p.B && gy >= 0 && gy < p.H && c < p.Cx) {
+                    // (planes: 4 halves of hi and of lo per pixel -- the pad channels of a tensor's last octet are zeros)
+                    const size_t row = ((size_t)(img * p.H + gy) * p.W) * p.XCs + coff + c;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int gxx = gx + h;
+                        if (gxx >= 0 && gxx < p.W && 2 * pr + h < p.hw) {
+                            const uint2 vh = *reinterpret_cast<const uint2*>(p.Xhi + row + (size_t)gxx * p.XCs);
+                            const uint2 vl = *reinterpret_cast<const uint2*>(p.Xlo + row + (size_t)gxx * p.XCs);
+                            const float4 v = make_float4(__uint_as_float(vh.x), __uint_as_float(vh.y), __uint_as_float(vl.x),
+                                                         __uint_as_float(vl.y));
+                            if (h == 0) v0 = v; else v1 = v;
+                        }
+                    }
+                } else if (!PL && img < p.B && gy >= 0 && gy < p.H && c < p.Cx) {
                     const float* row = p.X + ((size_t)(img * p.H + gy) * p.W) * p.Cxt + coff + c;
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
@@ -1392,7 +1410,16 @@ __global__ void __launch_bounds__(256, 2) wgrad_f16x3(const WgradParams p) {
             const int img = img0 + il;
             const int co = co0 + 4 * q;
             float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-            if (img < p.B && co < p.Cg) {
+            if (PL && img < p.B && co < p.Cg) {
+                const size_t at = ((size_t)(img * p.H + y0 + y) * p.W + x0 + x) * p.GCs + co;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint2 vh = *reinterpret_cast<const uint2*>(p.Ghi + at + (size_t)h * p.GCs);
+                    const uint2 vl = *reinterpret_cast<const uint2*>(p.Glo + at + (size_t)h * p.GCs);
+                    const float4 v = make_float4(__uint_as_float(vh.x), __uint_as_float(vh.y), __uint_as_float(vl.x), __uint_as_float(vl.y));
+                    if (h == 0) v0 = v; else v1 = v;
+                }
+            } else if (!PL && img < p.B && co < p.Cg) {
                 const float* src = p.G + ((size_t)(img * p.H + y0 + y) * p.W + x0 + x) * p.Cg + co;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -1413,6 +1440,22 @@ __global__ void __launch_bounds__(256, 2) wgrad_f16x3(const WgradParams p) {
         }
     };
     auto split_store = [&](_Float16* base, int plane_stride, int chan_stride, int pos, float4 a, float4 b, float sc) {
+        if constexpr (PL) {
+            // a, b = pixels 2 pr and 2 pr + 1: {hi(c0, c1), hi(c2, c3), lo(c0, c1), lo(c2, c3)} as bit patterns; the LDS image wants, per
+            // channel, the pixel pair in one word
+            const unsigned ah0 = __float_as_uint(a.x), ah1 = __float_as_uint(a.y), al0 = __float_as_uint(a.z), al1 = __float_as_uint(a.w);
+            const unsigned bh0 = __float_as_uint(b.x), bh1 = __float_as_uint(b.y), bl0 = __float_as_uint(b.z), bl1 = __float_as_uint(b.w);
+            const unsigned hw[4] = {(ah0 & 0xffffu) | (bh0 << 16), (ah0 >> 16) | (bh0 & 0xffff0000u), (ah1 & 0xffffu) | (bh1 << 16),
+                                    (ah1 >> 16) | (bh1 & 0xffff0000u)};
+            const unsigned lw[4] = {(al0 & 0xffffu) | (bl0 << 16), (al0 >> 16) | (bl0 & 0xffff0000u), (al1 & 0xffffu) | (bl1 << 16),
+                                    (al1 >> 16) | (bl1 & 0xffff0000u)};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                *reinterpret_cast<unsigned*>(base + k * chan_stride + pos) = hw[k];
+                *reinterpret_cast<unsigned*>(base + plane_stride + k * chan_stride + pos) = lw[k];
+            }
+            return;
+        }
         const float va[4] = {a.x * sc, a.y * sc, a.z * sc, a.w * sc};
         const float vb[4] = {b.x * sc, b.y * sc, b.z * sc, b.w * sc};
         float big = 0.f;
@@ -1624,14 +1667,21 @@ hipError_t launch_wgrad(const WgradParams& p, hipStream_t stream) {
     if (p.f16) {
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16x3),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16x3<false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16x3<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024);
             if (e != hipSuccess) return e;
             attr_set = true;
         }
         const unsigned chunks = (unsigned)(((p.Cx + kHwC - 1) / kHwC) * ((p.Cg + kHwC - 1) / kHwC));
-        hipLaunchKernelGGL(wgrad_f16x3, dim3((unsigned)p.nslices, chunks, (unsigned)p.ngroups), dim3(256), wgrad_f16_lds(p),
-                           stream, p);
+        if (p.planes)
+            hipLaunchKernelGGL(wgrad_f16x3<true>, dim3((unsigned)p.nslices, chunks, (unsigned)p.ngroups), dim3(256), wgrad_f16_lds(p),
+                               stream, p);
+        else
+            hipLaunchKernelGGL(wgrad_f16x3<false>, dim3((unsigned)p.nslices, chunks, (unsigned)p.ngroups), dim3(256), wgrad_f16_lds(p),
+                               stream, p);
         return hipGetLastError();
     }
     const bool big = p.nhalo > kWgHalo;
@@ -1654,6 +1704,9 @@ struct WgReduce {
     float* g2;
     const unsigned* xmax;     // split-precision launches: the operand scales are divided out here
     const unsigned* gmax;
+    const float* xinv;        // ... plane-staged launches: the inverse scales of the planes (NULL: 1)
+    const float* ginv;
+    int planes;
     int f16;
     short mslab[kWgMaxSlabs];
 };
@@ -1678,7 +1731,8 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const WgReduce q, int
     const int ci = (int)(r % q.Cx);
     const int sb = (int)(r / q.Cx);
     const size_t dsti = ((size_t)q.mslab[sb] * q.Ctot + q.c_off + ci) * q.Cg + co;
-    if (q.f16) s /= (double)wg_scale(q.xmax) * (double)wg_scale(q.gmax);
+    if (q.f16 && q.planes) s *= (double)(q.xinv ? *q.xinv : 1.f) * (double)(q.ginv ? *q.ginv : 1.f);
+    else if (q.f16) s /= (double)wg_scale(q.xmax) * (double)wg_scale(q.gmax);
     float v = (float)s;
     if (q.g2) q.g2[dsti] = v;
     if (q.w && q.reg_kind) v += reg_grad(q.w[dsti], q.reg_kind, q.reg_c);
@@ -1691,6 +1745,7 @@ hipError_t launch_wgrad_reduce(const WgradParams& p, int Ctot, int c_off, float*
     q.ws = p.ws; q.nslices = p.nslices; q.nslab = p.nslab; q.Cx = p.Cx; q.Cg = p.Cg; q.Ctot = Ctot; q.c_off = c_off;
     q.g = g; q.w = w; q.reg_kind = reg_kind; q.reg_c = reg_c; q.g2 = g2;
     q.xmax = p.xmax; q.gmax = p.gmax; q.f16 = p.f16;
+    q.xinv = p.xinv; q.ginv = p.ginv; q.planes = p.f16 && p.planes;
     for (int s = 0; s < kWgMaxSlabs; ++s) q.mslab[s] = s < p.nslab ? p.mslab[s] : 0;
     const size_t n = (size_t)p.nslab * p.Cx * p.Cg;
     int SP = 1;
