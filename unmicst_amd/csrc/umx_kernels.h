@@ -272,8 +272,10 @@ struct HWRefDev { int dst; int base; unsigned short nvalid, arr; };   // == umx:
 struct RepackDesc {
     const HWRefDev* refs;
     int n;                  // units to fill
-    const float* arr[2];    // fp32 operands of the launch's groups for this phase: [tap][Cp][Np]
+    const float* arr[2];    // fp32 operands of the launch's groups for this phase: [tap][Cp][Np]; or (direct) the groups' master tensors
+    const float* arr2[2];   // (direct, nullable) a second master added element for element (a block's 3x3 filter + its shortcut's)
     int stride;             // Np: elements between consecutive input channels
+    int estride[2];         // (direct) the same per group inside the master tensor; 0 = the packed operand (stride above)
     float scale;            // 2^s applied to the weights (the launch's HConvParams::dyn[0] points at 2^-s)
     uint4* slab;            // the phase list's weight slab (headers stay as the planner wrote them)
     int bwd;                // (host bookkeeping) as PackDesc::bwd

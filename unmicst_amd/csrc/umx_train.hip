@@ -15,6 +15,7 @@
 #include "umx_kernels.h"
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -35,6 +36,7 @@ struct TConv {                       // one convolution of the step: device-pack
     float* packed[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     double mac = 0.0;                // algorithmic multiply-accumulates per image
     int hidx = -1;                   // index into umx_trainer::hls (split-precision plan), -1: fp32 kernel
+    bool direct = false;             // its weight images are gathered straight from the master tensors (no fp32 operand)
     float* winv = nullptr;           // device scalar 2^-s: undoes the scale of the repacked weights in the epilogue
     int wsh = 0;                     // s
     struct WSrc { size_t off, off2, cnt; };
@@ -271,6 +273,36 @@ int setup_hconv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int 
     T_TRY(talloc(tr, &tc.winv, 1));
     T_HIP(tr, hipMemcpy(tc.winv, &inv, sizeof inv, hipMemcpyHostToDevice));
     static_assert(sizeof(umx::HWRef) == sizeof(HWRefDev) && sizeof(HWRefDev) == 12, "reference record layout");
+    // The planner's references address the packed fp32 operand [tap][Cp][Np]; rewritten here into the master tensor's own
+    // coordinates (the index arithmetic of pack_weights_kernel, done once on the host), the per-step repack reads the parameters
+    // directly and this convolution needs no fp32 operand at all.  An octet that straddles two parity blocks keeps the packed route.
+    bool direct = !getenv("UMX_TRAIN_PACKED_REPACK");
+    for (int ph = 0; ph < nphase && direct; ++ph)
+        for (const umx::HWRef& r : L.wrefs[ph]) {
+            const GroupSpec& G = gs[r.arr];
+            const int c0 = (int)(((size_t)r.base / L.Np) % round_up(G.C, 4));
+            if (c0 / G.Cblk != (c0 + r.nvalid - 1) / G.Cblk) { direct = false; break; }
+        }
+    if (direct)
+        for (int ph = 0; ph < nphase; ++ph) {
+            std::vector<umx::HWRef> out;
+            out.reserve(L.wrefs[ph].size());
+            for (const umx::HWRef& r : L.wrefs[ph]) {
+                const GroupSpec& G = gs[r.arr];
+                const int Cp = round_up(G.C, 4);
+                const int co = (int)((size_t)r.base % L.Np);
+                const size_t row = (size_t)r.base / L.Np;
+                const int c0 = (int)(row % Cp), t = (int)(row / Cp);
+                const int par = c0 / G.Cblk, cc = c0 - par * G.Cblk;
+                const int m = G.taps[ph].m[(size_t)t * G.npar + par];
+                if (m < 0) continue;   // a tap this parity block does not have: the unit stays zero
+                const size_t idx = G.transpose ? ((size_t)m * G.d2 + G.c_off + co) * G.d3 + cc : ((size_t)m * G.d2 + G.c_off + cc) * G.d3 + co;
+                if (idx > (size_t)INT_MAX) return tfail(tr, UMX_ERR_INVALID, "%s: master tensor too large for a weight reference", what);
+                out.push_back(umx::HWRef{r.dst, (int)idx, r.nvalid, r.arr});
+            }
+            L.wrefs[ph].swap(out);
+        }
+    tc.direct = direct;
     for (int ph = 0; ph < nphase; ++ph) {
         const std::vector<umx::HWRef>& refs = L.wrefs[ph];
         if (refs.empty()) continue;
@@ -281,7 +313,11 @@ int setup_hconv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int 
         memset(&rd, 0, sizeof rd);
         rd.refs = d;
         rd.n = (int)refs.size();
-        for (int g = 0; g < ngroups; ++g) rd.arr[g] = tc.packed[ph][g];
+        for (int g = 0; g < ngroups; ++g) {
+            rd.arr[g] = direct ? tr->d_w + gs[g].w_off : tc.packed[ph][g];
+            rd.arr2[g] = direct && gs[g].w2_off != SIZE_MAX ? tr->d_w + gs[g].w2_off : nullptr;
+            rd.estride[g] = direct ? (gs[g].transpose ? 1 : gs[g].d3) : 0;
+        }
         rd.stride = tc.cp.Np;
         rd.scale = std::ldexp(1.f, sh);
         rd.slab = const_cast<uint4*>(L.hcp.ph[ph].w);
@@ -403,6 +439,7 @@ int setup_conv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int C
         p.vec4[g] = (gs[g].C % 4) == 0;
     }
     // packed operands + descriptors
+    size_t npacks = 0;
     for (int ph = 0; ph < nphase; ++ph)
         for (int g = 0; g < ngroups; ++g) {
             const TapSet& ts = gs[g].taps[ph];
@@ -424,10 +461,13 @@ int setup_conv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int C
             for (size_t i = 0; i < ts.m.size(); ++i) d.mtap[i] = (short)ts.m[i];
             d.bwd = tr->cur_bwd ? 1 : 0;
             tr->packs.push_back(d);
+            ++npacks;
             tr->max_pack = std::max(tr->max_pack, elems);
             tc.mac += (double)H * W * nt * gs[g].C * Cout;
         }
+    const size_t packs_before = tr->packs.size() - npacks;
     T_TRY(setup_hconv(tr, tc, what, H, W, Cout, act, nphase, o_mul, oy, ox, ngroups, gs));
+    if (tc.hidx >= 0 && tc.direct) tr->packs.resize(packs_before);   // nothing reads this convolution's fp32 operands
     return UMX_OK;
 }
 

@@ -377,9 +377,10 @@ hipError_t launch_absmax(const float* x, size_t n, unsigned* omax, hipStream_t s
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Forward / input-gradient convolutions on conv_f16x3 (round 4).  The filters change every step: pack_weights_kernel rebuilds the
-// fp32 operands [tap][Cp][Np] from the masters as before, and this kernel gathers them into the LDS-image order the planner laid
-// out once (HWRef, umx_internal.h), scaled by the power of two that puts the layer's largest |w| of the START of training in
+// Forward / input-gradient convolutions on conv_f16x3 (round 4).  The filters change every step: this kernel gathers them into
+// the LDS-image order the planner laid out once (HWRef, umx_internal.h) -- straight from the master tensors where the trainer
+// could rewrite the planner's references into master coordinates (estride != 0), else from the fp32 operands [tap][Cp][Np]
+// pack_weights_kernel rebuilds -- scaled by the power of two that puts the layer's largest |w| of the START of training in
 // [2^10, 2^11) -- 32 x headroom; a weight that outgrows binary16 raises the range flag -- as (hi, lo) binary16 pairs.
 // One thread per 16-byte unit; consecutive lanes read consecutive output channels of the fp32 operand (coalesced per element).
 // ------------------------------------------------------------------------------------------------------------
@@ -389,13 +390,17 @@ __global__ void __launch_bounds__(256) repack_f16x3_kernel(const RepackDesc* __r
     for (int i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += gridDim.x * 256) {
         const HWRefDev r = d.refs[i];
         const float* const src = d.arr[r.arr] + r.base;
+        const float* const src2 = d.arr2[r.arr] ? d.arr2[r.arr] + r.base : nullptr;
+        const int es = d.estride[r.arr] ? d.estride[r.arr] : d.stride;
         union { _Float16 h[8]; uint4 u; } vh, vl;
         vh.u = make_uint4(0, 0, 0, 0);
         vl.u = make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             if (e < (int)r.nvalid) {
-                const float v = src[(size_t)e * d.stride] * d.scale;
+                float w = src[(size_t)e * es];
+                if (src2) w += src2[(size_t)e * es];   // (the sum pack_weights_kernel makes, same order)
+                const float v = w * d.scale;
                 bad = bad || !(fabsf(v) < 60000.f);
                 vh.h[e] = (_Float16)v;
                 vl.h[e] = (_Float16)(v - (float)vh.h[e]);
