@@ -340,6 +340,7 @@ struct WgradParams {
     int* overflow;                // set when a scaled operand leaves the binary16 range
     // plane-staged variant (planes = 1, f16 only): the operands as (hi, lo) binary16 NHWC planes with XCs / GCs stored channels
     // (multiples of 8, pad channels zero) and the inverse of the power-of-two scale each was stored with (NULL: unscaled)
+    int thin;                     // > 0: wgrad_thin_kernel (Cx <= 4, one slab group): rows of the image per workgroup
     int planes;
     const _Float16 *Xhi, *Xlo, *Ghi, *Glo;
     int XCs, GCs;

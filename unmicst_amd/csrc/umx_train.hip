@@ -353,7 +353,13 @@ int setup_hconv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int 
             if (h.xcd_order == 2) h.xcd_order = 1;
             tr->split_floats = std::max(tr->split_floats, (size_t)S * h.split_stride);
         }
-        if (getenv("UMX_DEBUG_PLAN")) fprintf(stderr, "[umx train] %s: %ld workgroups, K split %d\n", what, wgs, S);
+        if (getenv("UMX_DEBUG_PLAN")) {
+            int nk = 0;
+            for (int ph = 0; ph < nphase; ++ph)
+                for (int si = 0; si < h.ph[ph].nstages; ++si) nk += L.stages_host[h.ph[ph].stage0 + si].nk;
+            fprintf(stderr, "[umx train] %s%s: %d x %d -> %d ch, %d phase(s), NT %d x %d blocks, %d k-steps, %ld workgroups, K split %d\n",
+                    what, tr->cur_bwd ? " (backward)" : "", H, W, Cout, nphase, h.NT, h.nblocks, nk, wgs, S);
+        }
     }
     std::vector<HStage>().swap(L.stages_host);
     tc.hidx = (int)tr->hls.size();

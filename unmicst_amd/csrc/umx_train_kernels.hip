@@ -1276,6 +1276,84 @@ __global__ void __launch_bounds__(256, 2) wgrad_mfma_f32(const WgradParams p) {
 }
 
 
+// ------------------------------------------------------------------------------------------------ weight gradient, thin X
+// The first layer (and the v2 graph's top skip connection) has 1 - 4 input channels: a 16-channel MFMA tile is 6 - 25 % full and
+// the 128-pixel tiles of the kernel above spend their time staging (165 - 277 us for 2 x 36 channels at 8 x 256 x 256, the last
+// kernel of the backward pass with nothing left to hide behind).  Here the GEMM runs on the vector ALUs: a workgroup owns `thin`
+// whole image rows, stages their X halo (a few KB) in LDS, and thread (output channel co, pixel group pg) walks the strip's
+// pixels pg, pg + PG, ... with one coalesced load of G per pixel and nslab * CX broadcast LDS reads + FMAs.  The PG partial sums
+// are added in pixel-group order; the slices by wgrad_reduce_kernel as before (same ws layout).
+template <int CX>
+__global__ void __launch_bounds__(256) wgrad_thin_kernel(const WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int R = p.thin, hw = p.hw, hh = p.hh;
+    const int slice = blockIdx.x;
+    const int row0 = slice * R;                       // global row = img * H + y; R divides H: a strip stays inside one image
+    const int img = row0 / p.H, y0 = row0 - img * p.H;
+    const int ns = p.gcount[0];
+    const int coff = p.coff[0];
+    float* const Xl = smem;                            // [hh][hw][CX]
+    float* const red = smem + ((hh * hw * CX + 3) & ~3);   // [PG][ns * CX][Cg]
+    for (int e = tid; e < hh * hw; e += 256) {
+        const int hy = e / hw, hx = e - hy * hw;
+        const int gy = y0 + p.ymin + hy, gx = p.xmin + hx;
+        const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const float* src = p.X + ((size_t)(img * p.H + (in ? gy : 0)) * p.W + (in ? gx : 0)) * p.Cxt + coff;
+#pragma unroll
+        for (int c = 0; c < CX; ++c) Xl[e * CX + c] = in ? src[c] : 0.f;
+    }
+    int so[kWgNS];
+#pragma unroll
+    for (int s = 0; s < kWgNS; ++s) {
+        const int sb = s < ns ? s : 0;
+        so[s] = __builtin_amdgcn_readfirstlane(((p.dy[sb] - p.ymin) * hw + (p.dx[sb] - p.xmin)) * CX);
+    }
+    __syncthreads();
+    const int Cg = p.Cg, PG = 256 / Cg;
+    const int pg = tid / Cg, co = tid - pg * Cg;
+    float acc[kWgNS][CX];
+#pragma unroll
+    for (int s = 0; s < kWgNS; ++s)
+#pragma unroll
+        for (int c = 0; c < CX; ++c) acc[s][c] = 0.f;
+    if (pg < PG) {
+        const int npx = R * p.W;
+        const int wl = 31 - __builtin_clz(p.W);      // W is a power of two (wgrad_setup)
+        const float* const G = p.G + (size_t)row0 * p.W * Cg + co;
+#pragma unroll 4
+        for (int px = pg; px < npx; px += PG) {
+            const float g = G[(size_t)px * Cg];
+            const int y = px >> wl, x = px & (p.W - 1);
+            const float* const xp = Xl + (y * hw + x) * CX;
+#pragma unroll
+            for (int s = 0; s < kWgNS; ++s)
+                if (s < ns) {
+#pragma unroll
+                    for (int c = 0; c < CX; ++c) acc[s][c] = __builtin_fmaf(xp[so[s] + c], g, acc[s][c]);
+                }
+        }
+#pragma unroll
+        for (int s = 0; s < kWgNS; ++s)
+            if (s < ns) {
+#pragma unroll
+                for (int c = 0; c < CX; ++c) red[((size_t)pg * ns * CX + s * CX + c) * Cg + co] = acc[s][c];
+            }
+    }
+    __syncthreads();
+    const int nout = ns * CX * Cg;                     // (s, ci, co) in the order of the ws slab: [slab][Cx][Cg]
+    float* const dst = p.ws + (size_t)slice * p.nslab * CX * Cg;
+    for (int e = tid; e < nout; e += 256) {
+        float t = red[e];
+        for (int j = 1; j < PG; ++j) t += red[(size_t)j * nout + e];
+        dst[e] = t;
+    }
+}
+
+static size_t wgrad_thin_lds(const WgradParams& p) {
+    return sizeof(float) * ((size_t)((p.hh * p.hw * p.Cx + 3) & ~3) + (size_t)(256 / p.Cg) * p.gcount[0] * p.Cx * p.Cg);
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient, f16x3
 // The same GEMM on the binary16 matrix cores with fp32-equivalent products: x*g = xh*gh + xh*gl + xl*gh, (hi, lo) exact
 // binary16 pairs, fp32 accumulation (the scheme of conv_f16x3).  One v_mfma_f32_16x16x32_f16 covers
@@ -1618,6 +1696,28 @@ bool wgrad_setup(WgradParams* p, std::string* why) {
         s += n;
     }
     p->f16 = 0;
+    p->thin = 0;
+    if (p->Cx <= 4 && p->ngroups == 1 && p->Cg <= 128 && (p->W & (p->W - 1)) == 0 && !getenv("UMX_TRAIN_WGRAD_NO_THIN")) {
+        // whole rows per workgroup, ~1024 workgroups, the strip's halo + the partial sums inside 64 KB of LDS
+        int R = 1;
+        while (R * 2 <= p->H && p->H % (R * 2) == 0 && (long)p->B * p->H / (R * 2) >= 1024) R *= 2;
+        WgradParams q = *p;
+        for (;; R /= 2) {
+            q.thin = R;
+            q.hh = R + ymax - ymin;
+            q.hw = p->W + xmax - xmin;
+            if (wgrad_thin_lds(q) <= 64 * 1024 || R == 1) break;
+        }
+        if (wgrad_thin_lds(q) <= 64 * 1024) {
+            p->thin = q.thin; p->hh = q.hh; p->hw = q.hw;
+            p->imgplane = p->hh * p->hw;
+            p->nslices = p->B * p->H / p->thin;
+            p->ntiles = p->nslices;
+            p->tiles_per_slice = 1;
+            p->mi = 1;
+            return true;
+        }
+    }
     if (TW >= 8 && p->Cx > 4 && !getenv("UMX_TRAIN_WGRAD_F32")) {
         auto stride_halves = [](int halves) { int dw = (halves + 1) / 2; while (dw % 16 != 8) ++dw; return 2 * dw; };
         p->hp = (p->hw + 7) / 8 * 8;
@@ -1677,6 +1777,18 @@ static hipError_t launch_wgrad_mi(const WgradParams& p, hipStream_t stream) {
 }
 
 hipError_t launch_wgrad(const WgradParams& p, hipStream_t stream) {
+    if (p.thin > 0) {
+        const size_t lds = wgrad_thin_lds(p);
+        const dim3 grid((unsigned)p.nslices);
+        switch (p.Cx) {
+            case 1: hipLaunchKernelGGL(wgrad_thin_kernel<1>, grid, dim3(256), lds, stream, p); break;
+            case 2: hipLaunchKernelGGL(wgrad_thin_kernel<2>, grid, dim3(256), lds, stream, p); break;
+            case 3: hipLaunchKernelGGL(wgrad_thin_kernel<3>, grid, dim3(256), lds, stream, p); break;
+            case 4: hipLaunchKernelGGL(wgrad_thin_kernel<4>, grid, dim3(256), lds, stream, p); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if (p.f16) {
         static bool attr_set = false;
         if (!attr_set) {
