@@ -1281,9 +1281,9 @@ __global__ void __launch_bounds__(256, 2) wgrad_mfma_f32(const WgradParams p) {
 // the 128-pixel tiles of the kernel above spend their time staging (165 - 277 us for 2 x 36 channels at 8 x 256 x 256, the last
 // kernel of the backward pass with nothing left to hide behind).  Here the GEMM runs on the vector ALUs: a workgroup owns `thin`
 // whole image rows, stages their X halo (a few KB) in LDS, and thread (output channel co, pixel group pg) walks the strip's
-// pixels pg, pg + PG, ... with one coalesced load of G per pixel and nslab * CX broadcast LDS reads + FMAs.  The PG partial sums
-// are added in pixel-group order; the slices by wgrad_reduce_kernel as before (same ws layout).
-template <int CX>
+// pixels pg, pg + PG, ... with one coalesced load of G (four output channels) per pixel and nslab * CX broadcast LDS reads.  The PG
+// partial sums are added in a fixed order; the slices by wgrad_reduce_kernel as before (same ws layout).
+template <int CX, int V>   // V output channels per thread: 4 (Cg % 4 == 0: 16-byte loads of G) or 1
 __global__ void __launch_bounds__(256) wgrad_thin_kernel(const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -1294,7 +1294,7 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(const WgradParams p) {
     const int ns = p.gcount[0];
     const int coff = p.coff[0];
     float* const Xl = smem;                            // [hh][hw][CX]
-    float* const red = smem + ((hh * hw * CX + 3) & ~3);   // [PG][ns * CX][Cg]
+    float* const red = smem + ((hh * hw * CX + 3) & ~3);   // [ceil(PG / 4)][ns * CX][Cg]
     for (int e = tid; e < hh * hw; e += 256) {
         const int hy = e / hw, hx = e - hy * hw;
         const int gy = y0 + p.ymin + hy, gx = p.xmin + hx;
@@ -1310,48 +1310,121 @@ __global__ void __launch_bounds__(256) wgrad_thin_kernel(const WgradParams p) {
         so[s] = __builtin_amdgcn_readfirstlane(((p.dy[sb] - p.ymin) * hw + (p.dx[sb] - p.xmin)) * CX);
     }
     __syncthreads();
-    const int Cg = p.Cg, PG = 256 / Cg;
-    const int pg = tid / Cg, co = tid - pg * Cg;
-    float acc[kWgNS][CX];
+    const int Cg = p.Cg, Q = Cg / V, PG = 256 / Q;
+    const int pg = tid / Q, co = (tid - pg * Q) * V;
+    float acc[kWgNS][CX][V];
 #pragma unroll
     for (int s = 0; s < kWgNS; ++s)
 #pragma unroll
-        for (int c = 0; c < CX; ++c) acc[s][c] = 0.f;
-    if (pg < PG) {
+        for (int c = 0; c < CX; ++c)
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[s][c][v] = 0.f;
+    const int nout = ns * CX * Cg;                     // (s, ci, co) in the order of the ws slab: [slab][Cx][Cg]
+    {   // branch-free: every thread walks ceil(npx / PG) pixels, a pixel past the strip is clamped and its G taken as zero (the four
+        // threads past the last pixel group do the same and drop their sums) -- the compiler keeps two loads of G in flight
         const int npx = R * p.W;
         const int wl = 31 - __builtin_clz(p.W);      // W is a power of two (wgrad_setup)
         const float* const G = p.G + (size_t)row0 * p.W * Cg + co;
-#pragma unroll 4
-        for (int px = pg; px < npx; px += PG) {
-            const float g = G[(size_t)px * Cg];
-            const int y = px >> wl, x = px & (p.W - 1);
+        auto load_g = [&](int px, float* g) {
+            const int pc = min(px, npx - 1);
+            if constexpr (V == 4) {
+                const float4 g4 = *reinterpret_cast<const float4*>(G + (size_t)pc * Cg);
+                g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
+            } else {
+                g[0] = G[(size_t)pc * Cg];
+            }
+        };
+        auto step = [&](int px, const float* gin) {
+            const bool live = px < npx;
+            const int pc = min(px, npx - 1);
+            float g[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) g[v] = live ? gin[v] : 0.f;
+            const int y = pc >> wl, x = pc & (p.W - 1);
             const float* const xp = Xl + (y * hw + x) * CX;
+            float xv[kWgNS][CX];   // (all kWgNS slabs: a slab past ns re-reads slab 0 and its sums are dropped)
+#pragma unroll
+            for (int s = 0; s < kWgNS; ++s)
+#pragma unroll
+                for (int c = 0; c < CX; ++c) xv[s][c] = xp[so[s] + c];
+#pragma unroll
+            for (int s = 0; s < kWgNS; ++s)
+#pragma unroll
+                for (int c = 0; c < CX; ++c)
+#pragma unroll
+                    for (int v = 0; v < V; ++v) acc[s][c][v] = __builtin_fmaf(xv[s][c], g[v], acc[s][c][v]);
+        };
+        const int niter = (npx + PG - 1) / PG;
+        int ahead = 2 * PG;   // (opaque: hipcc otherwise proves the prefetch is the next iteration's own load and sinks it back there)
+        asm volatile("" : "+s"(ahead));
+        float ga[V], gb[V];
+        load_g(pg, ga);
+        load_g(pg + PG, gb);
+        for (int i = 0; i < niter; i += 2) {
+            const int px = pg + i * PG;
+            float g0[V], g1[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) { g0[v] = ga[v]; g1[v] = gb[v]; }
+            load_g(px + ahead, ga);
+            load_g(px + ahead + PG, gb);
+            step(px, g0);
+            step(px + PG, g1);
+        }
+    }
+    // the PG partial sums, in a fixed order and through S = ceil(PG / 4) LDS slots (a slot per group would cost 36 KB for 36 output
+    // channels and leave a CU three workgroups, one short of the 1024-workgroup launch fitting in one round): the top m = min(S, n - S)
+    // groups are folded into the bottom m until S are left, and those are added in group order
+    const int S = (PG + 3) / 4;
+    auto slot = [&](int g, int s, int c, int v) { return (size_t)g * nout + (size_t)(s * CX + c) * Cg + co + v; };
+    int n = PG;
+    while (n > S) {
+        const int m = min(S, n - S);
+        if (pg >= n - m && pg < n) {
 #pragma unroll
             for (int s = 0; s < kWgNS; ++s)
                 if (s < ns) {
 #pragma unroll
-                    for (int c = 0; c < CX; ++c) acc[s][c] = __builtin_fmaf(xp[so[s] + c], g, acc[s][c]);
+                    for (int c = 0; c < CX; ++c)
+#pragma unroll
+                        for (int v = 0; v < V; ++v) red[slot(pg - (n - m), s, c, v)] = acc[s][c][v];
                 }
         }
+        __syncthreads();
+        if (pg < m) {
+#pragma unroll
+            for (int s = 0; s < kWgNS; ++s)
+                if (s < ns) {
+#pragma unroll
+                    for (int c = 0; c < CX; ++c)
+#pragma unroll
+                        for (int v = 0; v < V; ++v) acc[s][c][v] += red[slot(pg, s, c, v)];
+                }
+        }
+        __syncthreads();
+        n -= m;
+    }
+    if (pg < n) {
 #pragma unroll
         for (int s = 0; s < kWgNS; ++s)
             if (s < ns) {
 #pragma unroll
-                for (int c = 0; c < CX; ++c) red[((size_t)pg * ns * CX + s * CX + c) * Cg + co] = acc[s][c];
+                for (int c = 0; c < CX; ++c)
+#pragma unroll
+                    for (int v = 0; v < V; ++v) red[slot(pg, s, c, v)] = acc[s][c][v];
             }
     }
     __syncthreads();
-    const int nout = ns * CX * Cg;                     // (s, ci, co) in the order of the ws slab: [slab][Cx][Cg]
     float* const dst = p.ws + (size_t)slice * p.nslab * CX * Cg;
     for (int e = tid; e < nout; e += 256) {
         float t = red[e];
-        for (int j = 1; j < PG; ++j) t += red[(size_t)j * nout + e];
+        for (int j = 1; j < n; ++j) t += red[(size_t)j * nout + e];
         dst[e] = t;
     }
 }
 
 static size_t wgrad_thin_lds(const WgradParams& p) {
-    return sizeof(float) * ((size_t)((p.hh * p.hw * p.Cx + 3) & ~3) + (size_t)(256 / p.Cg) * p.gcount[0] * p.Cx * p.Cg);
+    const int V = p.Cg % 4 == 0 ? 4 : 1, PG = 256 / (p.Cg / V);
+    return sizeof(float) * ((size_t)((p.hh * p.hw * p.Cx + 3) & ~3) + (size_t)((PG + 3) / 4) * p.gcount[0] * p.Cx * p.Cg);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient, f16x3
@@ -1780,13 +1853,19 @@ hipError_t launch_wgrad(const WgradParams& p, hipStream_t stream) {
     if (p.thin > 0) {
         const size_t lds = wgrad_thin_lds(p);
         const dim3 grid((unsigned)p.nslices);
+        const bool v4 = p.Cg % 4 == 0;
+#define UMX_THIN(CX) \
+    if (v4) hipLaunchKernelGGL((wgrad_thin_kernel<CX, 4>), grid, dim3(256), lds, stream, p); \
+    else hipLaunchKernelGGL((wgrad_thin_kernel<CX, 1>), grid, dim3(256), lds, stream, p); \
+    break;
         switch (p.Cx) {
-            case 1: hipLaunchKernelGGL(wgrad_thin_kernel<1>, grid, dim3(256), lds, stream, p); break;
-            case 2: hipLaunchKernelGGL(wgrad_thin_kernel<2>, grid, dim3(256), lds, stream, p); break;
-            case 3: hipLaunchKernelGGL(wgrad_thin_kernel<3>, grid, dim3(256), lds, stream, p); break;
-            case 4: hipLaunchKernelGGL(wgrad_thin_kernel<4>, grid, dim3(256), lds, stream, p); break;
+            case 1: UMX_THIN(1)
+            case 2: UMX_THIN(2)
+            case 3: UMX_THIN(3)
+            case 4: UMX_THIN(4)
             default: return hipErrorInvalidValue;
         }
+#undef UMX_THIN
         return hipGetLastError();
     }
     if (p.f16) {
