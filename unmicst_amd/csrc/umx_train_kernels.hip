@@ -63,7 +63,9 @@ static inline ChanLayout chan_layout(int C) {
 
 int chan_blocks(size_t N, int C) {
     const ChanLayout l = chan_layout(C);
-    const size_t want = N / ((size_t)l.k * 32) + 1;
+    // (a handful of rows per block: the deep layers have 512 - 2048 rows, and 17 blocks walking 30 rows each left their
+    //  activation-backward kernel latency-bound at 158 us for 1.2 MB -- round 4 time line)
+    const size_t want = N / ((size_t)l.k * 4) + 1;
     const size_t cap = std::max(64, 1024 / l.cblocks);
     return (int)std::min<size_t>(cap, std::max<size_t>(1, want));
 }
@@ -840,9 +842,41 @@ __global__ void __launch_bounds__(256) leaky_bwd_s2d_kernel(const float* __restr
     if (gmax) block_absmax_to(gmax, mx);
 }
 
+// C % 4 == 0 and < 2^32 elements (every layer of the shipped widths): four channels per thread, 16-byte accesses, 32-bit index
+// arithmetic (the scalar kernel: 146 us for 3 x 75 MB at 8 x 256 x 256 x 36, this one the memory time)
+__global__ void __launch_bounds__(256) leaky_bwd_s2d_v4_kernel(const float4* __restrict__ d_us, const float4* __restrict__ us,
+                                                               unsigned S, unsigned Q, float4* __restrict__ gS, unsigned n4, unsigned* gmax) {
+    float mx = 0.f;
+    for (unsigned e = blockIdx.x * 256 + threadIdx.x; e < n4; e += gridDim.x * 256) {
+        const unsigned q4 = e % Q;
+        unsigned r = e / Q;
+        const unsigned q = r & 3u; r >>= 2;
+        const unsigned j = r % S; r /= S;
+        const unsigned i = r % S;
+        const unsigned b = r / S;
+        const unsigned src = ((b * (2 * S) + 2 * i + (q >> 1)) * (2 * S) + 2 * j + (q & 1u)) * Q + q4;
+        const float4 d = d_us[src], u = us[src];
+        float4 v;
+        v.x = d.x * (u.x > 0.f ? 1.f : 0.2f);
+        v.y = d.y * (u.y > 0.f ? 1.f : 0.2f);
+        v.z = d.z * (u.z > 0.f ? 1.f : 0.2f);
+        v.w = d.w * (u.w > 0.f ? 1.f : 0.2f);
+        gS[e] = v;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (gmax) block_absmax_to(gmax, mx);
+}
+
 hipError_t launch_leaky_bwd_s2d_max(const float* d_us, const float* us, int B, int S, int C, float* gS, unsigned* gmax,
                                     hipStream_t stream) {
     const size_t n = (size_t)B * S * S * 4 * C;
+    if (C % 4 == 0 && n < 0xffffffffull && !getenv("UMX_TRAIN_ACT_SCALAR")) {
+        const unsigned n4 = (unsigned)(n / 4);
+        const unsigned blocks = std::min(2048u, (n4 + 255u) / 256u);
+        hipLaunchKernelGGL(leaky_bwd_s2d_v4_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, reinterpret_cast<const float4*>(d_us),
+                           reinterpret_cast<const float4*>(us), (unsigned)S, (unsigned)(C / 4), reinterpret_cast<float4*>(gS), n4, gmax);
+        return hipGetLastError();
+    }
     const unsigned blocks = (unsigned)std::min<size_t>(1024, (n + 255) / 256);
     hipLaunchKernelGGL(leaky_bwd_s2d_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, d_us, us, S, C, gS, n, gmax);
     return hipGetLastError();
