@@ -49,6 +49,8 @@ struct H16 {                         // (hi, lo) binary16 NHWC planes of one ten
     int Cs = 0;
 };
 
+constexpr int kSlots = 4;   // dz / gS buffers the main stream may run ahead of the weight gradients by (UMX_TRAIN_SLOTS: 2 .. 4)
+
 struct TapSet {
     std::vector<std::pair<int, int>> off;   // (dy, dx) input offsets
     std::vector<int> m;                     // master tap index per (tap, parity) : size off.size() * npar
@@ -94,12 +96,13 @@ struct umx_trainer {
     float *d_labels = nullptr, *d_weights = nullptr, *d_probs = nullptr, *d_dt = nullptr;
     std::vector<float*> dskip;          // gradient w.r.t. ds[idx] from the up path (idx >= 1)
     float *DA = nullptr, *DB = nullptr, *DZ = nullptr, *GS = nullptr;
-    float* DZ2[2] = {nullptr, nullptr};   // gradient w.r.t. a conv output, double-buffered: the weight gradients of layer l
-    float* GS2[2] = {nullptr, nullptr};   // run on the side stream while the main stream moves on to layer l+1
+    float* DZ2[kSlots] = {};   // gradient w.r.t. a conv output, one per slot: the weight gradients of layer l run on a side stream
+    float* GS2[kSlots] = {};   // while the main stream moves on to layers l+1 .. l+nslots-1
+    int nslots = kSlots;
     hipStream_t side = nullptr;
     hipStream_t side2 = nullptr;          // a second side stream: the dz / gS slots alternate between the two (UMX_TRAIN_ONE_SIDE=1: one)
     hipEvent_t ev_join2 = nullptr;
-    hipEvent_t ev_dz[2] = {nullptr, nullptr}, ev_gs[2] = {nullptr, nullptr}, ev_side[2] = {nullptr, nullptr}, ev_join = nullptr;
+    hipEvent_t ev_dz[kSlots] = {}, ev_gs[kSlots] = {}, ev_side[kSlots] = {}, ev_join = nullptr;
     bool overlap = true;
     double* d_part = nullptr;  size_t part_doubles = 0;
     double* d_part2 = nullptr;          // the side stream's own partial sums (regularisation loss under the forward pass)
@@ -128,8 +131,8 @@ struct umx_trainer {
     int n_fwd_packs = 0, n_fwd_rdescs = 0;   // descriptors [0, n_fwd) serve the forward pass, the rest the backward pass only
     hipEvent_t ev_begin = nullptr, ev_packed = nullptr;
     std::vector<H16> h_ds, h_us, h_cv;  // planes of ds[i], us[idx], cv[idx]
-    H16 h_b, h_dz[2], h_gs[2];
-    float* d_xinv = nullptr;            // [4] inverse scales of the dz / gS slots' planes, written by split_dyn_kernel
+    H16 h_b, h_dz[kSlots], h_gs[kSlots];
+    float* d_xinv = nullptr;            // [2 * kSlots] inverse scales of the dz / gS slots' planes, written by split_dyn_kernel
     // launches
     std::vector<TConv> c_fwd_d, c_dg_d, c_T, c_fwd_u, c_dg_us, c_dg_skip, c_dg_T;
     TConv c_fwd_b, c_dg_b;
@@ -774,9 +777,9 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
     // (two side streams, one per dz / gS slot: consecutive layers' weight gradients -- small grids that leave most CUs idle at a batch
     // of 8 -- run next to each other as well as next to the main stream)
     hipStream_t wss[2] = {tr->overlap ? tr->side : st, tr->overlap ? (tr->side2 ? tr->side2 : tr->side) : st};
-#define ws wss[slot]
+#define ws wss[slot & 1]
     int slot = 0;
-    bool used[2] = {false, false};
+    bool used[kSlots] = {};
     auto dz_begin = [&](int sl) -> int {      // main: the slot's previous consumers on the side stream are done
         if (tr->overlap && used[sl]) T_HIP(tr, hipStreamWaitEvent(st, tr->ev_side[sl], 0));
         return UMX_OK;
@@ -784,12 +787,12 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
     auto dz_ready = [&](int sl) -> int {      // main has written DZ2[sl]; the side stream may read it
         if (tr->overlap) {
             T_HIP(tr, hipEventRecord(tr->ev_dz[sl], st));
-            T_HIP(tr, hipStreamWaitEvent(wss[sl], tr->ev_dz[sl], 0));
+            T_HIP(tr, hipStreamWaitEvent(wss[sl & 1], tr->ev_dz[sl], 0));
         }
         return UMX_OK;
     };
     auto side_done = [&](int sl) -> int {
-        if (tr->overlap) T_HIP(tr, hipEventRecord(tr->ev_side[sl], wss[sl]));
+        if (tr->overlap) T_HIP(tr, hipEventRecord(tr->ev_side[sl], wss[sl & 1]));
         used[sl] = true;
         return UMX_OK;
     };
@@ -820,7 +823,7 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         const bool gs_planes = tr->hconv && (tr->c_dg_T[idx].hidx >= 0 || tr->wg_planes);
         if (gs_planes) {   // (in front of the event: the transposed convolution's weight gradient stages from these planes too)
             tr->h_gs[slot].Cs = round_up(4 * Cup, 8);
-            T_TRY(to_h16(tr, gs, (size_t)B * (S / 2) * (S / 2), 4 * Cup, tr->h_gs[slot], tr->smax[idx], tr->d_xinv + 2 + slot, st));
+            T_TRY(to_h16(tr, gs, (size_t)B * (S / 2) * (S / 2), 4 * Cup, tr->h_gs[slot], tr->smax[idx], tr->d_xinv + kSlots + slot, st));
         }
         if (tr->overlap) {
             T_HIP(tr, hipEventRecord(tr->ev_gs[slot], st));
@@ -829,12 +832,12 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         {
             const H16* const pin = !tr->hconv ? nullptr : idx == L - 1 ? &tr->h_b : &tr->h_cv[idx + 1];
             T_TRY(run_wgrad(tr, tr->wg_T[idx], gs, layer_in, Cup, 0, tr->o_wt[idx], o.reg_up, SIZE_MAX, tr->smax[idx],
-                            idx == L - 1 ? tr->bmax : tr->cvmax[idx + 1], ws, gs_planes ? &tr->h_gs[slot] : nullptr, tr->d_xinv + 2 + slot, pin,
+                            idx == L - 1 ? tr->bmax : tr->cvmax[idx + 1], ws, gs_planes ? &tr->h_gs[slot] : nullptr, tr->d_xinv + kSlots + slot, pin,
                             nullptr));
         }
         T_TRY(side_done(slot));
-        T_TRY(dgrad(tr->c_dg_T[idx], gs, tr->h_gs[slot], tr->d_xinv + 2 + slot, tr->DA));
-        slot ^= 1;
+        T_TRY(dgrad(tr->c_dg_T[idx], gs, tr->h_gs[slot], tr->d_xinv + kSlots + slot, tr->DA));
+        slot = (slot + 1) % tr->nslots;
         S /= 2;
     }
     {   // bottom layer
@@ -848,7 +851,7 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
                         tr->hconv ? &tr->h_ds[L] : nullptr, nullptr, tr->hconv ? &tr->h_dz[slot] : nullptr, tr->d_xinv + slot));
         T_TRY(side_done(slot));
         T_TRY(dgrad(tr->c_dg_b, dz, tr->h_dz[slot], tr->d_xinv + slot, tr->DB));
-        slot ^= 1;
+        slot = (slot + 1) % tr->nslots;
     }
     for (int i = L - 1; i >= 0; --i) {     // down layers
         BnSite& s = tr->bn_d[i];
@@ -866,7 +869,7 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         T_TRY(side_done(slot));
         S *= 2;
         if (i >= 1) T_TRY(dgrad(tr->c_dg_d[i], dz, tr->h_dz[slot], tr->d_xinv + slot, tr->DB));
-        slot ^= 1;
+        slot = (slot + 1) % tr->nslots;
     }
 #undef ws
     if (tr->overlap) {   // join: the optimiser (and the caller) see every gradient
@@ -966,6 +969,7 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
     tr->ds.assign(L + 1, nullptr);
     tr->bn_d.resize(L); tr->bn_u.resize(L);
     tr->us.assign(L, nullptr); tr->cv.assign(L, nullptr); tr->dskip.assign(L, nullptr);
+    if (const char* e = getenv("UMX_TRAIN_SLOTS")) tr->nslots = std::max(2, std::min(kSlots, atoi(e)));
     size_t max_act = (size_t)B * P * P * std::max(n[0], K);
     int S = P;
     for (int i = 0; i < L; ++i) {
@@ -996,8 +1000,10 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
     T_TRY(talloc(tr, &tr->DZ, max_act));
     T_TRY(talloc(tr, &tr->GS, max_act));
     tr->DZ2[0] = tr->DZ; tr->GS2[0] = tr->GS;
-    T_TRY(talloc(tr, &tr->DZ2[1], max_act));
-    T_TRY(talloc(tr, &tr->GS2[1], max_act));
+    for (int sl = 1; sl < tr->nslots; ++sl) {
+        T_TRY(talloc(tr, &tr->DZ2[sl], max_act));
+        T_TRY(talloc(tr, &tr->GS2[sl], max_act));
+    }
     int maxC = K;
     for (int v : n) maxC = std::max(maxC, v);
     tr->part_doubles = std::max<size_t>((size_t)1024 * 2 * maxC, (size_t)1024 * n[1] * K) + 1024;
@@ -1051,11 +1057,11 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
             if (idx >= 1) T_TRY(alloc_h16(tr, tr->h_cv[idx], (size_t)B * S2 * S2, n[idx + 1]));
             max_dz = std::max(max_dz, (size_t)B * S2 * S2 * round_up(n[idx + 1], 8));
         }
-        for (int sl = 0; sl < 2; ++sl) {   // gradient planes, one set per dz / gS slot; Cs is set per use
+        for (int sl = 0; sl < tr->nslots; ++sl) {   // gradient planes, one set per dz / gS slot; Cs is set per use
             T_TRY(tzero(tr, &tr->h_dz[sl].hi, max_dz)); T_TRY(tzero(tr, &tr->h_dz[sl].lo, max_dz));
             T_TRY(tzero(tr, &tr->h_gs[sl].hi, max_gs)); T_TRY(tzero(tr, &tr->h_gs[sl].lo, max_gs));
         }
-        T_TRY(tzero(tr, &tr->d_xinv, 4));
+        T_TRY(tzero(tr, &tr->d_xinv, 2 * kSlots));
     }
 
     // ---- conv launches
@@ -1303,8 +1309,8 @@ int umx_trainer_create(const umx_hparams* hp, const float* weight_blob, size_t b
         if (hipStreamCreateWithFlags(&tr->side, hipStreamNonBlocking) != hipSuccess) rc = tfail(tr, UMX_ERR_HIP, "hipStreamCreate failed");
         if (!getenv("UMX_TRAIN_ONE_SIDE") && hipStreamCreateWithFlags(&tr->side2, hipStreamNonBlocking) != hipSuccess)
             rc = tfail(tr, UMX_ERR_HIP, "hipStreamCreate failed");
-        hipEvent_t* evs[] = {&tr->ev_dz[0], &tr->ev_dz[1], &tr->ev_gs[0], &tr->ev_gs[1], &tr->ev_side[0], &tr->ev_side[1], &tr->ev_join,
-                             &tr->ev_begin, &tr->ev_packed, &tr->ev_join2};
+        std::vector<hipEvent_t*> evs = {&tr->ev_join, &tr->ev_begin, &tr->ev_packed, &tr->ev_join2};
+        for (int sl = 0; sl < kSlots; ++sl) { evs.push_back(&tr->ev_dz[sl]); evs.push_back(&tr->ev_gs[sl]); evs.push_back(&tr->ev_side[sl]); }
         for (hipEvent_t* e : evs)
             if (rc == UMX_OK && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess)
                 rc = tfail(tr, UMX_ERR_HIP, "hipEventCreate failed");
@@ -1331,9 +1337,11 @@ void umx_trainer_destroy(umx_trainer* tr) {
         if (tr->ev[i]) (void)hipEventDestroy(tr->ev[i]);
     if (tr->side) { (void)hipStreamSynchronize(tr->side); (void)hipStreamDestroy(tr->side); }
     if (tr->side2) { (void)hipStreamSynchronize(tr->side2); (void)hipStreamDestroy(tr->side2); }
-    for (hipEvent_t e : {tr->ev_dz[0], tr->ev_dz[1], tr->ev_gs[0], tr->ev_gs[1], tr->ev_side[0], tr->ev_side[1], tr->ev_join, tr->ev_begin,
-                         tr->ev_packed, tr->ev_join2})
+    for (hipEvent_t e : {tr->ev_join, tr->ev_begin, tr->ev_packed, tr->ev_join2})
         if (e) (void)hipEventDestroy(e);
+    for (int sl = 0; sl < kSlots; ++sl)
+        for (hipEvent_t e : {tr->ev_dz[sl], tr->ev_gs[sl], tr->ev_side[sl]})
+            if (e) (void)hipEventDestroy(e);
     if (tr->stream) (void)hipStreamDestroy(tr->stream);
     delete tr;
 }
