@@ -35,6 +35,10 @@ struct Group {           // one operand group of a launch, host description
     int C;               // channels
     std::vector<std::pair<int, int>> taps[4];  // per phase: (dy, dx) input offsets
     std::vector<float> packed[4];              // per phase: [ntaps][Cp][Np]
+    // (training) per phase, [tap][octet]: 1 = every weight of this (tap, 8 input channels) pair is a structural zero -- the input
+    // gradient of a stride-2 transposed convolution on the space-to-depth tensor has 9 real (window position, parity block) pairs
+    // of 16 -- and the planner leaves the pair out of the K loop.  Empty: none.
+    std::vector<unsigned char> dead[4];
 };
 
 // Training (umx_train.hip): where one 16-byte unit of a packed weight image comes from.  The filters change every step, so the

@@ -177,8 +177,14 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                 if (!nt) continue;
                 std::vector<Pair> pairs = carry;
                 carry.clear();
+                const std::vector<unsigned char>& dead = L.g[gi].dead[ph];
+                const int noct_g = (L.g[gi].C + 7) / 8;
                 for (int t = 0; t < nt; ++t)
-                    for (int o = o0; o < o1; ++o) pairs.push_back({gi, ph, t, o, slot, o - o0});
+                    for (int o = o0; o < o1; ++o) {
+                        if (!dead.empty() && dead[(size_t)t * noct_g + o]) continue;
+                        pairs.push_back({gi, ph, t, o, slot, o - o0});
+                    }
+                if (pairs.empty()) continue;
                 const int rem = (int)pairs.size() % 4;
                 if (rem && carry_ok && c + 1 < ch.size() && (int)pairs.size() >= 4) {
                     // stages the next chunk will have if it takes the remainder (it pads or carries on in turn)

@@ -257,6 +257,16 @@ int setup_hconv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int 
         L.g[g].src = g;
         L.g[g].C = gs[g].C;
         for (int ph = 0; ph < nphase; ++ph) L.g[g].taps[ph] = gs[g].taps[ph].off;
+        if (gs[g].npar > 1 && gs[g].Cblk % 8 == 0 && !getenv("UMX_TRAIN_KEEP_ZERO_PAIRS")) {
+            const int noct = (gs[g].C + 7) / 8;
+            for (int ph = 0; ph < nphase; ++ph) {
+                const TapSet& ts = gs[g].taps[ph];
+                L.g[g].dead[ph].assign(ts.off.size() * (size_t)noct, 0);
+                for (size_t t = 0; t < ts.off.size(); ++t)
+                    for (int o = 0; o < noct; ++o)
+                        if (ts.m[t * gs[g].npar + (size_t)(8 * o / gs[g].Cblk)] < 0) L.g[g].dead[ph][t * noct + o] = 1;
+            }
+        }
         // largest |w| the packed operand can hold now: the master tensor(s) this group reads (summed pair: the sum of the maxima)
         int ntap_master = 0;
         for (int ph = 0; ph < nphase; ++ph)
