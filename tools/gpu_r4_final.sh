@@ -12,7 +12,10 @@ for w in solo-16384 duo-4096 solo-1024 legacy-1024; do
   timeout 900 python bench.py --workload $w --steps 10 --warmup 3 --cpu-seconds 20 --breakdown > $O/bench_$w.log 2>&1
 done
 timeout 900 python bench.py --workload train-synth256 --steps 50 --warmup 5 --cpu-seconds 30 > $O/bench_train.log 2>&1
+for b in 16 32; do timeout 600 python bench.py --workload train-synth256 --train-batch $b --steps 20 --warmup 3 --cpu-seconds 0 > $O/bench_train_b$b.log 2>&1; done
 bash tools/gpu_train_prof.sh final/train_prof 8 > $O/train_prof.txt 2>&1
+bash tools/gpu_train_timeline.sh final/train_tl 8 > $O/train_tl.txt 2>&1
+bash tools/gpu_train_pmc.sh final/train_pmc > $O/train_pmc.txt 2>&1
 bash tools/gpu_pmc.sh final/pmc_synth256 --scaling weak > $O/pmc_synth256.log 2>&1
 grep -E "passed|failed" $O/pytest_gpu.log | tail -2; tail -1 $O/smoke.log
 for f in $O/bench_*.log; do echo == $f; grep "^{" $f | cut -c1-200; done
