@@ -559,10 +559,6 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
             return;
         }
         if (p.dst_f32) {   // (the planner never pairs fp32 output with the fused transposed convolution)
-            // (trainer, unsplit launches whose output the next convolution reads: the (hi, lo) NHWC planes of the same values in the
-            // same pass -- Cout % 4 == 0, the planes' pad channels stay the zeros they were allocated as -- and the tensor's max |v|)
-            const bool planes = p.dst_hi != nullptr;
-            unsigned pmax = 0u;
 #pragma unroll
             for (int m = 0; m < KMT; ++m) {
                 const int t = wave * KMT + m;
@@ -579,36 +575,12 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
                     const float* const v = res[n];
                     float* const d = p.dst_f32 + split_off + pix * p.Cout + c0;
                     if ((p.Cout & 3) == 0) {
-                        if (c0 < p.Cout) {
-                            *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
-                            if (planes) {
-                                typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-                                h2v h0, h1, l0, l1;
-                                h0[0] = (_Float16)v[0]; h0[1] = (_Float16)v[1]; h1[0] = (_Float16)v[2]; h1[1] = (_Float16)v[3];
-                                l0[0] = (_Float16)(v[0] - (float)h0[0]); l0[1] = (_Float16)(v[1] - (float)h0[1]);
-                                l1[0] = (_Float16)(v[2] - (float)h1[0]); l1[1] = (_Float16)(v[3] - (float)h1[1]);
-                                const long at = pix * p.Cds + c0;
-                                *reinterpret_cast<uint2*>(p.dst_hi + at) =
-                                    make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
-                                *reinterpret_cast<uint2*>(p.dst_lo + at) =
-                                    make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) pmax = max(pmax, __float_as_uint(v[r]) & 0x7fffffffu);
-                            }
-                        }
+                        if (c0 < p.Cout) *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (c0 + r < p.Cout) d[r] = v[r];
                     }
-                }
-            }
-            if (planes) {
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) pmax = max(pmax, (unsigned)__shfl_xor((int)pmax, off));
-                if (lane == 0) {
-                    if (p.omax && pmax > *reinterpret_cast<volatile unsigned*>(p.omax)) atomicMax(p.omax, pmax);
-                    if (pmax >= 0x476a6000u) atomicOr(p.overflow_flag, 1);   // (|v| >= 60000, infinity or NaN)
                 }
             }
             return;

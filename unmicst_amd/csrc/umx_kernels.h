@@ -141,7 +141,6 @@ struct HConvParams {
     const float* dyn[2];         // fp32 output only (the trainer's launches): non-NULL device scalars multiplied into pre_s when the
                                  // epilogue runs -- the power-of-two scales of this step's repacked weights and of a gradient tensor's
                                  // (hi, lo) planes, both chosen on the device
-    unsigned* omax;              // fp32 output with dst_hi / dst_lo set as well (trainer): max |v| written, as float bits (atomicMax), or NULL
     int* overflow_flag;
     long long* dbg;              // diagnostic builds only (UMX_DEBUG_STAMPS): per-workgroup s_memtime segments, or NULL
 };
@@ -370,8 +369,7 @@ struct OptParams {
 };
 // dst[i] = act(sum_s part[s*stride + i]) : the second half of a K-split convolution
 hipError_t launch_split_reduce(const float* part, int nsplit, size_t stride, size_t n, int act, float* dst,
-                               hipStream_t stream, _Float16* hi = nullptr, _Float16* lo = nullptr, unsigned* omax = nullptr,
-                               int* overflow = nullptr);   // (hi, lo: the result's binary16 planes too, flat -- stored channels == real)
+                               hipStream_t stream);
 hipError_t launch_optimizer(const OptParams& o, float* w, const float* g, float* m, float* v, size_t n, hipStream_t stream);
 
 __host__ __device__ inline uint16_t double_to_half_rne(double d);

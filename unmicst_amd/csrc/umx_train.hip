@@ -505,10 +505,7 @@ int to_h16(umx_trainer* tr, const float* x, size_t npix, int C, const H16& h, co
     return UMX_OK;
 }
 
-// (out / omax: the output's (hi, lo) planes and max |v| written by the launch itself -- or by the K split's reduce -- where the layout
-//  allows: fp32 and stored channel counts multiples of 4, equal for the reduce; returns *planes_done accordingly)
-int run_hconv(umx_trainer* tr, TConv& tc, const H16& s0, const H16* s1, float* dst, const float* xinv, hipStream_t st,
-              const H16* out = nullptr, unsigned* omax = nullptr, bool* planes_done = nullptr) {
+int run_hconv(umx_trainer* tr, TConv& tc, const H16& s0, const H16* s1, float* dst, const float* xinv, hipStream_t st) {
     HConvParams p = tr->hls[tc.hidx].hcp;
     p.B = tr->B;
     p.overflow_flag = reinterpret_cast<int*>(tr->d_maxw + tr->n_maxw);
@@ -523,22 +520,13 @@ int run_hconv(umx_trainer* tr, TConv& tc, const H16& s0, const H16* s1, float* d
     p.dst_f32 = dst;
     p.dyn[0] = tc.winv;
     p.dyn[1] = xinv;
-    const bool want = out && out->hi && p.Cout % 4 == 0 && !getenv("UMX_TRAIN_NO_EPILOGUE_PLANES");
-    if (planes_done) *planes_done = false;
     if (p.ksplit > 1) {   // raw partial sums, then the ordered reduce applies the activation
         const int act = p.act;
         p.act = ACT_NONE;
         p.dst_f32 = tr->d_split;
         T_HIP(tr, launch_conv_f16(p, st));
-        const bool pl = want && out->Cs == p.Cout && p.split_stride % 4 == 0 && !getenv("UMX_TRAIN_ACT_SCALAR");
-        T_HIP(tr, launch_split_reduce(tr->d_split, p.ksplit, p.split_stride, p.split_stride, act, dst, st, pl ? out->hi : nullptr,
-                                      pl ? out->lo : nullptr, pl ? omax : nullptr, p.overflow_flag));
-        if (planes_done) *planes_done = pl;
+        T_HIP(tr, launch_split_reduce(tr->d_split, p.ksplit, p.split_stride, p.split_stride, act, dst, st));
         return UMX_OK;
-    }
-    if (want) {
-        p.dst_hi = out->hi; p.dst_lo = out->lo; p.Cds = out->Cs; p.omax = omax;
-        if (planes_done) *planes_done = true;
     }
     T_HIP(tr, launch_conv_f16(p, st));
     return UMX_OK;
@@ -724,17 +712,11 @@ int forward_pass(umx_trainer* tr, const float* data, bool training, bool update)
     for (int idx = L - 1; idx >= 0; --idx) {
         BnSite& s = tr->bn_u[idx];
         S *= 2;
-        // (max |us| for the split-precision weight gradient: tracked by whatever writes the planes -- the transposed convolution's
-        // own epilogue or its K split's reduce where the layout allows, else the plane split)
-        bool us_planes = false;
-        if (tr->c_T[idx].hidx >= 0)
-            T_TRY(run_hconv(tr, tr->c_T[idx], *hcur, nullptr, tr->us[idx], nullptr, st, &tr->h_us[idx], training ? tr->usmax[idx] : nullptr,
-                            &us_planes));
-        else
-            T_TRY(run_conv(tr, tr->c_T[idx], cur, nullptr, tr->us[idx]));
+        T_TRY(conv(tr->c_T[idx], cur, nullptr, hcur, nullptr, tr->us[idx]));
+        // (max |us| for the split-precision weight gradient: tracked by the plane split where there is one)
         if (training && !tr->hconv) T_HIP(tr, launch_absmax(tr->us[idx], Bz * S * S * tr->n[idx + 1], tr->usmax[idx], st));
-        if (tr->hconv && !us_planes) T_TRY(to_h16(tr, tr->us[idx], Bz * S * S, tr->n[idx + 1], tr->h_us[idx], nullptr, nullptr, st,
-                                                  training ? tr->usmax[idx] : nullptr));
+        if (tr->hconv) T_TRY(to_h16(tr, tr->us[idx], Bz * S * S, tr->n[idx + 1], tr->h_us[idx], nullptr, nullptr, st,
+                                    training ? tr->usmax[idx] : nullptr));
         T_TRY(conv(tr->c_fwd_u[idx], tr->ds[idx], tr->us[idx], tr->hconv ? &tr->h_ds[idx] : nullptr, tr->hconv ? &tr->h_us[idx] : nullptr, s.z));
         T_TRY(bn_forward_stats(tr, s, update, training));
         if (tr->hconv && idx >= 1) {

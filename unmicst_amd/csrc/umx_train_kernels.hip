@@ -2012,51 +2012,8 @@ __global__ void __launch_bounds__(256) split_reduce_kernel(const float* __restri
     dst[i] = act_of(s, act);
 }
 
-// n % 4 == 0 and 16-byte aligned slices: four sums per thread (the scalar kernel above moved 4 bytes per lane and instruction);
-// optionally the result's (hi, lo) binary16 planes in the same pass (hi != NULL: the tensor's stored channel count equals its real one,
-// so the planes are the same flat index space) with max |v| (omax, one atomicMax per block) and the range flag -- what
-// split_dyn_kernel would do to the tensor in a pass of its own.
-__global__ void __launch_bounds__(256) split_reduce_v4_kernel(const float4* __restrict__ part, int nsplit, size_t stride4, size_t n4,
-                                                              int act, float4* __restrict__ dst, uint2* __restrict__ hi,
-                                                              uint2* __restrict__ lo, unsigned* omax, int* overflow) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    float mx = 0.f;
-    if (i < n4) {
-        float4 s = part[i];
-        for (int k = 1; k < nsplit; ++k) {
-            const float4 t = part[(size_t)k * stride4 + i];
-            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-        }
-        s.x = act_of(s.x, act); s.y = act_of(s.y, act); s.z = act_of(s.z, act); s.w = act_of(s.w, act);
-        dst[i] = s;
-        if (hi) {
-            const float f[4] = {s.x, s.y, s.z, s.w};
-            union { _Float16 h[4]; uint2 u; } a, b;
-            bool bad = false;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                mx = fmaxf(mx, fabsf(f[k]));
-                bad = bad || !(fabsf(f[k]) < 60000.f);
-                a.h[k] = (_Float16)f[k];
-                b.h[k] = (_Float16)(f[k] - (float)a.h[k]);
-            }
-            hi[i] = a.u;
-            lo[i] = b.u;
-            if (bad) atomicOr(overflow, 1);
-        }
-    }
-    if (hi && omax) block_absmax_to(omax, mx);
-}
-
 hipError_t launch_split_reduce(const float* part, int nsplit, size_t stride, size_t n, int act, float* dst,
-                               hipStream_t stream, _Float16* hi, _Float16* lo, unsigned* omax, int* overflow) {
-    if (n % 4 == 0 && stride % 4 == 0 && !getenv("UMX_TRAIN_ACT_SCALAR")) {
-        hipLaunchKernelGGL(split_reduce_v4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream,
-                           reinterpret_cast<const float4*>(part), nsplit, stride / 4, n / 4, act, reinterpret_cast<float4*>(dst),
-                           reinterpret_cast<uint2*>(hi), reinterpret_cast<uint2*>(lo), omax, overflow);
-        return hipGetLastError();
-    }
-    if (hi) return hipErrorInvalidValue;   // (the caller asks for planes only where the vector kernel applies)
+                               hipStream_t stream) {
     hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, part, nsplit, stride, n,
                        act, dst);
     return hipGetLastError();
