@@ -141,6 +141,18 @@ UMX_API int umx_infer_image_dev(umx_ctx* ctx, const double* image_dev, int C_img
 UMX_API int umx_infer_image_raw(umx_ctx* ctx, const void* raw_host, int bits, int C_img, int H, int W, int rescale,
                         double mean, double std, int mode, uint8_t* out_host);
 
+/* umx_infer_image_raw with rescale != 0 and the planes' extrema handed in: range[2 * c], range[2 * c + 1] = (min, max) of plane c's
+ * raw samples, as the file reader that produced raw_host found them (the reference's drivers read the page with tifffile and call
+ * np.min / np.max on it, UnMicst1-5.py:817-821; UnMicst.py:606-610).  The call then needs no pass over the whole slide in front of its
+ * first tile: rows go up and planes come down under the tile kernels, as without a rescale.  The values are trusted (they must be
+ * the true extrema for the result to equal umx_infer_image_raw's); range == NULL is umx_infer_image_raw(rescale = 1). */
+UMX_API int umx_infer_image_raw_range(umx_ctx* ctx, const void* raw_host, int bits, int C_img, int H, int W, const uint32_t* range,
+                                      double mean, double std, int mode, uint8_t* out_host);
+
+/* (min, max) of n uint8 / uint16 samples on the host, one pass on up to 16 threads: the pair umx_infer_image_raw_range takes, for a
+ * caller whose reader did not keep it (the reference: np.min / np.max over the page, UnMicst1-5.py:817-821).  No context, no GPU. */
+UMX_API int umx_plane_range(const void* raw_host, int bits, size_t n, uint32_t* range);
+
 /* The same recipe at --scalingFactor != 1 (reference UnMicst1-5.py:813-816: resize to (int(H*sf), int(W*sf)) before the
  * inference, :850: resize of the uint8 planes back to (H, W)), with skimage.transform.resize's defaults -- order 1, mode
  * 'reflect', anti-aliasing Gaussian on shrinking axes, clip to the input range -- evaluated in float64 on the device.

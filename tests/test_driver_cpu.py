@@ -142,9 +142,11 @@ class _OracleEngine:
                                                        "replace" if mode else "accumulate", k)
                          for k in range(self.hp.nClasses)])
 
-    def infer_image_raw(self, raw, rescale, mean, std, mode=0):
+    def infer_image_raw(self, raw, rescale, mean, std, mode=0, value_range=None):
         """Host restatement of umx_infer_image_raw (the GPU test checks the real one against the general host recipe)."""
         planes = raw[None] if raw.ndim == 2 else raw
+        if value_range is not None:   # what the driver hands in must be what the recipe finds itself
+            assert [tuple(r) for r in value_range] == [(int(p.min()), int(p.max())) for p in planes]
         pre = [driver.preprocess(p, 1, -1)[1 if rescale else 0] for p in planes]
         image = np.stack(pre) if raw.ndim == 3 else pre[0]
         pm = self.infer_image(image, mean, std, mode)
@@ -248,3 +250,15 @@ def test_preview_page_by_lookup_equals_the_float64_recipe():
         assert np.array_equal(driver.preview_u8(raw), want)
     small = rng.integers(0, 4000, (10, 12)).astype(np.uint16)          # (below the table's break-even: the direct recipe)
     assert np.array_equal(driver.preview_u8(small), np.uint8(255 * (imtools.im2double(small) / np.max(imtools.im2double(small)))))
+
+
+def test_plane_range_on_threads_equals_numpy():
+    """driver.plane_range: row bands on threads for large planes, plain reductions for small ones."""
+    rng = np.random.default_rng(3)
+    big = rng.integers(7, 60000, size=(2100, 2048), dtype=np.uint16)
+    big[2099, 2047] = 65535
+    big[0, 0] = 3
+    assert driver.plane_range(big) == (3, 65535)
+    small = rng.integers(0, 255, size=(40, 50), dtype=np.uint8)
+    assert driver.plane_range(small) == (int(small.min()), int(small.max()))
+    assert np.array_equal(driver.preview_u8(big, 65535), driver.preview_u8(big))

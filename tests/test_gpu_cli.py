@@ -113,6 +113,11 @@ def test_raw_fast_path_is_bit_identical_to_the_host_recipe(workspace):
                 pm = eng.infer_image(rescaled if rescale else resized, mean, std)
                 want = np.stack([imtools.to_uint8_via_resize(pm[k], raw.shape) for k in range(hp.nClasses)])
                 assert got.dtype == np.uint8 and np.array_equal(got, want), (raw.dtype, rescale)
+                if rescale:   # the extrema handed in (umx_infer_image_raw_range: slab-wise upload under the tile kernels)
+                    ranged = eng.infer_image_raw(raw, True, mean, std, value_range=[driver.plane_range(raw)])
+                    assert np.array_equal(ranged, want), raw.dtype
+        with pytest.raises(umx.UmxError):   # not a (min, max) of 8-bit samples
+            eng.infer_image_raw(raw8, True, mean, std, value_range=[(0, 300)])
         # two planes (duo-style input) are rescaled independently
         hp2 = helpers.small_hps()["v2_duo_like"]
     blob2 = model.random_blob(hp2, seed=8)
@@ -123,6 +128,12 @@ def test_raw_fast_path_is_bit_identical_to_the_host_recipe(workspace):
         pm = eng.infer_image(pre, 0.2, 0.2)
         want = np.stack([imtools.to_uint8_via_resize(pm[k], two.shape[1:]) for k in range(hp2.nClasses)])
         assert np.array_equal(got, want)
+        assert np.array_equal(eng.infer_image_raw(two, True, 0.2, 0.2, value_range=[driver.plane_range(p) for p in two]), want)
+    # a slide of several launch groups: the ranged call goes up slab by slab, the plain one whole planes first
+    big = np.tile(raw16, (3, 2))[:1100, :1000]
+    with umx.Engine(hp, blob, max_batch=16) as eng:
+        assert np.array_equal(eng.infer_image_raw(big, True, mean, std, value_range=[driver.plane_range(big)]),
+                              eng.infer_image_raw(big, True, mean, std))
 
 
 def test_clean_checkout_runs_on_the_shipped_models_directory(workspace):

@@ -2,7 +2,47 @@
 // pre/post-processing around it, :807-854), with uploads / downloads overlapped with the tile kernels.
 #include "umx_internal.h"
 
+#include <limits>
+#include <thread>
+
 using namespace umx;
+
+// (min, max) of a host plane in one pass on a few threads -- what np.min / np.max over the page cost the reference's driver
+// (UnMicst1-5.py:817-821) twice; the loops are plain enough for the host compiler to vectorise (AVX2 where the CPU has it)
+namespace {
+template <class T>
+__attribute__((target("avx2"))) void range_avx2(const T* x, size_t n, uint32_t* lo, uint32_t* hi) {
+    T a = std::numeric_limits<T>::max(), b = 0;
+    for (size_t i = 0; i < n; ++i) { a = x[i] < a ? x[i] : a; b = x[i] > b ? x[i] : b; }
+    *lo = a; *hi = b;
+}
+template <class T>
+void range_plain(const T* x, size_t n, uint32_t* lo, uint32_t* hi) {
+    T a = std::numeric_limits<T>::max(), b = 0;
+    for (size_t i = 0; i < n; ++i) { a = x[i] < a ? x[i] : a; b = x[i] > b ? x[i] : b; }
+    *lo = a; *hi = b;
+}
+template <class T>
+void range_threads(const T* x, size_t n, uint32_t* out) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("UMX_HOST_THREADS")) nt = (unsigned)std::max(1, atoi(e));
+    nt = (unsigned)std::max<size_t>(1, std::min<size_t>(nt, n >> 20));   // >= 1 M samples per thread
+    std::vector<uint32_t> lo(nt, 0xFFFFFFFFu), hi(nt, 0u);
+    auto work = [&](unsigned t) {
+        const size_t a = n * t / nt, b = n * (t + 1) / nt;
+        if (avx2) range_avx2(x + a, b - a, &lo[t], &hi[t]);
+        else range_plain(x + a, b - a, &lo[t], &hi[t]);
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& t : th) t.join();
+    out[0] = *std::min_element(lo.begin(), lo.end());
+    out[1] = *std::max_element(hi.begin(), hi.end());
+}
+}  // namespace
+
 
 extern "C" {
 
@@ -110,7 +150,15 @@ static int host_submit_impl(umx_ctx* ctx, int slot, bool sync_call, const void* 
     int up_done = 0;
     if (src_bits) {
         for (int c = 0; c < C_img; ++c) HIP_TRY(ctx, launch_minmax_init(mm + 16 * c, ctx->stream));
-        if (rescale) {   // whole planes first: min / max per plane, reduced as the slabs arrive
+        if (rescale && ctx->range_in) {
+            // the caller's file reader saw every sample and hands the planes' (min, max) in: the words the reduction below would
+            // leave, so the slide goes up slab by slab under the tile kernels like an un-rescaled one (a synchronous rescaled
+            // call otherwise spends the whole upload -- 21 ms for the 1.07 GB metric slide -- in front of its first tile)
+            for (int c = 0; c < C_img; ++c) {
+                HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(mm + 16 * c), (int)ctx->range_in[2 * c], 1, ctx->stream));
+                HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(mm + 16 * c + 1), (int)ctx->range_in[2 * c + 1], 1, ctx->stream));
+            }
+        } else if (rescale) {   // whole planes first: min / max per plane, reduced as the slabs arrive
             for (int s = 0; s < S; ++s) {
                 const int r1 = s == S - 1 ? H : rows_needed((tcut[s + 1] - 1) / g.npc + 1);
                 if (r1 <= up_done) continue;
@@ -233,6 +281,29 @@ int umx_infer_image_raw(umx_ctx* ctx, const void* raw_host, int bits, int C_img,
     if (!(stdv != 0.0)) return fail(ctx, UMX_ERR_INVALID, "std must be non-zero");
     if (mode != UMX_MODE_ACCUMULATE && mode != UMX_MODE_REPLACE) return fail(ctx, UMX_ERR_INVALID, "bad mode %d", mode);
     return infer_host(ctx, raw_host, bits, C_img, H, W, rescale, mean, stdv, mode, UMX_STITCH_FP16_COMPAT, 1, out_host);
+}
+
+int umx_plane_range(const void* raw_host, int bits, size_t n, uint32_t* range) {
+    if (!raw_host || !range || n == 0 || (bits != 8 && bits != 16)) return UMX_ERR_INVALID;
+    if (bits == 16) range_threads(static_cast<const uint16_t*>(raw_host), n, range);
+    else range_threads(static_cast<const uint8_t*>(raw_host), n, range);
+    return UMX_OK;
+}
+
+int umx_infer_image_raw_range(umx_ctx* ctx, const void* raw_host, int bits, int C_img, int H, int W, const uint32_t* range,
+                              double mean, double stdv, int mode, uint8_t* out_host) {
+    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    if (!range) return umx_infer_image_raw(ctx, raw_host, bits, C_img, H, W, 1, mean, stdv, mode, out_host);
+    if (C_img < 1) return fail(ctx, UMX_ERR_INVALID, "bad image/out/H/W");
+    const uint32_t top = bits == 8 ? 255u : 65535u;
+    for (int c = 0; c < C_img; ++c)
+        if (range[2 * c] > range[2 * c + 1] || range[2 * c + 1] > top)
+            return fail(ctx, UMX_ERR_INVALID, "plane %d: range (%u, %u) is not a (min, max) of %d-bit samples", c, range[2 * c],
+                        range[2 * c + 1], bits);
+    ctx->range_in = range;
+    const int rc = umx_infer_image_raw(ctx, raw_host, bits, C_img, H, W, 1, mean, stdv, mode, out_host);
+    ctx->range_in = nullptr;
+    return rc;
 }
 
 // ---- the drivers' whole recipe at --scalingFactor != 1 on the device (reference UnMicst1-5.py:807-821,845-854):

@@ -147,6 +147,7 @@ struct umx_ctx {
     int ncu = 256;
     // host entry points: uploads / downloads on their own streams, slab by slab, under the tile kernels
     hipStream_t up_stream = nullptr, dn_stream = nullptr;
+    const uint32_t* range_in = nullptr;   // (during umx_infer_image_raw_range) the planes' (min, max) as the caller's reader found them
     struct HostSlot {   // device buffers + events of one in-flight host call (two slots: slide i+1 uploads while slide i computes)
         double* d_image = nullptr;  size_t image_cap = 0;
         float* d_probs = nullptr;   size_t probs_cap = 0;

@@ -148,12 +148,23 @@ class _Stages:
             print("umx-cli-timing " + json.dumps(d), file=sys.stderr)
 
 
-def preview_u8(raw: np.ndarray) -> np.ndarray:
+def plane_range(raw: np.ndarray):
+    """(min, max) of a plane in one pass on host threads (umx_plane_range): the reference's np.min / np.max over the page
+    (UnMicst1-5.py:817-821), 2 x 70 ms in numpy for a 16384 x 16384 uint16 page.  The fast path hands the pair to the engine
+    (umx_infer_image_raw_range: the upload then overlaps the inference) and reuses the maximum for the preview page."""
+    a = np.asarray(raw)
+    if a.dtype in (np.uint8, np.uint16) and a.size >= (1 << 20):
+        from . import umx as _umx
+        return _umx.plane_range(a)
+    return int(a.min()), int(a.max())
+
+
+def preview_u8(raw: np.ndarray, top_value=None) -> np.ndarray:
     """np.uint8(255 * (im2double(raw) / max)) (reference UnMicst1-5.py:809-810,861): a function of the raw value alone, so it is
     evaluated once per possible value with the same float64 operations and looked up -- four float64 passes over a 16384 x
     16384 plane (2.1 GB each) were 1.5 s of the tool's 3 s."""
     if raw.dtype in (np.uint8, np.uint16) and raw.size > (1 << 16):
-        top = imtools.im2double(np.asarray(raw.max(), dtype=raw.dtype))
+        top = imtools.im2double(np.asarray(raw.max() if top_value is None else top_value, dtype=raw.dtype))
         vals = imtools.im2double(np.arange(np.iinfo(raw.dtype).max + 1, dtype=raw.dtype))
         return np.uint8(255 * (vals / top))[raw]
     rawI = imtools.im2double(raw)
@@ -187,6 +198,7 @@ def run(tool: str, argv=None, script_dir: str = None) -> int:
         parent = os.path.dirname(os.path.dirname(image_path))
         stem, file_type = split_name(os.path.basename(image_path), spec)
 
+        top_value = None                      # max of the preview plane where the fast path has found it already
         raws = [read_plane(image_path, file_type, ch, spec) for ch in channels]
         raw = raws[-1]                        # the reference keeps the last plane read for the preview (rawI)
         raw_shape = raw.shape[:2]
@@ -210,7 +222,12 @@ def run(tool: str, argv=None, script_dir: str = None) -> int:
             if args.outlier != -1 and spec.infer_rescaled:   # (a tool that feeds the un-rescaled plane ignores the limit)
                 u8_planes = UNet2D.singleImageInferenceRawOutlier(stack_raw, args.scalingFactor, args.outlier, "accumulate")
             elif float(args.scalingFactor) == 1.0:
-                u8_planes = UNet2D.singleImageInferenceRaw(stack_raw, spec.infer_rescaled, "accumulate")
+                # (the page's extrema from the host pass the reference makes too: the engine then starts on the first rows while
+                # the rest of the page is still crossing the bus)
+                ranges = [plane_range(r) for r in raws] if spec.infer_rescaled else None
+                if ranges:
+                    top_value = ranges[-1][1]
+                u8_planes = UNet2D.singleImageInferenceRaw(stack_raw, spec.infer_rescaled, "accumulate", value_range=ranges)
             else:   # both resizes (skimage defaults) run on the device too
                 u8_planes = UNet2D.singleImageInferenceRawScaled(stack_raw, args.scalingFactor, spec.infer_rescaled, "accumulate")
 
@@ -235,11 +252,11 @@ def run(tool: str, argv=None, script_dir: str = None) -> int:
                 tiffio.imsave(stack, pm, append=page > 0)
                 if page == 1:
                     tiffio.imsave(preview, pm, append=False)
-                    tiffio.imsave(preview, preview_u8(raw), append=True)
+                    tiffio.imsave(preview, preview_u8(raw, top_value), append=True)
         else:
             cont = out_dir + "//" + stem + "_ContoursPM_" + suffix + ".tif"
             tiffio.imsave(cont, plane_u8(class_order[1]), append=False)
-            tiffio.imsave(cont, preview_u8(raw), append=True)
+            tiffio.imsave(cont, preview_u8(raw, top_value), append=True)
             tiffio.imsave(out_dir + "//" + stem + "_NucleiPM_" + suffix + ".tif", plane_u8(class_order[2]), append=False)
         st.mark("write")
     finally:

@@ -25,7 +25,7 @@ STITCH_FP16_COMPAT, STITCH_FP32 = 0, 1
 EXPORTS = [
     "umx_device_count", "umx_device_mem_info", "umx_create", "umx_create_opts", "umx_precision_of", "umx_destroy", "umx_last_error", "umx_set_stream", "umx_synchronize",
     "umx_forward_tiles", "umx_forward_tiles_dev", "umx_tile_grid", "umx_infer_image", "umx_infer_image_dev",
-    "umx_infer_image_raw", "umx_infer_image_raw_scaled", "umx_infer_image_raw_outlier", "umx_infer_image_raw_submit", "umx_infer_image_wait", "umx_tiff_lzw_decode",
+    "umx_infer_image_raw", "umx_infer_image_raw_range", "umx_plane_range", "umx_infer_image_raw_scaled", "umx_infer_image_raw_outlier", "umx_infer_image_raw_submit", "umx_infer_image_wait", "umx_tiff_lzw_decode",
     "umx_tiff_packbits_decode", "umx_shard_unique_id", "umx_shard_init", "umx_shard_init_transport", "umx_shard_fini", "umx_shard_plan",
     "umx_infer_image_sharded_dev",
     "umx_band_tiles_dev", "umx_stitch_dev", "umx_profile_enable", "umx_profile_read", "umx_prof_entry_size", "umx_test_double_to_half",
@@ -166,6 +166,11 @@ def load(path: Optional[str] = None):
     L.umx_infer_image_raw.restype = c_int
     L.umx_infer_image_raw.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_int,
                                       c_void_p]
+    L.umx_plane_range.restype = c_int
+    L.umx_plane_range.argtypes = [c_void_p, c_int, ctypes.c_size_t, c_void_p]
+    L.umx_infer_image_raw_range.restype = c_int
+    L.umx_infer_image_raw_range.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_double, c_double, c_int,
+                                            c_void_p]
     L.umx_band_tiles_dev.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_double,
                                      c_int, c_int, c_void_p]
     L.umx_stitch_dev.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]
@@ -187,6 +192,19 @@ def load(path: Optional[str] = None):
         getattr(L, name).restype = c_int
     _lib = L
     return L
+
+
+def plane_range(raw: np.ndarray):
+    """(min, max) of a contiguous uint8 / uint16 array by umx_plane_range (one pass, host threads; no GPU involved)."""
+    a = np.ascontiguousarray(raw)
+    if a.dtype not in (np.uint8, np.uint16) or a.size == 0:
+        raise TypeError("plane_range takes non-empty uint8 / uint16 arrays")
+    a = a.astype(a.dtype.newbyteorder("="), copy=False)
+    out = np.zeros(2, np.uint32)
+    rc = load().umx_plane_range(a.ctypes.data, a.dtype.itemsize * 8, a.size, out.ctypes.data)
+    if rc != 0:
+        raise UmxError(rc, "umx_plane_range")
+    return int(out[0]), int(out[1])
 
 
 def _hp_struct(hp: HParams) -> _HP:
@@ -421,6 +439,13 @@ class Engine:
         self._check(self._L.umx_infer_image(self._ctx, ctypes.c_void_p(image_ptr), C, H, W, float(mean), float(std),
                                             int(mode), int(stitch), ctypes.c_void_p(out_ptr)))
 
+    def infer_image_raw_range_ptr(self, raw_ptr: int, bits: int, C: int, H: int, W: int, value_range, mean: float, std: float,
+                                  out_ptr: int, mode: int = MODE_ACCUMULATE) -> None:
+        """umx_infer_image_raw_range on raw HOST addresses (rescale implied; value_range: per plane (min, max))."""
+        rng = np.ascontiguousarray(np.asarray(value_range, dtype=np.uint32).reshape(C, 2))
+        self._check(self._L.umx_infer_image_raw_range(self._ctx, ctypes.c_void_p(raw_ptr), int(bits), C, H, W, rng.ctypes.data,
+                                                      float(mean), float(std), int(mode), ctypes.c_void_p(out_ptr)))
+
     def infer_image_raw_ptr(self, raw_ptr: int, bits: int, C: int, H: int, W: int, rescale: bool, mean: float, std: float,
                             out_ptr: int, mode: int = MODE_ACCUMULATE) -> None:
         """umx_infer_image_raw on raw HOST addresses: uint8 / uint16 [C,H,W] in, uint8 [K,H,W] out."""
@@ -438,8 +463,10 @@ class Engine:
         self._check(self._L.umx_infer_image_wait(self._ctx, int(slot)))
 
     def infer_image_raw(self, raw: np.ndarray, rescale: bool, mean: float, std: float,
-                        mode: int = MODE_ACCUMULATE) -> np.ndarray:
-        """Driver fast path at scalingFactor 1: raw uint8/uint16 (H,W) or (C,H,W) -> uint8 [K,H,W] (see include/umx.h)."""
+                        mode: int = MODE_ACCUMULATE, value_range=None) -> np.ndarray:
+        """Driver fast path at scalingFactor 1: raw uint8/uint16 (H,W) or (C,H,W) -> uint8 [K,H,W] (see include/umx.h).
+        value_range (with rescale): per plane (min, max) of the raw samples, as the reader found them (umx_infer_image_raw_range:
+        the upload then overlaps the tile kernels in this synchronous call too)."""
         raw = np.ascontiguousarray(raw)
         if raw.dtype not in (np.uint8, np.uint16):
             raise TypeError("raw planes must be uint8 or uint16")
@@ -450,6 +477,11 @@ class Engine:
         C, H, W = raw.shape
         raw = raw.astype(raw.dtype.newbyteorder("="), copy=False)
         out = np.empty((self.hp.nClasses, H, W), np.uint8)
+        if rescale and value_range is not None:
+            rng = np.ascontiguousarray(np.asarray(value_range, dtype=np.uint32).reshape(C, 2))
+            self._check(self._L.umx_infer_image_raw_range(self._ctx, raw.ctypes.data, raw.dtype.itemsize * 8, C, H, W, rng.ctypes.data,
+                                                          float(mean), float(std), int(mode), out.ctypes.data))
+            return out
         self._check(self._L.umx_infer_image_raw(self._ctx, raw.ctypes.data, raw.dtype.itemsize * 8, C, H, W,
                                                 1 if rescale else 0, float(mean), float(std), int(mode), out.ctypes.data))
         return out

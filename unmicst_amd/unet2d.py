@@ -156,10 +156,11 @@ class UNet2D:
             lambda: UNet2D.Engine.infer_image(image, UNet2D.DatasetMean, UNet2D.DatasetStDev, m, UNet2D.stitch))
 
     @staticmethod
-    def singleImageInferenceRaw(raw, rescale, mode="accumulate"):
+    def singleImageInferenceRaw(raw, rescale, mode="accumulate", value_range=None):
         """Driver fast path (``--scalingFactor 1``, ``--outlier -1``): raw uint8/uint16 plane(s) -> uint8 class planes
         [nClasses, H, W], with the drivers' im2double / rescale_intensity / double uint8 cast done on the GPU
-        (reference UnMicst1-5.py:807-821,848-854).  ``rescale`` False reproduces solo's un-rescaled input."""
+        (reference UnMicst1-5.py:807-821,848-854).  ``rescale`` False reproduces solo's un-rescaled input.  ``value_range``: per
+        plane (min, max) of the raw samples where the caller has them already (the upload then overlaps the inference)."""
         if UNet2D.Engine is None:
             raise RuntimeError("call UNet2D.singleImageInferenceSetup first")
         if mode not in ("accumulate", "replace"):
@@ -170,7 +171,8 @@ class UNet2D:
             raise ValueError("image has %d planes, the model takes %d channels" % (raw.shape[0], UNet2D.hparams.nChannels))
         m = _umx.MODE_ACCUMULATE if mode == "accumulate" else _umx.MODE_REPLACE
         return UNet2D._with_range_fallback(
-            lambda: UNet2D.Engine.infer_image_raw(raw, bool(rescale), UNet2D.DatasetMean, UNet2D.DatasetStDev, m))
+            lambda: UNet2D.Engine.infer_image_raw(raw, bool(rescale), UNet2D.DatasetMean, UNet2D.DatasetStDev, m,
+                                                  value_range=value_range if rescale else None))
 
     @staticmethod
     def singleImageInferenceRawScaled(raw, scaling, rescale, mode="accumulate"):
