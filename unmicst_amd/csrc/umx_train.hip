@@ -103,6 +103,9 @@ struct umx_trainer {
     hipStream_t side2 = nullptr;          // a second side stream: the dz / gS slots alternate between the two (UMX_TRAIN_ONE_SIDE=1: one)
     hipEvent_t ev_join2 = nullptr;
     hipEvent_t ev_dz[kSlots] = {}, ev_gs[kSlots] = {}, ev_side[kSlots] = {}, ev_join = nullptr;
+    hipStream_t aux = nullptr;                    // the skip connections' input gradients: needed only on the way back down the U, so
+    hipEvent_t ev_aux[kSlots] = {};               // they leave the main stream's dependent chain (slot free again / gradient ready)
+    std::vector<hipEvent_t> ev_skip;
     bool overlap = true;
     double* d_part = nullptr;  size_t part_doubles = 0;
     double* d_part2 = nullptr;          // the side stream's own partial sums (regularisation loss under the forward pass)
@@ -115,6 +118,7 @@ struct umx_trainer {
     float* d_ws2 = nullptr;             // ... of the second side stream
     float* d_split = nullptr;  size_t split_floats = 0;   // partial outputs of K-split convolutions
     float* d_split2 = nullptr;                            // ... of those enqueued on the side stream
+    float* d_split3 = nullptr;                            // ... on the aux stream
     // forward / input-gradient convolutions on conv_f16x3 (UMX_TRAIN_CONV_F32=1: the exact-fp32 kernels of rounds 1-3)
     bool hconv = true;
     bool wg_planes = true;              // the split-precision weight gradient stages from the planes (UMX_TRAIN_WGRAD_FP32_STAGE=1: from fp32)
@@ -523,9 +527,10 @@ int run_hconv(umx_trainer* tr, TConv& tc, const H16& s0, const H16* s1, float* d
     if (p.ksplit > 1) {   // raw partial sums, then the ordered reduce applies the activation
         const int act = p.act;
         p.act = ACT_NONE;
-        p.dst_f32 = tr->d_split;
+        float* const scratch = st == tr->stream ? tr->d_split : st == tr->aux ? tr->d_split3 : tr->d_split2;   // (one scratch per stream)
+        p.dst_f32 = scratch;
         T_HIP(tr, launch_conv_f16(p, st));
-        T_HIP(tr, launch_split_reduce(tr->d_split, p.ksplit, p.split_stride, p.split_stride, act, dst, st));
+        T_HIP(tr, launch_split_reduce(scratch, p.ksplit, p.split_stride, p.split_stride, act, dst, st));
         return UMX_OK;
     }
     T_HIP(tr, launch_conv_f16(p, st));
@@ -789,9 +794,11 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
     hipStream_t wss[2] = {tr->overlap ? tr->side : st, tr->overlap ? (tr->side2 ? tr->side2 : tr->side) : st};
 #define ws wss[slot & 1]
     int slot = 0;
-    bool used[kSlots] = {};
+    bool used[kSlots] = {}, aux_used[kSlots] = {};
+    const bool use_aux = tr->overlap && tr->aux && tr->hconv;
     auto dz_begin = [&](int sl) -> int {      // main: the slot's previous consumers on the side stream are done
         if (tr->overlap && used[sl]) T_HIP(tr, hipStreamWaitEvent(st, tr->ev_side[sl], 0));
+        if (aux_used[sl]) { T_HIP(tr, hipStreamWaitEvent(st, tr->ev_aux[sl], 0)); aux_used[sl] = false; }
         return UMX_OK;
     };
     auto dz_ready = [&](int sl) -> int {      // main has written DZ2[sl]; the side stream may read it
@@ -828,7 +835,15 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         T_TRY(run_wgrad(tr, tr->wg_u1[idx], tr->us[idx], dz, Cskip + Cup, Cskip, tr->o_w2[idx], o.reg_up, SIZE_MAX, tr->usmax[idx], s.gmax, ws,
                         tr->hconv ? &tr->h_us[idx] : nullptr, nullptr, pdz, tr->d_xinv + slot));
         T_TRY(dgrad(tr->c_dg_us[idx], dz, tr->h_dz[slot], tr->d_xinv + slot, tr->DB));
-        if (idx >= 1) T_TRY(dgrad(tr->c_dg_skip[idx], dz, tr->h_dz[slot], tr->d_xinv + slot, tr->dskip[idx]));   // (side stream: 2 % slower)
+        if (idx >= 1 && use_aux && tr->c_dg_skip[idx].hidx >= 0) {   // (on the weight gradients' stream it was 2 % slower; this stream is its own)
+            T_HIP(tr, hipStreamWaitEvent(tr->aux, tr->ev_dz[slot], 0));
+            T_TRY(run_hconv(tr, tr->c_dg_skip[idx], tr->h_dz[slot], nullptr, tr->dskip[idx], tr->d_xinv + slot, tr->aux));
+            T_HIP(tr, hipEventRecord(tr->ev_aux[slot], tr->aux));
+            T_HIP(tr, hipEventRecord(tr->ev_skip[idx], tr->aux));
+            aux_used[slot] = true;
+        } else if (idx >= 1) {
+            T_TRY(dgrad(tr->c_dg_skip[idx], dz, tr->h_dz[slot], tr->d_xinv + slot, tr->dskip[idx]));
+        }
         T_HIP(tr, launch_leaky_bwd_s2d_max(tr->DB, tr->us[idx], B, S / 2, Cup, gs, tr->smax[idx], st));
         const bool gs_planes = tr->hconv && (tr->c_dg_T[idx].hidx >= 0 || tr->wg_planes);
         if (gs_planes) {   // (in front of the event: the transposed convolution's weight gradient stages from these planes too)
@@ -868,6 +883,7 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
         float* dz = tr->DZ2[slot];
         ActParams a = act_params(tr, s, 1, ACT_LEAKY, down_rate(tr, i), LAYER_DOWN + i);
         const float* dy1 = (i + 1 <= L - 1) ? tr->dskip[i + 1] : nullptr;
+        if (dy1 && use_aux && tr->c_dg_skip[i + 1].hidx >= 0) T_HIP(tr, hipStreamWaitEvent(st, tr->ev_skip[i + 1], 0));
         T_TRY(dz_begin(slot));
         tr->h_dz[slot].Cs = round_up(tr->n[i + 1], 8);
         T_TRY(bn_backward(tr, s, a, tr->DB, dy1, dz, tr->hconv && i >= 1 ? &tr->h_dz[slot] : nullptr, tr->d_xinv + slot));
@@ -1195,6 +1211,7 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
     T_TRY(talloc(tr, &tr->d_ws2, tr->ws_floats));
     T_TRY(talloc(tr, &tr->d_split, tr->split_floats));
     T_TRY(talloc(tr, &tr->d_split2, tr->split_floats));
+    T_TRY(talloc(tr, &tr->d_split3, tr->split_floats));
     {
         std::vector<RegSeg> rs;
         for (const Seg& sg : tr->segs)
@@ -1319,7 +1336,12 @@ int umx_trainer_create(const umx_hparams* hp, const float* weight_blob, size_t b
         if (hipStreamCreateWithFlags(&tr->side, hipStreamNonBlocking) != hipSuccess) rc = tfail(tr, UMX_ERR_HIP, "hipStreamCreate failed");
         if (!getenv("UMX_TRAIN_ONE_SIDE") && hipStreamCreateWithFlags(&tr->side2, hipStreamNonBlocking) != hipSuccess)
             rc = tfail(tr, UMX_ERR_HIP, "hipStreamCreate failed");
+        if (!getenv("UMX_TRAIN_NO_AUX") && hipStreamCreateWithFlags(&tr->aux, hipStreamNonBlocking) != hipSuccess)
+            rc = tfail(tr, UMX_ERR_HIP, "hipStreamCreate failed");
+        tr->ev_skip.assign(32, nullptr);
         std::vector<hipEvent_t*> evs = {&tr->ev_join, &tr->ev_begin, &tr->ev_packed, &tr->ev_join2};
+        for (hipEvent_t& e : tr->ev_skip) evs.push_back(&e);
+        for (int sl = 0; sl < kSlots; ++sl) evs.push_back(&tr->ev_aux[sl]);
         for (int sl = 0; sl < kSlots; ++sl) { evs.push_back(&tr->ev_dz[sl]); evs.push_back(&tr->ev_gs[sl]); evs.push_back(&tr->ev_side[sl]); }
         for (hipEvent_t* e : evs)
             if (rc == UMX_OK && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess)
@@ -1347,8 +1369,13 @@ void umx_trainer_destroy(umx_trainer* tr) {
         if (tr->ev[i]) (void)hipEventDestroy(tr->ev[i]);
     if (tr->side) { (void)hipStreamSynchronize(tr->side); (void)hipStreamDestroy(tr->side); }
     if (tr->side2) { (void)hipStreamSynchronize(tr->side2); (void)hipStreamDestroy(tr->side2); }
+    if (tr->aux) { (void)hipStreamSynchronize(tr->aux); (void)hipStreamDestroy(tr->aux); }
     for (hipEvent_t e : {tr->ev_join, tr->ev_begin, tr->ev_packed, tr->ev_join2})
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : tr->ev_skip)
+        if (e) (void)hipEventDestroy(e);
+    for (int sl = 0; sl < kSlots; ++sl)
+        if (tr->ev_aux[sl]) (void)hipEventDestroy(tr->ev_aux[sl]);
     for (int sl = 0; sl < kSlots; ++sl)
         for (hipEvent_t e : {tr->ev_dz[sl], tr->ev_gs[sl], tr->ev_side[sl]})
             if (e) (void)hipEventDestroy(e);
