@@ -450,21 +450,13 @@ def main():
     if not args.resident_only:
         host_elapsed, host_prof, res_h = timed(step_host)
         if not sharded:
-            # what ONE per-file driver call achieves: a synchronous umx_infer_image_raw with the drivers' intensity rescale
-            # (the whole upload and its min/max pass precede the first tile), one slide at a time
+            # what ONE per-file driver call achieves: a synchronous umx_infer_image_raw with the drivers' intensity rescale, one
+            # slide at a time
             sync_out = torch.empty((K, H, W), dtype=torch.uint8).pin_memory()
 
             def step_sync():
                 eng._check(eng._L.umx_infer_image_raw(eng._ctx, host_u16.data_ptr(), 16, C_img, H, W, 1, float(mean), float(std),
                                                       umx.MODE_ACCUMULATE, sync_out.data_ptr()))
-            # ... and the driver's call as it is made since round 4: the page's (min, max) come from the host pass over the page
-            # (driver.plane_range, timed here beside the call it feeds) and the upload overlaps the tile kernels
-            from unmicst_amd import driver as _driver
-            planes_np = host_u16.numpy().view(np.uint16)
-
-            def step_ranged():
-                rng = [_driver.plane_range(planes_np[c]) for c in range(C_img)]
-                eng.infer_image_raw_range_ptr(host_u16.data_ptr(), 16, C_img, H, W, rng, float(mean), float(std), sync_out.data_ptr())
 
             def timed_sync(fn, n):
                 fn()
@@ -473,14 +465,17 @@ def main():
                     fn()
                 return time.perf_counter() - t0
             ns = max(3, min(args.steps, 10))
-            dts = timed_sync(step_ranged, ns)
-            dtd = timed_sync(step_sync, max(2, ns // 3))
+            dts = timed_sync(step_sync, ns)
+            # (round 3's form of the same call: the whole upload and a device reduction in front of the first tile)
+            os.environ["UMX_HOST_RANGE"] = "0"
+            nd = max(2, ns // 3)
+            dtd = timed_sync(step_sync, nd)
+            del os.environ["UMX_HOST_RANGE"]
             host_sync = {"value": round(tiles_total * ns / dts, 2), "unit": "tiles/s", "ms_per_call": round(1e3 * dts / ns, 3),
-                         "calls": ns, "device_range": {"value": round(tiles_total * max(2, ns // 3) / dtd, 2),
-                                                       "ms_per_call": round(1e3 * dtd / max(2, ns // 3), 3)},
-                         "note": "synchronous call, one slide at a time, the per-file driver's: (min, max) of each plane by "
-                                 "driver.plane_range on the host (inside the timed call) -> umx_infer_image_raw_range, rows go up "
-                                 "under the tile kernels; device_range: umx_infer_image_raw(rescale=1), whole upload + min/max first "
+                         "calls": ns, "device_range": {"value": round(tiles_total * nd / dtd, 2), "ms_per_call": round(1e3 * dtd / nd, 3)},
+                         "note": "synchronous umx_infer_image_raw(rescale=1), one slide at a time: the per-file driver's call -- the "
+                                 "planes' (min, max) by host threads while the rows cross the bus, tiles start on the first slab; "
+                                 "device_range (UMX_HOST_RANGE=0): whole upload + device min/max first, as in round 3 "
                                  "(`value` above streams two slides through submit / wait)"}
     res_elapsed, res_prof, res_r = timed(step_resident)
     # rounds 1-3 quoted the 2048-row band of the same slide (946 tiles: one rank's share at N = 8): kept beside the slide at N = 1

@@ -137,7 +137,9 @@ UMX_API int umx_infer_image_dev(umx_ctx* ctx, const double* image_dev, int C_img
  *   multiply by 1/255 or 1/65535)  ->  rescale != 0: rescale_intensity(in (min,max) of the plane, out (0, 0.983)) per
  *   plane (legacy / duo / cyto feed this; solo feeds the un-rescaled plane, rescale == 0)  ->  umx_infer_image (fp16-compat
  *   stitch)  ->  uint8(255 * pm) -> resize (identity) -> uint8(255 * .): out [nClasses,H,W] uint8.
- * Bit-identical to the host-side recipe (unmicst_amd/driver.py); saves the float64 upload and the fp16 download. */
+ * Bit-identical to the host-side recipe (unmicst_amd/driver.py); saves the float64 upload and the fp16 download.  With rescale the
+ * call finds each plane's (min, max) with host threads (umx_plane_range) while the rows are on their way up, and the tile gather
+ * applies the rescale to the raw samples: no pass over the slide precedes the first tile. */
 UMX_API int umx_infer_image_raw(umx_ctx* ctx, const void* raw_host, int bits, int C_img, int H, int W, int rescale,
                         double mean, double std, int mode, uint8_t* out_host);
 

@@ -97,7 +97,7 @@ def test_default_output_dir_and_scaling(workspace):
     assert nuc.shape == (832, 960)
 
 
-def test_raw_fast_path_is_bit_identical_to_the_host_recipe(workspace):
+def test_raw_fast_path_is_bit_identical_to_the_host_recipe(workspace, monkeypatch):
     """umx_infer_image_raw (im2double, min/max, rescale_intensity, inference, double uint8 cast on the GPU) against the
     general host-side recipe of the driver, for the rescaled (legacy/duo) and un-rescaled (solo quirk) inputs, uint16 and
     uint8 planes."""
@@ -129,11 +129,22 @@ def test_raw_fast_path_is_bit_identical_to_the_host_recipe(workspace):
         want = np.stack([imtools.to_uint8_via_resize(pm[k], two.shape[1:]) for k in range(hp2.nClasses)])
         assert np.array_equal(got, want)
         assert np.array_equal(eng.infer_image_raw(two, True, 0.2, 0.2, value_range=[driver.plane_range(p) for p in two]), want)
-    # a slide of several launch groups: the ranged call goes up slab by slab, the plain one whole planes first
+    # a slide of several launch groups: the plain call finds the range on host threads under its own uploads, UMX_HOST_RANGE=0 on
+    # the device behind the whole upload, the ranged call is handed it -- one result
     big = np.tile(raw16, (3, 2))[:1100, :1000]
     with umx.Engine(hp, blob, max_batch=16) as eng:
-        assert np.array_equal(eng.infer_image_raw(big, True, mean, std, value_range=[driver.plane_range(big)]),
-                              eng.infer_image_raw(big, True, mean, std))
+        plain = eng.infer_image_raw(big, True, mean, std)
+        assert np.array_equal(eng.infer_image_raw(big, True, mean, std, value_range=[driver.plane_range(big)]), plain)
+        monkeypatch.setenv("UMX_HOST_RANGE", "0")
+        assert np.array_equal(eng.infer_image_raw(big, True, mean, std), plain)
+        monkeypatch.delenv("UMX_HOST_RANGE")
+        # ... and the rescale inside the raw tile gather (default) against the float64 image made by a pass of its own
+        monkeypatch.setenv("UMX_NO_RAW_RESCALE", "1")
+        assert np.array_equal(eng.infer_image_raw(big, True, mean, std), plain)
+        flat = np.full((300, 280), 1234, np.uint16)          # min == max: np.clip branch of rescale_intensity
+        want_flat = eng.infer_image_raw(flat, True, mean, std)
+        monkeypatch.delenv("UMX_NO_RAW_RESCALE")
+        assert np.array_equal(eng.infer_image_raw(flat, True, mean, std), want_flat)
 
 
 def test_clean_checkout_runs_on_the_shipped_models_directory(workspace):

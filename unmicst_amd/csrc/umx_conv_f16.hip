@@ -1075,9 +1075,20 @@ template <int CW, int SRC>
 __global__ void __launch_bounds__(256) gather_split_kernel(const void* __restrict__ image_v, double inv_max, int C_img, int band_row0,
                                                           int band_rows, TileGeom g, int Cn, double mean, double stdv,
                                                           int tile0, int ntiles, float scale, uint4* __restrict__ hi,
-                                                          uint4* __restrict__ lo) {
+                                                          uint4* __restrict__ lo, const unsigned* __restrict__ mm) {
     constexpr int NC = CW > 0 ? CW : 8;
     const size_t total = (size_t)ntiles * g.P * g.P;
+    // raw planes with the drivers' intensity rescale (mm != NULL: words [16 * plane] = the plane's min, max raw value): the float64
+    // recipe of raw_to_double_kernel, operation for operation, in front of the normalisation
+    double rlo[NC], rhi[NC];
+    if constexpr (SRC != 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int pl = C_img == 1 ? 0 : (c < Cn ? c : 0);
+            rlo[c] = mm ? __dmul_rn((double)mm[16 * pl], inv_max) : 0.0;
+            rhi[c] = mm ? __dmul_rn((double)mm[16 * pl + 1], inv_max) : 0.0;
+        }
+    }
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(e % g.P);
         const size_t r1 = e / g.P;
@@ -1101,6 +1112,12 @@ __global__ void __launch_bounds__(256) gather_split_kernel(const void* __restric
                     if constexpr (SRC == 0) v = static_cast<const double*>(image_v)[at];
                     else if constexpr (SRC == 1) v = __dmul_rn((double)static_cast<const unsigned short*>(image_v)[at], inv_max);
                     else v = __dmul_rn((double)static_cast<const unsigned char*>(image_v)[at], inv_max);
+                    if constexpr (SRC != 0) {
+                        if (mm) {
+                            if (rlo[c] != rhi[c]) v = __dmul_rn(__ddiv_rn(__dsub_rn(v, rlo[c]), __dsub_rn(rhi[c], rlo[c])), 0.983);
+                            else v = fmin(fmax(v, 0.0), 0.983);
+                        }
+                    }
                 }
                 f = (float)((v - mean) / stdv) * scale;
             }
@@ -1123,8 +1140,9 @@ __global__ void __launch_bounds__(256) gather_split_kernel(const void* __restric
 // `raw_bits` 0: `image` holds float64 planes; 16 / 8: the raw integer planes (im2double happens in the gather)
 hipError_t launch_gather_split(const void* image, int raw_bits, int C_img, int band_row0, int band_rows, const TileGeom& g, int Cn,
                                double mean, double stdv, int tile0, int ntiles, float scale, _Float16* hi, _Float16* lo, int cw,
-                               hipStream_t stream) {
+                               hipStream_t stream, const unsigned* mm) {
     if (ntiles <= 0) return hipSuccess;
+    if (mm && raw_bits == 0) return hipErrorInvalidValue;   // (the rescale rides on the raw sources only)
     if (Cn > 8 || (cw > 0 && Cn > cw) || (raw_bits != 0 && raw_bits != 8 && raw_bits != 16)) return hipErrorInvalidValue;
     const size_t total = (size_t)ntiles * g.P * g.P;
     const unsigned blocks = (unsigned)((total + 255) / 256 < 256 * 16 ? (total + 255) / 256 : 256 * 16);
@@ -1132,7 +1150,7 @@ hipError_t launch_gather_split(const void* image, int raw_bits, int C_img, int b
     uint4* const l4 = reinterpret_cast<uint4*>(lo);
     const double inv_max = raw_bits == 16 ? 1.0 / 65535 : 1.0 / 255;
 #define UMX_GS2(CWV, SRCV) hipLaunchKernelGGL((gather_split_kernel<CWV, SRCV>), dim3(blocks), dim3(256), 0, stream, image, inv_max, C_img, \
-                                              band_row0, band_rows, g, Cn, mean, stdv, tile0, ntiles, scale, h4, l4)
+                                              band_row0, band_rows, g, Cn, mean, stdv, tile0, ntiles, scale, h4, l4, mm)
 #define UMX_GS(CWV) do { if (raw_bits == 0) UMX_GS2(CWV, 0); else if (raw_bits == 16) UMX_GS2(CWV, 1); else UMX_GS2(CWV, 2); } while (0)
     if (cw == 0) UMX_GS(0);
     else if (cw == 1) UMX_GS(1);

@@ -307,7 +307,8 @@ bool gathers_raw(const umx_ctx* ctx) {
 }
 
 int tiles_range(umx_ctx* ctx, const double* image_dev, int C_img, const TileGeom& g, int band_row0, int band_rows,
-                       double mean, double stdv, int t0, int t1, float* probs_dev, const void* raw_dev, int raw_bits) {
+                       double mean, double stdv, int t0, int t1, float* probs_dev, const void* raw_dev, int raw_bits,
+                       const unsigned* mm_dev) {
     const size_t prob_f = (size_t)g.P * g.P * ctx->hp.nClasses;
     if (ctx->site_gather < 0) ctx->site_gather = site_of(ctx, "pi2d.gather_normalise", "gather_normalise");
     const bool direct16 = ctx->precision == UMX_PREC_F16X3 && ctx->hp.nChannels <= 8 && ctx->bufs[0].Cs == 8;
@@ -325,7 +326,8 @@ int tiles_range(umx_ctx* ctx, const double* image_dev, int C_img, const TileGeom
             if (direct16) {   // gather + normalise + (hi, lo) split in one pass
                 const Buffer& b0 = cur_bufs(ctx)[0];
                 HIP_TRY(ctx, launch_gather_split(src, raw_dev ? raw_bits : 0, C_img, band_row0, band_rows, g, ctx->hp.nChannels, mean, stdv, t, nb,
-                                                 std::ldexp(1.f, ctx->act_shift), hi_of(b0), lo_of(b0, nb), ctx->in_cw, run_stream(ctx)));
+                                                 std::ldexp(1.f, ctx->act_shift), hi_of(b0), lo_of(b0, nb), ctx->in_cw, run_stream(ctx),
+                                                 raw_dev ? mm_dev : nullptr));
             } else {
                 HIP_TRY(ctx, launch_gather_normalise(image_dev, C_img, band_row0, band_rows, g, ctx->hp.nChannels, mean, stdv, t,
                                                      nb, tiles32, run_stream(ctx)));

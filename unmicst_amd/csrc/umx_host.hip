@@ -83,9 +83,10 @@ static int host_submit_impl(umx_ctx* ctx, int slot, bool sync_call, const void* 
     const size_t raw_b = src_bits ? plane * C_img * in_b : 0;
     const size_t mm_off = (raw_off + raw_b + 255) & ~(size_t)255;
     int rc;
-    // raw planes without an intensity rescale: the tile gather converts as it reads (the float64 image -- 8 bytes written and
-    // 14 read per pixel and channel -- is never made, and not allocated either: 4.3 GB for a two-channel 16384 x 16384 slide)
-    const bool raw_gather = src_bits != 0 && !rescale && gathers_raw(ctx);
+    // raw planes: the tile gather converts (and, with `rescale`, rescales to the plane's (min, max) words, ready in stream order
+    // before the first tile) as it reads -- the float64 image, 8 bytes written and 14 read per pixel and channel, is never made, and
+    // not allocated either: 4.3 GB for a two-channel 16384 x 16384 slide
+    const bool raw_gather = src_bits != 0 && gathers_raw(ctx) && !(rescale && getenv("UMX_NO_RAW_RESCALE"));
     if (!raw_gather && (rc = grow(ctx, (void**)&hs.d_image, &hs.image_cap, plane * C_img * sizeof(double)))) return rc;
     if ((rc = grow(ctx, &hs.d_out, &hs.out_cap, mm_off + 64 * (size_t)C_img))) return rc;
     if ((rc = grow(ctx, (void**)&hs.d_probs, &hs.probs_cap, (size_t)g.npr * g.npc * g.P * g.P * K * sizeof(float)))) return rc;
@@ -148,15 +149,37 @@ static int host_submit_impl(umx_ctx* ctx, int slot, bool sync_call, const void* 
         return UMX_OK;
     };
     int up_done = 0;
+    // A synchronous rescaled call whose caller handed no range in: every slab's upload is enqueued first (pinned pages: DMA), the
+    // planes' (min, max) found by host threads while the rows cross the bus (3 ms per 537 MB plane), and the tile kernels start on
+    // the first slab as soon as that pass is done -- instead of behind the whole upload and a device reduction (UMX_HOST_RANGE=0)
+    uint32_t own_range[2 * 8];
+    const uint32_t* range_in = ctx->range_in;
+    std::vector<int> pre_r1;   // rows up after slab s, when the uploads were enqueued ahead
+    if (src_bits && rescale && !range_in && sync_call && C_img <= 8 && !(getenv("UMX_HOST_RANGE") && atoi(getenv("UMX_HOST_RANGE")) == 0)) {
+        pre_r1.resize(S);
+        for (int s = 0; s < S; ++s) {
+            const int r1 = s == S - 1 ? H : rows_needed((tcut[s + 1] - 1) / g.npc + 1);
+            if (r1 > up_done) {
+                if ((rc = upload(up_done, r1))) return rc;
+                if (!single) HIP_TRY(ctx, hipEventRecord(ev_up[s], ctx->up_stream));
+                up_done = r1;
+            }
+            pre_r1[s] = up_done;
+        }
+        for (int c = 0; c < C_img; ++c)
+            if (umx_plane_range((const unsigned char*)src + (size_t)c * plane * in_b, src_bits, plane, own_range + 2 * c) != UMX_OK)
+                return fail(ctx, UMX_ERR_INVALID, "plane range");
+        range_in = own_range;
+    }
     if (src_bits) {
         for (int c = 0; c < C_img; ++c) HIP_TRY(ctx, launch_minmax_init(mm + 16 * c, ctx->stream));
-        if (rescale && ctx->range_in) {
+        if (rescale && range_in) {
             // the caller's file reader saw every sample and hands the planes' (min, max) in: the words the reduction below would
             // leave, so the slide goes up slab by slab under the tile kernels like an un-rescaled one (a synchronous rescaled
             // call otherwise spends the whole upload -- 21 ms for the 1.07 GB metric slide -- in front of its first tile)
             for (int c = 0; c < C_img; ++c) {
-                HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(mm + 16 * c), (int)ctx->range_in[2 * c], 1, ctx->stream));
-                HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(mm + 16 * c + 1), (int)ctx->range_in[2 * c + 1], 1, ctx->stream));
+                HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(mm + 16 * c), (int)range_in[2 * c], 1, ctx->stream));
+                HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(mm + 16 * c + 1), (int)range_in[2 * c + 1], 1, ctx->stream));
             }
         } else if (rescale) {   // whole planes first: min / max per plane, reduced as the slabs arrive
             for (int s = 0; s < S; ++s) {
@@ -179,7 +202,13 @@ static int host_submit_impl(umx_ctx* ctx, int slot, bool sync_call, const void* 
     for (int s = 0; s < S; ++s) {
         // rows the tiles of this slab read: up to the last patch row it touches
         const int r1 = s == S - 1 ? H : rows_needed((tcut[s + 1] - 1) / g.npc + 1);
-        if (r1 > up_done) {
+        if (!pre_r1.empty()) {   // uploaded ahead: wait for this slab's rows, convert them
+            const int r0 = s ? pre_r1[s - 1] : 0;
+            if (pre_r1[s] > r0) {
+                if (!single) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ev_up[s], 0));
+                if ((rc = convert(r0, pre_r1[s]))) return rc;
+            }
+        } else if (r1 > up_done) {
             if ((rc = upload(up_done, r1))) return rc;
             if (!single) {
                 HIP_TRY(ctx, hipEventRecord(ev_up[s], ctx->up_stream));
@@ -191,7 +220,7 @@ static int host_submit_impl(umx_ctx* ctx, int slot, bool sync_call, const void* 
         if (tcut[s + 1] > tcut[s]) {
             float* const pr = hs.d_probs + (size_t)tcut[s] * g.P * g.P * K;
             if ((rc = tiles_range(ctx, raw_gather ? nullptr : hs.d_image, C_img, g, 0, H, mean, stdv, tcut[s], tcut[s + 1], pr, raw_gather ? d_raw : nullptr,
-                                  raw_gather ? src_bits : 0)))
+                                  raw_gather ? src_bits : 0, raw_gather && rescale ? mm : nullptr)))
                 return rc;
         }
         // image rows no later tile touches: below the first incomplete patch row

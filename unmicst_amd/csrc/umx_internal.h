@@ -280,7 +280,8 @@ TileGeom geom_of(const umx_hparams& hp, int H, int W);
 // tiles [t0, t1) of the slide (row-major tile index) -> probs_dev (tile t0 first): gather + normalise + UNet
 // (raw_dev / raw_bits: the same planes as raw uint8 / uint16 values, for an engine that gathers from them -- gathers_raw())
 int tiles_range(umx_ctx* ctx, const double* image_dev, int C_img, const TileGeom& g, int band_row0, int band_rows,
-                double mean, double stdv, int t0, int t1, float* probs_dev, const void* raw_dev = nullptr, int raw_bits = 0);
+                double mean, double stdv, int t0, int t1, float* probs_dev, const void* raw_dev = nullptr, int raw_bits = 0,
+                const unsigned* mm_dev = nullptr /* raw planes: rescale_intensity to each plane's (min, max) words, 16 words apart */);
 // the tile gather of this engine can read raw integer planes (im2double in the gather: no float64 image is written or read)
 bool gathers_raw(const umx_ctx* ctx);
 

@@ -185,7 +185,7 @@ hipError_t launch_split_f32(const float* x, size_t npix, int C, int Cs, float sc
 
 hipError_t launch_gather_split(const void* image, int raw_bits, int C_img, int band_row0, int band_rows, const TileGeom& g, int Cn,
                                double mean, double stdv, int tile0, int ntiles, float scale, _Float16* hi, _Float16* lo, int cw,
-                               hipStream_t stream);
+                               hipStream_t stream, const unsigned* mm = nullptr /* raw sources: rescale to the planes' (min, max) words */);
 
 hipError_t launch_gather_normalise(const double* image, int C_img, int band_row0, int band_rows, const TileGeom& g,
                                    int Cn, double mean, double stdv, int tile0, int ntiles, float* tiles,
