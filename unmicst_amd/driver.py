@@ -291,4 +291,11 @@ def run(tool: str, argv=None, script_dir: str = None) -> int:
 
 
 def main(tool: str, script_file: str) -> None:
-    sys.exit(run(tool, None, os.path.dirname(os.path.realpath(script_file))))
+    rc = run(tool, None, os.path.dirname(os.path.realpath(script_file)))
+    # every output file is written and closed, the engine destroyed: what is left is interpreter finalisation and the unloading of the
+    # HIP runtime, 0.2 s of a 0.9 s tool.  UMX_NO_FAST_EXIT=1 leaves through sys.exit as usual.
+    if os.environ.get("UMX_NO_FAST_EXIT"):
+        sys.exit(rc)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(rc)
