@@ -147,6 +147,28 @@ def test_raw_fast_path_is_bit_identical_to_the_host_recipe(workspace, monkeypatc
         assert np.array_equal(eng.infer_image_raw(flat, True, mean, std), want_flat)
 
 
+def test_two_slides_in_flight_equal_the_synchronous_calls(workspace):
+    """umx_infer_image_raw_submit / umx_infer_image_wait: two slides enqueued on the two slots before either is waited for, with and
+    without the intensity rescale (a submitted rescaled call finds its range on the device, the synchronous one on host threads), equal
+    the synchronous calls byte for byte; a slot that still holds a call refuses the next one."""
+    from unmicst_amd import umx
+    hp, blob, mean, std = helpers.load_nuclei_dapi()
+    raw16 = helpers.load_sample_105()[0]
+    a = np.ascontiguousarray(np.tile(raw16, (2, 2))[:900, :1100])
+    b = np.ascontiguousarray(a[::-1, ::-1] // 2)
+    with umx.Engine(hp, blob, max_batch=16) as eng:
+        for rescale in (False, True):
+            want = [eng.infer_image_raw(x, rescale, mean, std) for x in (a, b)]
+            outs = [np.empty_like(want[0]), np.empty_like(want[1])]
+            for slot, x in enumerate((a, b)):
+                eng.infer_image_raw_submit(slot, x.ctypes.data, 16, 1, x.shape[0], x.shape[1], rescale, mean, std, outs[slot].ctypes.data)
+            with pytest.raises(umx.UmxError):
+                eng.infer_image_raw_submit(0, a.ctypes.data, 16, 1, a.shape[0], a.shape[1], rescale, mean, std, outs[0].ctypes.data)
+            for slot in (1, 0):
+                eng.infer_image_wait(slot)
+            assert np.array_equal(outs[0], want[0]) and np.array_equal(outs[1], want[1]), rescale
+
+
 def test_clean_checkout_runs_on_the_shipped_models_directory(workspace):
     """`python unmicstWrapper.py --tool unmicst-legacy img.tif` out of the box: no UMX_MODELS_DIR, the converted nucleiDAPI
     weights come from <repo>/models/nucleiDAPI/umx_model.npz (reference UnMicst.py:547,556: models/<--model>)."""
