@@ -1522,7 +1522,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_f16x3(const WgradParams p) {
     const float sx = PL ? 1.f : wg_scale(p.xmax), sg = PL ? 1.f : wg_scale(p.gmax);
 
     // this wave's (slab, channel tile) pairs
-    const int npairs = ns * 3, pair0 = wave * kHwPW;
+    // (pairs dealt evenly: a transposed convolution's parity groups have 1 - 4 slabs = 3 - 12 pairs, and seven per wave in wave order
+    //  left two or three of the four waves without work)
+    const int npairs = ns * 3;
+    const int ppw = __builtin_amdgcn_readfirstlane((npairs + 3) >> 2), pair0 = wave * ppw, pair1 = min(npairs, pair0 + ppw);
     int aoff[kHwPW], dxs[kHwPW], sbi[kHwPW], t2i[kHwPW];
 #pragma unroll
     for (int i = 0; i < kHwPW; ++i) {
@@ -1717,7 +1720,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_f16x3(const WgradParams p) {
             const _Float16* const xp = Xh + li * p.xs + il * imgplaneP + y * p.hp + x;
 #pragma unroll
             for (int i = 0; i < kHwPW; ++i) {
-                if (pair0 + i < npairs) {
+                if (pair0 + i < pair1) {
                     h8v xf[2];
 #pragma unroll
                     for (int pl = 0; pl < 2; ++pl) {
@@ -1751,7 +1754,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_f16x3(const WgradParams p) {
     const size_t slab_sz = (size_t)p.Cx * p.Cg;
 #pragma unroll
     for (int i = 0; i < kHwPW; ++i) {
-        if (pair0 + i < npairs) {
+        if (pair0 + i < pair1) {
             float* dst = p.ws + ((size_t)slice * p.nslab + slab0 + sbi[i]) * slab_sz;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
