@@ -586,6 +586,15 @@ int setup_wgrad(umx_trainer* tr, WgradParams& w, const char* what, int H, int Cx
     std::string why;
     if (!wgrad_setup(&w, &why)) return tfail(tr, UMX_ERR_INVALID, "%s: %s", what, why.c_str());
     tr->ws_floats = std::max(tr->ws_floats, wgrad_ws_floats(w));
+    if (getenv("UMX_DEBUG_PLAN")) {
+        std::string groups;
+        for (int g = 0; g < w.ngroups; ++g) groups += (g ? "/" : "") + std::to_string(w.gcount[g]);
+        fprintf(stderr, "[umx train] wgrad %s: %d x %d, X %d (of %d) ch x G %d ch, %d slabs in groups %s, %s, %d img/tile, %d tiles, %d slices x %d tiles, "
+                        "grid %d x %d x %d\n",
+                what, H, H, Cx, Cxt, Cg, w.nslab, groups.c_str(), w.thin ? "thin" : w.f16 ? "f16x3" : "fp32 mfma", w.imgs, w.ntiles, w.nslices,
+                w.tiles_per_slice, w.nslices,
+                w.thin ? 1 : w.f16 ? ((Cx + 47) / 48) * ((Cg + 47) / 48) : ((Cx + 16 * w.mi - 1) / (16 * w.mi)) * ((Cg + 63) / 64), w.thin ? 1 : w.ngroups);
+    }
     return UMX_OK;
 }
 
