@@ -83,6 +83,7 @@ ROUTES = [{}, {"UMX_TRAIN_CONV_F32": "1"}, {"UMX_TRAIN_NO_KSPLIT": "1"}, {"UMX_T
           {"UMX_TRAIN_SLOTS": "2"},              # the main stream at most two layers ahead of the weight gradients (rounds 2-3) instead of four
           {"UMX_TRAIN_KEEP_ZERO_PAIRS": "1"},    # the transposed convolutions' input gradient multiplies its 7 of 16 structurally-zero (tap, parity) pairs
           {"UMX_TRAIN_NO_AUX": "1"},             # the skip connections' input gradients on the main stream instead of a stream of their own
+          {"UMX_TRAIN_WGRAD_QUAD": "1"},         # the weight gradient stages (pixel pair, channel quad) tasks with 8-byte loads instead of octets with 16-byte ones
           {"UMX_TRAIN_PACKED_REPACK": "1"},      # weight images gathered from the packed fp32 operands instead of the master tensors
           {"UMX_TRAIN_CONV_F32": "1", "UMX_TRAIN_KSPLIT_WGS": "4096", "UMX_TRAIN_KSPLIT_MAX": "3"}]
 

@@ -1502,7 +1502,12 @@ __device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
 // PL = true (round 4): the operands are staged from the (hi, lo) binary16 NHWC planes their producers already wrote for conv_f16x3
 // (WgradParams::Xhi ..): half the bytes, no conversion, and a staging task is 16 bit operations instead of ~56 conversions and
 // subtractions.  X planes are unscaled, G planes carry the power of two of their tensor (undone by the reduce through *ginv).
-template <bool PL>
+// OC (with PL): a staging task is (pixel pair, channel OCTET) with octets fastest over the lanes -- 16-byte loads, six lanes on one
+// pixel's 96 contiguous bytes -- instead of (pixel pair, channel quad) with pixel pairs fastest, whose 8-byte loads put every lane of
+// an instruction on a cache line of its own (timing ablation, profiles/r04/train_wgrad_ablation.txt: this kernel's global loads are
+// 30 % of its time and slow the main stream's memory-bound kernels by 7 - 25 %).  Needs 16-byte aligned octets: channel offsets
+// and stored channel counts that are multiples of 8.
+template <bool PL, bool OC = false>
 __global__ void __launch_bounds__(256, 2) wgrad_f16x3(const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     _Float16* const Xh = reinterpret_cast<_Float16*>(smem_b);   // [2][48][xs]
@@ -1547,7 +1552,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_f16x3(const WgradParams p) {
     // e / prow and r / hh by reciprocal multiplication (e < kHwXT * 256 = 1280, divisors < 32: exact) -- three runtime integer
     // divisions per staging task, twice per tile, were ~35 instructions each
     const unsigned inv_prow = 65536u / (unsigned)prow + 1u, inv_hh = 65536u / (unsigned)p.hh + 1u;
-    float4 xr[kHwXT][2], gr[kHwGT][2];
+    float4 xr[OC ? 1 : kHwXT][2], gr[OC ? 1 : kHwGT][2];
+    constexpr int kOX = 3, kOG = 2;                          // octet tasks per thread: 256 * 3 >= imgs * hh * prow * 6, 256 * 2 >= 64 * 6
+    uint4 xo[OC ? kOX : 1][4], go[OC ? kOG : 1][4];          // [task][px0 hi, px1 hi, px0 lo, px1 lo]
+    const int nxo = p.imgs * p.hh * prow * 6;
     auto load_tile = [&](int t) {
         const int tx = t % p.tiles_x;
         const int ty = (t / p.tiles_x) % p.tiles_y;
@@ -1555,6 +1563,54 @@ __global__ void __launch_bounds__(256, 2) wgrad_f16x3(const WgradParams p) {
         const int y0 = ty * TH, x0 = tx * TW;
         int tid_o = tid;
         asm volatile("" : "+v"(tid_o));
+        if constexpr (OC) {
+            const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int i = 0; i < kOX; ++i) {
+                const int e = tid_o + i * 256;
+                xo[i][0] = xo[i][1] = xo[i][2] = xo[i][3] = z4;
+                if (e < nxo) {
+                    const int e2 = (int)(((unsigned)e * 10923u) >> 16);   // e / 6 (e < 768: exact)
+                    const int o = e - e2 * 6;
+                    int r = (int)(((unsigned)e2 * inv_prow) >> 16);
+                    const int pr = e2 - r * prow;
+                    const int il = (int)(((unsigned)r * inv_hh) >> 16), hy = r - il * p.hh;
+                    const int gy = y0 + p.ymin + hy, gx = x0 + p.xmin + 2 * pr, img = img0 + il;
+                    const int c = ci0 + 8 * o;
+                    if (img < p.B && gy >= 0 && gy < p.H && c < p.Cx) {
+                        const size_t row = ((size_t)(img * p.H + gy) * p.W) * p.XCs + coff + c;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int gxx = gx + h;
+                            if (gxx >= 0 && gxx < p.W && 2 * pr + h < p.hw) {
+                                xo[i][h] = *reinterpret_cast<const uint4*>(p.Xhi + row + (size_t)gxx * p.XCs);
+                                xo[i][2 + h] = *reinterpret_cast<const uint4*>(p.Xlo + row + (size_t)gxx * p.XCs);
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < kOG; ++i) {
+                const int e = tid_o + i * 256;              // 64 pixel pairs x 6 channel octets = 384 tasks
+                go[i][0] = go[i][1] = go[i][2] = go[i][3] = z4;
+                const int pp = (int)(((unsigned)e * 10923u) >> 16), o = e - pp * 6;
+                const int px = 2 * pp;
+                const int il = px >> (p.th_log2 + p.tw_log2);
+                const int y = (px >> p.tw_log2) & (TH - 1), x = px & (TW - 1);
+                const int img = img0 + il;
+                const int co = co0 + 8 * o;
+                if (pp < 64 && img < p.B && co < p.Cg) {
+                    const size_t at = ((size_t)(img * p.H + y0 + y) * p.W + x0 + x) * p.GCs + co;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        go[i][h] = *reinterpret_cast<const uint4*>(p.Ghi + at + (size_t)h * p.GCs);
+                        go[i][2 + h] = *reinterpret_cast<const uint4*>(p.Glo + at + (size_t)h * p.GCs);
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < kHwXT; ++i) {
             const int e = tid_o + i * 256;
@@ -1673,9 +1729,41 @@ __global__ void __launch_bounds__(256, 2) wgrad_f16x3(const WgradParams p) {
             *reinterpret_cast<unsigned*>(base + plane_stride + k * chan_stride + pos) = pack_h2(la, lb);
         }
     };
+    // an octet task's two pixels -> per channel one word (the pixel pair), hi and lo planes
+    auto store_octet = [&](_Float16* base, int plane_stride, int chan_stride, int pos, const uint4 (&v)[4]) {
+        const unsigned a[4] = {v[0].x, v[0].y, v[0].z, v[0].w}, b[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
+        const unsigned c[4] = {v[2].x, v[2].y, v[2].z, v[2].w}, d[4] = {v[3].x, v[3].y, v[3].z, v[3].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<unsigned*>(base + (2 * j) * chan_stride + pos) = (a[j] & 0xffffu) | (b[j] << 16);
+            *reinterpret_cast<unsigned*>(base + (2 * j + 1) * chan_stride + pos) = (a[j] >> 16) | (b[j] & 0xffff0000u);
+            *reinterpret_cast<unsigned*>(base + plane_stride + (2 * j) * chan_stride + pos) = (c[j] & 0xffffu) | (d[j] << 16);
+            *reinterpret_cast<unsigned*>(base + plane_stride + (2 * j + 1) * chan_stride + pos) = (c[j] >> 16) | (d[j] & 0xffff0000u);
+        }
+    };
     auto store_tile = [&]() {
         int tid_o = tid;
         asm volatile("" : "+v"(tid_o));
+        if constexpr (OC) {
+#pragma unroll
+            for (int i = 0; i < kOX; ++i) {
+                const int e = tid_o + i * 256;
+                if (e < nxo) {
+                    const int e2 = (int)(((unsigned)e * 10923u) >> 16);
+                    const int o = e - e2 * 6;
+                    const int r = (int)(((unsigned)e2 * inv_prow) >> 16);   // = il * hh + hy
+                    const int pr = e2 - r * prow;
+                    store_octet(Xh + (8 * o) * p.xs, kHwC * p.xs, p.xs, r * p.hp + 2 * pr, xo[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < kOG; ++i) {
+                const int e = tid_o + i * 256;
+                const int pp = (int)(((unsigned)e * 10923u) >> 16), o = e - pp * 6;
+                if (pp < 64) store_octet(Gh + (8 * o) * p.gs, kHwC * p.gs, p.gs, 2 * pp, go[i]);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < kHwXT; ++i) {
             const int e = tid_o + i * 256;
@@ -1923,11 +2011,19 @@ hipError_t launch_wgrad(const WgradParams& p, hipStream_t stream) {
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16x3<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16x3<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024);
             if (e != hipSuccess) return e;
             attr_set = true;
         }
         const unsigned chunks = (unsigned)(((p.Cx + kHwC - 1) / kHwC) * ((p.Cg + kHwC - 1) / kHwC));
-        if (p.planes)
+        bool oc = p.planes && p.XCs % 8 == 0 && p.GCs % 8 == 0 && p.imgs * p.hh * ((p.hw + 1) / 2) * 6 <= 3 * 256 && !getenv("UMX_TRAIN_WGRAD_QUAD");
+        for (int sb = 0; sb < p.nslab && oc; ++sb) oc = p.coff[sb] % 8 == 0;
+        if (oc)
+            hipLaunchKernelGGL((wgrad_f16x3<true, true>), dim3((unsigned)p.nslices, chunks, (unsigned)p.ngroups), dim3(256), wgrad_f16_lds(p),
+                               stream, p);
+        else if (p.planes)
             hipLaunchKernelGGL(wgrad_f16x3<true>, dim3((unsigned)p.nslices, chunks, (unsigned)p.ngroups), dim3(256), wgrad_f16_lds(p),
                                stream, p);
         else
