@@ -94,3 +94,21 @@ def test_oracle_forward_runs_and_is_a_distribution(name):
     # per-sample independence: the reference relies on it when it feeds stale tiles in the last batch
     p1 = oracle.forward(hp, blob, x[1:])
     assert np.array_equal(p1[0], p[1])
+
+
+@pytest.mark.parametrize("name,klass,floor", [("mousenucleiDAPI", 2, 0.45), ("CytoplasmIncell", 0, 0.55)])
+def test_oracle_runs_the_other_shipped_models_on_the_sample_image(name, klass, floor):
+    """The reference's two other models with weights in its tree (legacy graph, 3 x 3 kernels: the only TRAINED weights that
+    take the ks = 3 transposed-convolution crop) through the C oracle on a crop of 'UNet sample data' 105.tif.  The reference
+    holds no output of these models, so this pins no numbers -- it checks that the converted tensors make a model: a class
+    that follows the nuclei of the image (correlation with the nucleiDAPI model's bundled nuclei map; a permuted or
+    transposed tensor gives noise), probabilities that are finite and sum to one."""
+    hp, blob, mean, std = helpers.load_nuclei_dapi(name)
+    raw, _, _, g_nuc = helpers.load_sample_105()
+    crop = helpers.legacy_preprocess(raw)[:2 * hp.imSize, :2 * hp.imSize]
+    probs = oracle.tile_probs(hp, blob, crop, mean, std, batch_size=8)
+    assert probs.shape[-1] == hp.nClasses and np.isfinite(probs).all()
+    assert np.abs(probs.sum(-1) - 1.0).max() < 1e-5
+    planes = pi2d_oracle.stitch_all_classes(crop.shape, hp.imSize, probs)
+    a = planes[klass].astype(np.float64).ravel()
+    assert np.corrcoef(a, g_nuc[:crop.shape[0], :crop.shape[1]].ravel().astype(np.float64))[0, 1] > floor

@@ -207,6 +207,31 @@ def tensors_from_blob(hp: HParams, blob: np.ndarray) -> Dict[str, np.ndarray]:
     return out
 
 
+def hp_dict_from_checkpoint(hp: dict, names: Dict[str, dict]) -> dict:
+    """``hp.data`` reconciled with the tensor shapes of the checkpoint that is actually loaded.  The reference's
+    ``models/mousenucleiDAPI`` ships the hp.data of a 20-feature model whose shard is missing (.MISSING_LARGE_BLOBS:3) next
+    to ``nuclei20x2bin1chan.*`` (16 features): widths, kernel size, depth, extra convolutions, channels and classes are read
+    off the variables (names as in reference UnMicst.py:81-96,167-168 / UnMicst1-5.py:85-109,212-222); everything else
+    (imSize, batchSize, ...) stays as hp.data has it."""
+    out = dict(hp)
+    first = names.get("downsampling/ld0/kernel1") or names.get("downsampling/ld0/kernelD0")
+    top = names.get("lt/kernel")
+    if first is None or top is None:
+        return out
+    kh, _, cin, cout = first["shape"]
+    out["ks"], out["nChannels"], out["nOut0"] = int(kh), int(cin), int(cout)
+    out["nClasses"] = int(top["shape"][3])
+    layers = 0
+    while ("downsampling/ld%d/kernel1" % layers) in names or ("downsampling/ld%d/kernelD%d" % (layers, layers)) in names:
+        layers += 1
+    out["nLayers"] = layers
+    extra = 0
+    while ("downsampling/ld0/kernelExtra%d" % extra) in names or ("ld0/kernelExtra%d" % extra) in names:
+        extra += 1
+    out["nExtraConvs"] = extra
+    return out
+
+
 def blob_from_checkpoint(hp: HParams, ckpt_prefix: str) -> np.ndarray:
     """TF checkpoint -> canonical blob.  Raises KeyError when a variable the graph needs is absent
     (the reference fails the same way: tf NotFoundError on restore when graph and checkpoint disagree)."""
@@ -243,6 +268,10 @@ def random_blob(hp: HParams, seed: int = 20260101) -> np.ndarray:
 # model directory itself is unavailable (bench / tests on the GPU box)
 KNOWN_HP = {
     "nucleiDAPI": HParams(GRAPH_LEGACY, 128, 1, 3, 16, 2, 5, 1, batchSize=16),
+    # the two other models the reference ships WITH weights (legacy graph, 3x3 kernels): models/mousenucleiDAPI's
+    # nuclei20x2bin1chan checkpoint (16 features, not the 20 of its hp.data) and models/CytoplasmIncell (2 classes)
+    "mousenucleiDAPI": HParams(GRAPH_LEGACY, 256, 1, 3, 16, 3, 3, 1, batchSize=16),
+    "CytoplasmIncell": HParams(GRAPH_LEGACY, 128, 1, 2, 24, 2, 3, 1, batchSize=16),
     "nucleiDAPI1-5": HParams(GRAPH_V2, 64, 1, 3, 80, 4, 3, 0, batchSize=32),
     "nucleiDAPILAMIN": HParams(GRAPH_V2, 128, 2, 3, 36, 5, 3, 0, batchSize=24),
     # the metric tile of BASELINE.json (256x256x2): duo widths at imSize 256
@@ -262,7 +291,7 @@ CONVERTED_NAME = "umx_model.npz"   # written by tools/convert_model.py: the "con
 HP_ONLY_NAME = "umx_hp.npz"        # hyper-parameters + mean/std of a model whose weight shard is not in the tree
 
 
-def detect_graph(model_path: str) -> int:
+def detect_graph(model_path: str, prefix: str = "model.ckpt") -> int:
     """Which graph builder wrote this model directory, from the checkpoint's variable names: the legacy script names
     its first filter ``downsampling/ld0/kernel1`` (reference UnMicst.py:84), the v2 scripts ``.../kernelD0``
     (UnMicst1-5.py:89)."""
@@ -270,7 +299,7 @@ def detect_graph(model_path: str) -> int:
     if os.path.exists(conv):
         with np.load(conv) as z:
             return int(z["hp"][0])
-    names = tfckpt.read_index(os.path.join(model_path, "model.ckpt.index"))
+    names = tfckpt.read_index(os.path.join(model_path, prefix + ".index"))
     if "downsampling/ld0/kernelD0" in names:
         return GRAPH_V2
     if "downsampling/ld0/kernel1" in names:
@@ -300,13 +329,18 @@ def save_converted(art: "ModelArtefacts", model_path: str) -> str:
     return out
 
 
-def load_model_dir(model_path: str, graph: int = None, synthetic_if_missing: bool = False) -> ModelArtefacts:
+def load_model_dir(model_path: str, graph: int = None, synthetic_if_missing: bool = False,
+                   prefix: str = "model.ckpt") -> ModelArtefacts:
     """Read a model directory: the converted ``umx_model.npz`` if present, else the reference's own artefacts
     (hp.data, datasetMean/StDev pickles, model.ckpt -- reference UnMicst1-5.py:656-681).  ``graph`` None = detect.
 
     ``synthetic_if_missing``: when the directory has hyper-parameters but no weight shard (the reference ships
     nucleiDAPI1-5 / nucleiDAPILAMIN that way and downloads the shards at image-build time, Dockerfile:5-6), use
-    seeded synthetic weights instead of failing -- for plumbing tests only, never silently."""
+    seeded synthetic weights instead of failing -- for plumbing tests only, never silently.
+
+    ``prefix``: checkpoint prefix inside the directory (``saver.restore(sess, modelPath + '/model.ckpt')``, reference
+    UnMicst.py:500-503); a directory that holds another run's files (models/mousenucleiDAPI: ``nuclei20x2bin1chan``) is
+    converted by naming it, and the hyper-parameters then follow that checkpoint's tensor shapes."""
     conv = os.path.join(model_path, CONVERTED_NAME)
     if os.path.exists(conv):
         with np.load(conv) as z:
@@ -323,15 +357,18 @@ def load_model_dir(model_path: str, graph: int = None, synthetic_if_missing: boo
                                     % (model_path, CONVERTED_NAME))
         return ModelArtefacts(hp, random_blob(hp), mean, std)
     if graph is None:
-        graph = detect_graph(model_path)
-    hp = hparams_from_dict(load_pickle(os.path.join(model_path, "hp.data")), graph)
+        graph = detect_graph(model_path, prefix)
+    hp_dict = load_pickle(os.path.join(model_path, "hp.data"))
+    if prefix != "model.ckpt":
+        hp_dict = hp_dict_from_checkpoint(hp_dict, tfckpt.read_index(os.path.join(model_path, prefix + ".index")))
+    hp = hparams_from_dict(hp_dict, graph)
     mean = float(load_pickle(os.path.join(model_path, "datasetMean.data")))
     std = float(load_pickle(os.path.join(model_path, "datasetStDev.data")))
-    shard = os.path.join(model_path, "model.ckpt.data-00000-of-00001")
+    shard = os.path.join(model_path, prefix + ".data-00000-of-00001")
     if not os.path.exists(shard):
         if not synthetic_if_missing:
             raise FileNotFoundError("%s is missing (the reference downloads it separately, Dockerfile:5-6); "
                                     "set UMX_SYNTHETIC_WEIGHTS=1 to run with seeded synthetic weights" % shard)
         return ModelArtefacts(hp, random_blob(hp), mean, std)
-    blob = blob_from_checkpoint(hp, os.path.join(model_path, "model.ckpt"))
+    blob = blob_from_checkpoint(hp, os.path.join(model_path, prefix))
     return ModelArtefacts(hp, blob, mean, std)
