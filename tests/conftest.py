@@ -10,10 +10,8 @@ os.environ.setdefault("OMP_NUM_THREADS", _NT)
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 os.environ.setdefault("MKL_NUM_THREADS", _NT)
 
-# The test processes import torch at some point (oracles, sharding, the bench): bind libumx to torch's HIP runtime whatever the import
-# order.  The product default -- the system ROCm runtime unless torch is already imported -- is what the CLI subprocesses of
-# tests/test_gpu_cli.py run with (they drop this variable).
-os.environ.setdefault("UMX_HIP_RUNTIME", "torch")
+# (no UMX_HIP_RUNTIME here: libumx's default binding -- the runtime an installed PyTorch bundles, located without importing torch --
+# is what the test processes run on, whatever order they import torch and umx in; tests/test_host_logic.py covers the policy)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -90,7 +90,9 @@ def _expected_u8(name, raw):
 def test_legacy_script_with_model_flag_end_to_end(name, sample_file):
     """`python UnMicst.py 105.tif --model <name> --stackOutput` out of the box (the converted weights come from
     <repo>/models/<name>/umx_model.npz): pages in reversed class order, the preview = [class of page 1, raw / max]
-    (reference UnMicst.py:651-665); every page within 1 uint8 LSB of the same recipe run on the oracle."""
+    (reference UnMicst.py:651-665); every page against the same recipe run on the oracle: one fp16 ulp of the stitched plane
+    is one uint8 LSB after the first cast, and the reference's second cast np.uint8(255 * (v / 255)) maps some v to v - 1
+    (UnMicst.py:651-656), so a pixel may differ by 2 -- the bound tests/test_gpu_cli.py uses for the nucleiDAPI files."""
     base, img = sample_file
     out = str(base / ("out_" + name))
     env = {k: v for k, v in os.environ.items() if k not in ("UMX_MODELS_DIR", "UMX_HIP_RUNTIME", "UMX_PRECISION")}
@@ -106,7 +108,7 @@ def test_legacy_script_with_model_flag_end_to_end(name, sample_file):
     want = _expected_u8(name, raw)
     for page, k in enumerate(range(hp.nClasses)[::-1]):
         d = np.abs(stack[page].astype(int) - want[k].astype(int))
-        assert d.max() <= 1 and (d == 0).mean() > 0.97, (name, k, d.max(), (d == 0).mean())
+        assert d.max() <= 2 and (d <= 1).mean() > 0.9999 and (d == 0).mean() > 0.97, (name, k, d.max(), (d == 0).mean())
     assert np.array_equal(prev[0], stack[1])
     assert np.array_equal(prev[1], helpers.load_sample_105()[2])   # raw / max preview plane: the reference's own bytes
 

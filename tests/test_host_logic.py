@@ -207,3 +207,43 @@ def test_slabs_tile_the_owned_rows_and_only_need_computed_patch_rows():
                             hi = min(npr - 1, (s1 - 1 + m) // sub)     # last patch row touching the slab
                             assert hi < cuts[i + 1]
                     assert pos == y1
+
+
+def test_hip_runtime_binding_does_not_depend_on_import_order():
+    """`from unmicst_amd import umx, sharding; umx.Engine(...)` followed by a later `import torch` must not leave two
+    HIP runtimes in the process.  The default binds the runtime the installed PyTorch bundles WITHOUT importing torch (same
+    library whichever comes first); `system` is for the per-file tools, and the torch-facing helpers refuse to run on it."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+sys.path.insert(0, %r)
+order = sys.argv[1]
+if order == "torch-first":
+    import torch
+from unmicst_amd import umx, sharding
+umx.load()
+assert ("torch" in sys.modules) == (order == "torch-first")
+import torch
+want = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+mode = os.environ.get("UMX_HIP_RUNTIME", "auto")
+if mode == "system":
+    assert os.path.realpath(umx.hip_runtime) != os.path.realpath(want), umx.hip_runtime
+    try:
+        umx.require_torch_runtime("sharding.infer_image_sharded")
+    except RuntimeError as e:
+        assert "ONE HIP runtime" in str(e)
+    else:
+        raise SystemExit("mixing runtimes was not refused")
+else:
+    assert os.path.realpath(umx.hip_runtime) == os.path.realpath(want), umx.hip_runtime
+    umx.require_torch_runtime("sharding.infer_image_sharded")
+print("ok", order, mode)
+""" % helpers.ROOT
+    for order in ("umx-first", "torch-first"):
+        for mode in (None, "system"):
+            env = {k: v for k, v in os.environ.items() if k != "UMX_HIP_RUNTIME"}
+            if mode:
+                env["UMX_HIP_RUNTIME"] = mode
+            r = subprocess.run([sys.executable, "-c", code, order], capture_output=True, text=True, timeout=300, env=env)
+            assert r.returncode == 0 and "ok " + order in r.stdout, (order, mode, r.stdout[-500:], r.stderr[-1500:])

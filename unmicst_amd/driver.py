@@ -291,6 +291,9 @@ def run(tool: str, argv=None, script_dir: str = None) -> int:
 
 
 def main(tool: str, script_file: str) -> None:
+    # the per-file tools never import torch: they take the system ROCm runtime (umx._bind_hip_runtime: `system`; in every other
+    # process libumx binds the runtime an installed PyTorch bundles, so that a later `import torch` shares it)
+    os.environ.setdefault("UMX_HIP_RUNTIME", "system")
     rc = run(tool, None, os.path.dirname(os.path.realpath(script_file)))
     # every output file is written and closed, the engine destroyed: what is left is interpreter finalisation and the unloading of the
     # HIP runtime, 0.2 s of a 0.9 s tool.  UMX_NO_FAST_EXIT=1 leaves through sys.exit as usual.

@@ -62,6 +62,7 @@ def _geometry(eng, H: int, W: int):
 def infer_band_local(eng, d_image, mean: float, std: float, rank: int, world: int, mode: int, stitch: int):
     """What rank ``rank`` of ``world`` produces, computed stand-alone (the previous band's last patch row is
     recomputed instead of received).  Used by the 1-GPU bit-equality test and as the world_size == 1 path."""
+    umx.require_torch_runtime("sharding.infer_band_local")
     import torch
     hp = eng.hp
     C, H, W = d_image.shape
@@ -171,6 +172,7 @@ def infer_image_sharded(eng, d_band, band_row0: int, H: int, W: int, mean: float
          stitched and their all-gather starts asynchronously, overlapping the next slab's tiles.
     The stitch still visits tiles in ascending global index, so the result is bit-identical to a single-GPU run.
     """
+    umx.require_torch_runtime("sharding.infer_image_sharded")
     import torch
     import torch.distributed as dist
     hp = eng.hp

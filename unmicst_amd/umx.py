@@ -68,6 +68,20 @@ class ShardTransport(ctypes.Structure):
 
 
 _lib = None
+hip_runtime = None      # path of the libamdhip64 libumx was bound to (set by load())
+
+
+def _torch_hip_runtime() -> Optional[str]:
+    """Path of the libamdhip64 PyTorch bundles, WITHOUT importing torch (find_spec only locates the package)."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return None
+    if spec is None or not spec.origin:
+        return None
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    return cand if os.path.exists(cand) else None
 
 
 def _bind_hip_runtime() -> str:
@@ -75,23 +89,29 @@ def _bind_hip_runtime() -> str:
 
     libumx.so is linked without a HIP runtime dependency.  PyTorch wheels bundle their own libamdhip64 +
     libhsa-runtime64; a second copy (e.g. /opt/rocm's) initialised in the same process leaves one of the two
-    without a GPU.  Policy (UMX_HIP_RUNTIME = auto | torch | system, default auto): PyTorch's copy if PyTorch is ALREADY
-    imported in this process (bench.py, the multi-GPU path and the tests import it first: torch.distributed has to share
-    the runtime), else the system ROCm runtime -- the per-file command-line tools never need torch, and importing it only
-    to find a libamdhip64 cost them 1.5 - 2 s of a 2 - 3 s run (profiles/r04/cli_walltime.txt).  `torch`: import it if needed.
+    without a GPU.  Policy (UMX_HIP_RUNTIME = auto | torch | system, default auto):
+      auto    PyTorch's copy whenever a PyTorch with a bundled runtime is INSTALLED (located with find_spec and dlopen'ed
+              directly: torch itself is not imported, so the choice does not depend on import order and costs nothing) --
+              a later `import torch` in the process (sharding.py, the trainer's helpers, the oracles) then finds the very
+              runtime libumx already uses; the system ROCm runtime otherwise.
+      system  the system ROCm runtime.  The per-file command-line tools ask for it (driver.main: they never import torch, and
+              the system runtime initialises 0.1 s faster); mixing it with a later `import torch` is refused by
+              require_torch_runtime().
+      torch   import torch first (as rounds 1-4 did under the tests), then bind its copy.
     """
     import sys
     mode = os.environ.get("UMX_HIP_RUNTIME", "auto")
-    if mode == "torch" or (mode == "auto" and "torch" in sys.modules):
-        try:
-            import torch  # noqa: F401  (loads its bundled libamdhip64.so)
-            cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
-            if os.path.exists(cand):
-                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
-                return cand
-        except ImportError:
-            if mode == "torch":
-                raise
+    if mode not in ("auto", "torch", "system"):
+        raise ValueError("UMX_HIP_RUNTIME must be auto, torch or system (got %r)" % mode)
+    if mode == "torch":
+        import torch  # noqa: F401  (loads its bundled libamdhip64.so)
+    if mode in ("auto", "torch"):
+        cand = _torch_hip_runtime()
+        if cand is not None:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+            return cand
+        if "torch" in sys.modules and mode == "torch":
+            raise OSError("UMX_HIP_RUNTIME=torch: this PyTorch bundles no libamdhip64")
     for cand in (os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "libamdhip64.so"), "libamdhip64.so.7",
                  "libamdhip64.so"):
         try:
@@ -102,16 +122,28 @@ def _bind_hip_runtime() -> str:
     raise OSError("no HIP runtime (libamdhip64) found; libumx has no CPU fallback")
 
 
+def require_torch_runtime(who: str) -> None:
+    """Called by the torch-facing helpers (unmicst_amd/sharding.py, bench.py) before they hand torch tensors to libumx:
+    refuses to run when libumx is bound to another HIP runtime than the one PyTorch brings -- two runtimes in one process and
+    one of them loses the GPU (the symptom is hipErrorNoDevice or a hang far from the cause)."""
+    load()
+    want = _torch_hip_runtime()
+    if want is not None and hip_runtime is not None and os.path.realpath(want) != os.path.realpath(hip_runtime):
+        raise RuntimeError("%s needs libumx and PyTorch on ONE HIP runtime, but libumx is bound to %s and PyTorch brings %s "
+                           "(UMX_HIP_RUNTIME=%s): leave UMX_HIP_RUNTIME unset (auto) in processes that import torch"
+                           % (who, hip_runtime, want, os.environ.get("UMX_HIP_RUNTIME", "auto")))
+
+
 def load(path: Optional[str] = None):
     """dlopen libumx.so (built in-tree by unmicst_amd.build); raises if it is missing."""
-    global _lib
+    global _lib, hip_runtime
     if _lib is not None:
         return _lib
     path = path or os.environ.get("UMX_LIB") or _build.lib_path()   # UMX_LIB: an alternative build (kernel experiments)
     if not os.path.exists(path):
         raise FileNotFoundError("%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                 "(libumx has no CPU fallback)" % path)
-    _bind_hip_runtime()
+    hip_runtime = _bind_hip_runtime()
     L = ctypes.CDLL(path)
     c_int, c_void_p, c_double = ctypes.c_int, ctypes.c_void_p, ctypes.c_double
     ip = ctypes.POINTER(c_int)
