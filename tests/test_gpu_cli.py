@@ -78,6 +78,34 @@ def test_wrapper_subprocess_stack_output(workspace):
     assert total.min() >= 250 and total.max() <= 256      # three truncated probabilities sum to ~255
 
 
+def test_compat_per_class_writes_the_same_bytes(workspace):
+    """--compat-per-class (the reference's loop: one whole pass per class, UnMicst.py:651-674): host-side
+    pre-processing + one engine pass per class written, against the default single pass on the device.  Same files, byte for
+    byte; the flag travels through the wrapper."""
+    base, models, img = workspace
+    os.environ["UMX_MODELS_DIR"] = models
+    calls = []
+    real = UNet2D.singleImageInferenceAll.__func__ if hasattr(UNet2D.singleImageInferenceAll, "__func__") else UNet2D.singleImageInferenceAll
+    try:
+        UNet2D.singleImageInferenceAll = staticmethod(lambda image, mode: (calls.append(1), real(image, mode))[1])
+        a, b = str(base / "out_pc_a"), str(base / "out_pc_b")
+        assert driver.run("unmicst-legacy", [img, "--channel", "1", "--stackOutput", "--outputPath", a]) == 0
+        assert calls == []                                   # the default path never takes the per-class entry
+        assert driver.run("unmicst-legacy", [img, "--channel", "1", "--stackOutput", "--outputPath", b, "--compat-per-class"]) == 0
+        assert len(calls) == 3 and UNet2D.reuse_pass is True  # one whole pass per class; the switch is restored
+    finally:
+        UNet2D.singleImageInferenceAll = staticmethod(real)
+        del os.environ["UMX_MODELS_DIR"]
+    for name in ("105_Probabilities_2.tif", os.path.join("qc", "105_Preview_2.tif")):
+        assert np.array_equal(tiffio.imread_all(os.path.join(a, name)), tiffio.imread_all(os.path.join(b, name))), name
+    wrapper = __import__("importlib").util.spec_from_file_location("unmicstWrapper", os.path.join(ROOT, "unmicstWrapper.py"))
+    m = __import__("importlib").util.module_from_spec(wrapper)
+    wrapper.loader.exec_module(m)
+    tool, argv = m.script_argv(m.parse(["--tool", "unmicst-legacy", "--compat-per-class", img]))
+    assert tool == "unmicst-legacy" and argv[-1] == "--compat-per-class"
+    assert "--compat-per-class" not in m.script_argv(m.parse(["--tool", "unmicst-legacy", img]))[1]
+
+
 def test_default_output_dir_and_scaling(workspace):
     base, models, img = workspace
     os.environ["UMX_MODELS_DIR"] = models

@@ -26,6 +26,9 @@ def parse(argv=None):
     p.add_argument("--outlier", help="map percentile intensity to max when rescaling intensity values. "
                                      "Max intensity as default", type=float, default=-1)
     p.add_argument("--verbose", help="display error messages for debugging", action="store_true")
+    # (not in the reference: A/B timing of its one-pass-per-class loop, unmicst_amd/driver.py)
+    p.add_argument("--compat-per-class", dest="compat_per_class", action="store_true",
+                   help="A/B timing only: one full inference pass per output class, like the reference")
     return p.parse_args(argv)
 
 
@@ -53,6 +56,8 @@ def script_argv(a):
         argv += ["--classOrder"] + [str(c - 1) for c in a.classOrder[:3]]
     if a.verbose and tool != "UnMicstCyto2":
         argv.append("--verbose")
+    if a.compat_per_class:
+        argv.append("--compat-per-class")
     return tool, argv
 
 

@@ -76,6 +76,11 @@ def build_parser(spec: ToolSpec) -> argparse.ArgumentParser:
                                      "Max intensity as default", type=float, default=-1)
     if spec.has_verbose:
         p.add_argument("--verbose", help="display error messages for debugging", action="store_true")
+    # the one flag the reference does not have: the reference runs the whole slide once PER CLASS
+    # (UnMicst1-5.py:845-863); here one pass yields every class.  For A/B timing this switch takes the reference's shape:
+    # host-side pre-processing, then one full pass of the engine per class written.  Same bytes in the files.
+    p.add_argument("--compat-per-class", dest="compat_per_class", action="store_true",
+                   help="A/B timing only: one full inference pass per output class, like the reference (same output bytes)")
     return p
 
 
@@ -198,6 +203,7 @@ def run(tool: str, argv=None, script_dir: str = None) -> int:
         raise
     print("Using GPU " + str(UNet2D.Engine.device))
     st.mark("setup")
+    reuse_before = UNet2D.reuse_pass
     try:
         n_class = UNet2D.hp["nClasses"]
         image_path = args.imagePath
@@ -234,7 +240,10 @@ def run(tool: str, argv=None, script_dir: str = None) -> int:
         # --outlier percentile, exact by radix selection) + rescale, the double uint8 cast -- runs on the GPU next to the
         # inference (umx_infer_image_raw / _raw_scaled / _raw_outlier): no float64 upload / float16 download.
         fast = (all(r.dtype in (np.uint8, np.uint16) for r in raws)
-                and len({(r.shape, r.dtype) for r in raws}) == 1 and not os.environ.get("UMX_NO_RAW_PATH"))
+                and len({(r.shape, r.dtype) for r in raws}) == 1 and not os.environ.get("UMX_NO_RAW_PATH")
+                and not args.compat_per_class)
+        if args.compat_per_class:
+            UNet2D.reuse_pass = False            # every singleImageInference below is a whole pass (UnMicst1-5.py:848,867,872)
         preview_job = None
         if fast:
             stack_raw = np.stack(raws) if spec.n_inputs == 2 else raws[0]
@@ -284,6 +293,8 @@ def run(tool: str, argv=None, script_dir: str = None) -> int:
             tiffio.imsave(out_dir + "//" + stem + "_NucleiPM_" + suffix + ".tif", plane_u8(class_order[2]), append=False)
         st.mark("write")
     finally:
+        if args.compat_per_class:
+            UNet2D.reuse_pass = reuse_before
         UNet2D.singleImageInferenceCleanup()
         st.mark("cleanup")
         st.report()
