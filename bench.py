@@ -69,13 +69,10 @@ def parse_args(argv=None):
     ap.add_argument("--slabs", type=int, default=2, help="N>1 path: row slabs per band (stitch + async all-gather each)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N>1 code path (band halo exchange + slab all-gathers) even in a world of one rank")
-    ap.add_argument("--native-shard", action="store_true", help="(the default since round 4; kept for old command lines)")
-    ap.add_argument("--torch-shard", action="store_true",
-                    help="N>1 path through unmicst_amd/sharding.py over torch.distributed instead of the C ABI "
-                         "(umx_infer_image_sharded_dev: RCCL inside libumx, the default; torch only hands the communicator id to "
-                         "the ranks, and sharding.py checks the first slide)")
+    ap.add_argument("--native-shard", action="store_true", help="(the only N>1 path; kept for old command lines)")
     ap.add_argument("--resident-only", action="store_true",
                     help="time only the HBM-resident slide (kernel-only; the line's value is then NOT the section-8(d) metric)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the exact-fp32 and training legs of the default N = 1 line")
     ap.add_argument("--master-port", type=int, default=29577)
     ap.add_argument("--dry-launch", action="store_true",
                     help="N>1 launch test: every rank prints its rank/world line and exits before touching a GPU")
@@ -228,8 +225,9 @@ def ranks_block(dist, torch, hp, H, W, rank, agree, dev=None):
             "per_rank": [{"rank": i, "patch_row0": g[0], "patch_row1": g[1], "tiles": g[2], "owned_image_rows": [int(o[0]), int(o[1])]}
                          for i, (g, o) in enumerate(zip(gathered, owned))],
             "tiles_total": int(sum(g[2] for g in gathered)),
-            "allgather_bytes_per_step": {"contributed_per_rank": [int(K * max(o[1] - o[0], 0) * W * 2) for o in owned],
-                                         "received_per_rank": int(K * H * W * 2)},
+            # (uint8 planes since round 5: the stitched slabs are cast before they are gathered)
+            "allgather_bytes_per_step": {"contributed_per_rank": [int(K * max(o[1] - o[0], 0) * W) for o in owned],
+                                         "received_per_rank": int(K * H * W), "element": "uint8"},
             "host_path_equals_resident_path_all_ranks": agree_all}
 
 
@@ -334,96 +332,77 @@ def main():
             eng.infer_image_dev(band_f64.data_ptr(), C_img, H, W, mean, std, umx.MODE_ACCUMULATE, umx.STITCH_FP16_COMPAT,
                                 dev_out.data_ptr())
     else:
-        def torch_call(band):
-            return sharding.infer_image_sharded(eng, band, r0, H, W, mean, std, umx.MODE_ACCUMULATE,
-                                                umx.STITCH_FP16_COMPAT, nslabs=args.slabs, sync=False)
-        sharded_call = torch_call
-        shard_path = {"path": "unmicst_amd/sharding.py over torch.distributed", "native_checked_against_torch_path": None, "note": None}
-        if not args.torch_shard:
-            # the in-library schedule (RCCL inside libumx).  Every rank tries; the world agrees (MIN over the ranks) before anyone
-            # uses it, and its first slide is compared with sharding.py's on every rank: anything short of bit-equality and the
-            # whole world times the torch path instead, saying so in the line.
-            note = None
-            try:
-                idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-                if rank == 0:
-                    idt.copy_(torch.frombuffer(bytearray(umx.Engine.shard_unique_id()), dtype=torch.uint8))
-                dist.broadcast(idt, 0)
-                eng.shard_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
-                full_native = torch.empty((K, H, W), dtype=torch.float16, device=dev)
-
-                def native_call(band):
-                    eng.infer_image_sharded_dev(band.data_ptr(), C_img, H, W, r0, band.shape[1], mean, std, umx.MODE_ACCUMULATE,
-                                                umx.STITCH_FP16_COMPAT, args.slabs, full_native.data_ptr())
-                    return full_native
-                okv = 1
-            except Exception as e:   # noqa: BLE001
-                okv, note = 0, "native init failed on rank %d: %s" % (rank, e)
-            flag = torch.tensor([okv], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                try:
-                    with torch.cuda.stream(work):
-                        a = native_call(band_f64).clone()
-                        b = torch_call(band_f64)
-                        same = torch.tensor([1 if torch.equal(a, b) else 0], dtype=torch.int32, device=dev)
-                    work.synchronize()
-                except Exception as e:   # noqa: BLE001  (an error the library reports, not a hang: the world still agrees below)
-                    same = torch.tensor([0], dtype=torch.int32, device=dev)
-                    shard_path["note"] = "native first slide failed on rank %d: %s" % (rank, e)
-                dist.all_reduce(same, op=dist.ReduceOp.MIN)
-                if int(same.item()) == 1:
-                    sharded_call = native_call
-                    shard_path = {"path": "umx_infer_image_sharded_dev (RCCL inside libumx)", "native_checked_against_torch_path": True,
-                                  "note": None}
-                else:
-                    shard_path["native_checked_against_torch_path"] = False
-                    shard_path["note"] = shard_path["note"] or "the native path's first slide differed from sharding.py's on some rank: torch path timed"
-            else:
-                shard_path["note"] = note or "native init failed on another rank: torch path timed"
+        # N > 1 (and --force-sharded at N = 1): the SAME product path as the N = 1 line, band by band -- umx_infer_image_sharded_raw_submit:
+        # this rank's uint16 rows up from pinned host memory piece by piece under the tiles, im2double in the tile gather, stitched
+        # slabs cast to uint8 and all-gathered over RCCL, the rank's own rows down to pinned host memory, two slides in flight on the
+        # library's copy streams.  No torch op inside the timed region.  unmicst_amd/sharding.py (the same schedule over
+        # torch.distributed) only CHECKS the first slide; a world that cannot run the native path fails loudly instead of timing another one.
+        umx.require_torch_runtime("bench.py --gpus N")
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(umx.Engine.shard_unique_id()), dtype=torch.uint8))
+        if world > 1:
+            dist.broadcast(idt, 0)
+        eng.shard_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
         y0, y1 = sharding.owned_rows(pa, pb, npr, sub, margin, H)
-        # slides are streamed: the band of slide i+1 goes up on `up` and the stitched band of slide i-1 comes down on `dn`
-        # while slide i computes on `work` (two device input buffers, two pinned output buffers, events between the streams)
-        up, dn = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-        host_bands = [torch.empty((K, max(y1 - y0, 0), W), dtype=torch.float16).pin_memory() for _ in range(2)]
-        dev_u16s = [torch.empty((C_img, rows, W), dtype=torch.int16, device=dev) for _ in range(2)]
-        conv_done = [None, None]
+        full_f16 = torch.empty((K, H, W), dtype=torch.float16, device=dev)
+        fulls_u8 = [torch.empty((K, H, W), dtype=torch.uint8, device=dev) for _ in range(2)]
+        host_owns = [torch.empty((K, max(y1 - y0, 0), W), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        inflight = []
 
-        def step_host():   # H2D of this rank's band + tiles + halo exchange + stitch + all-gather + D2H of its stitched band
-            i = step_host.n & 1
+        def native_dev(band):
+            eng.infer_image_sharded_dev(band.data_ptr(), C_img, H, W, r0, band.shape[1], mean, std, umx.MODE_ACCUMULATE,
+                                        umx.STITCH_FP16_COMPAT, args.slabs, full_f16.data_ptr())
+            return full_f16
+        # first slide, outside the timed region: (1) the in-library schedule on the float64 band == sharding.py's over torch.distributed;
+        # (2) the raw entry's gathered uint8 stack and own rows == the drivers' uint8 recipe applied to (1)
+        with torch.cuda.stream(work):
+            a = native_dev(band_f64).clone()
+            b = sharding.infer_image_sharded(eng, band_f64, r0, H, W, mean, std, umx.MODE_ACCUMULATE, umx.STITCH_FP16_COMPAT,
+                                             nslabs=args.slabs, sync=False)
+            same_sched = bool(torch.equal(a, b))
+            first = (a * 255.0).to(torch.uint8)
+            want_u8 = (255.0 * (first.to(torch.float64) * (1.0 / 255))).to(torch.uint8)
+            del a, b, first
+        work.synchronize()
+        eng.infer_image_sharded_raw_submit(0, host_u16.data_ptr(), 16, C_img, H, W, r0, rows if pb > pa else 0, None, mean, std,
+                                           umx.MODE_ACCUMULATE, args.slabs, host_owns[0].data_ptr() if y1 > y0 else 0,
+                                           fulls_u8[0].data_ptr())
+        eng.infer_image_wait(0)
+        same_raw = bool(torch.equal(fulls_u8[0], want_u8)) and bool(torch.equal(host_owns[0], want_u8[:, y0:y1].cpu()))
+        okv = torch.tensor([1 if (same_sched and same_raw) else 0], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(okv, op=dist.ReduceOp.MIN)
+        if int(okv.item()) != 1:
+            print("bench.py: rank %d: the native sharded path is not bit-equal to its checkers (schedule vs sharding.py: %s, raw entry vs "
+                  "the uint8 recipe: %s) on some rank -- refusing to time anything else" % (rank, same_sched, same_raw), file=sys.stderr)
+            sys.exit(4)
+        del want_u8
+        shard_path = {"path": "umx_infer_image_sharded_raw_submit (RCCL inside libumx; uint16 band up, uint8 slabs gathered, own rows down)",
+                      "first_slide_equals_sharding_py_and_uint8_recipe_all_ranks": True, "note": None}
+
+        def step_host():   # H2D of this rank's band + tiles + halo exchange + stitch + uint8 all-gather + D2H of its own rows
+            slot = step_host.n & 1
             step_host.n += 1
-            with torch.cuda.stream(up):
-                if conv_done[i] is not None:
-                    up.wait_event(conv_done[i])          # the buffer's previous contents have been converted
-                dev_u16s[i].copy_(host_u16, non_blocking=True)
-                ev_up = up.record_event()
-            with torch.cuda.stream(work):
-                work.wait_event(ev_up)
-                band = (dev_u16s[i].to(torch.int32) & 0xFFFF).to(torch.float64) * (1.0 / 65535)
-                conv_done[i] = work.record_event()
-                full = sharded_call(band)
-                ev_full = work.record_event()
-            with torch.cuda.stream(dn):
-                dn.wait_event(ev_full)
-                host_bands[i].copy_(full[:, y0:y1], non_blocking=True)
-                full.record_stream(dn)
-            return full
+            if len(inflight) == 2:
+                eng.infer_image_wait(inflight.pop(0))
+            eng.infer_image_sharded_raw_submit(slot, host_u16.data_ptr(), 16, C_img, H, W, r0, rows if pb > pa else 0, None, mean, std,
+                                               umx.MODE_ACCUMULATE, args.slabs, host_owns[slot].data_ptr() if y1 > y0 else 0,
+                                               fulls_u8[slot].data_ptr())
+            inflight.append(slot)
+            return fulls_u8[slot]
         step_host.n = 0
 
         def step_resident():
             with torch.cuda.stream(work):
-                return sharded_call(band_f64)
+                return native_dev(band_f64)
 
     def fence():
-        if not sharded:
-            while inflight:
-                eng.infer_image_wait(inflight.pop(0))
+        while inflight:
+            eng.infer_image_wait(inflight.pop(0))
         eng.synchronize()            # also surfaces UMX_ERR_RANGE of the split-precision path
         work.synchronize()
-        if sharded:
-            up.synchronize()
-            dn.synchronize()
-        if sharded:
+        if sharded and world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -466,13 +445,22 @@ def main():
                 return time.perf_counter() - t0
             ns = max(3, min(args.steps, 10))
             dts = timed_sync(step_sync, ns)
+            crc_sync = crc32_of(sync_out)
             # (round 3's form of the same call: the whole upload and a device reduction in front of the first tile)
+            range_before = os.environ.get("UMX_HOST_RANGE")
             os.environ["UMX_HOST_RANGE"] = "0"
             nd = max(2, ns // 3)
-            dtd = timed_sync(step_sync, nd)
-            del os.environ["UMX_HOST_RANGE"]
+            try:
+                dtd = timed_sync(step_sync, nd)
+            finally:
+                if range_before is None:
+                    del os.environ["UMX_HOST_RANGE"]
+                else:
+                    os.environ["UMX_HOST_RANGE"] = range_before
             host_sync = {"value": round(tiles_total * ns / dts, 2), "unit": "tiles/s", "ms_per_call": round(1e3 * dts / ns, 3),
                          "calls": ns, "device_range": {"value": round(tiles_total * nd / dtd, 2), "ms_per_call": round(1e3 * dtd / nd, 3)},
+                         # (rescaled planes: another computation than `value`, so another CRC -- but the same one from both forms)
+                         "crc32_u8_planes": crc_sync, "device_range_same_bytes": crc32_of(sync_out) == crc_sync,
                          "note": "synchronous umx_infer_image_raw(rescale=1), one slide at a time: the per-file driver's call -- the "
                                  "planes' (min, max) by host threads while the rows cross the bus, tiles start on the first slab; "
                                  "device_range (UMX_HOST_RANGE=0): whole upload + device min/max first, as in round 3 "
@@ -518,10 +506,20 @@ def main():
                 first = (dev_out * 255.0).to(torch.uint8)
                 want_u8 = (255.0 * (first.to(torch.float64) * (1.0 / 255))).to(torch.uint8).cpu()
             agree = None if want_u8 is None else bool(torch.equal(want_u8, host_outs[0]) and torch.equal(want_u8, host_outs[1]))
-            checksum = float(dev_out.float().mean().item())
+            # a checksum that depends on the data: CRC-32 of the uint8 planes the host path delivered, next to the same of the
+            # drivers' uint8 recipe applied to the resident path's fp16 planes (equal iff every byte agrees)
+            checksum = None if want_u8 is None else {"crc32_u8_planes_host_path": crc32_of(host_outs[0]),
+                                                     "crc32_u8_planes_resident_path": crc32_of(want_u8)}
         else:
-            agree = None if host_elapsed is None else bool(torch.equal(res_h, res_r))
-            checksum = float(res_r.float().mean().item())
+            agree = None
+            if host_elapsed is not None:   # (both gathered stacks of the host path against the uint8 recipe on the resident path's)
+                first = (res_r * 255.0).to(torch.uint8)
+                want = (255.0 * (first.to(torch.float64) * (1.0 / 255))).to(torch.uint8)
+                agree = bool(torch.equal(want, fulls_u8[0]) and torch.equal(want, fulls_u8[1])
+                             and torch.equal(want[:, y0:y1].cpu(), host_owns[0]) and torch.equal(want[:, y0:y1].cpu(), host_owns[1]))
+                del first, want
+            checksum = None if host_elapsed is None else {"crc32_u8_own_rows_host_path": crc32_of(host_owns[0]),
+                                                          "crc32_u8_stack_gathered": crc32_of(fulls_u8[0].cpu())}
     elapsed, prof = (host_elapsed, host_prof) if host_elapsed is not None else (res_elapsed, res_prof)
     ranks = ranks_block(dist if sharded else None, torch, hp, H, W, rank, agree)
 
@@ -534,13 +532,24 @@ def main():
         cpu = None
         if world == 1 and args.cpu_seconds > 0:
             cpu = cpu_baseline(hp, blob, band_f64, mean, std, args.cpu_seconds)
+        # two short legs the default line carries at N = 1: the exact-fp32 engine on the 2048-row band and the
+        # training step of BASELINE configs[4]; `--no-legs` (or any non-default workload / N > 1) skips them
+        f32 = train = None
+        if world == 1 and not sharded and args.workload == "wsi-synth256" and not args.no_legs and not args.resident_only:
+            eng.close()
+            del band_f64
+            torch.cuda.empty_cache()
+            if eng.precision != "f32":
+                f32 = f32_leg(torch, umx, hp, blob, local_rank, args.batch, host_u16, C_img, W, mean, std)
+            train = train_leg(torch, dev)
         up_b = C_img * H * W * 2
-        dn_b = K * H * W * (1 if not sharded else 2)
+        dn_b = K * H * W
         scope = ("H2D+D2H inside the timed region: uint16 planes up (%.0f MB), uint8 probability planes down (%.0f MB), "
                  "per launch group on two copy streams under the tile kernels (umx_infer_image_raw_submit / _wait, two slides "
                  "in flight; im2double on the device, no intensity rescale as in the solo driver)" % (up_b / 1e6, dn_b / 1e6)) if not sharded else (
-                 "H2D+D2H inside the timed region: each rank uploads its uint16 band and downloads its stitched fp16 band; "
-                 "band halo exchange + slab-wise RCCL all-gather of the fp16 stack on every rank")
+                 "H2D+D2H inside the timed region: each rank uploads its uint16 band and downloads its own rows as uint8 planes "
+                 "(umx_infer_image_sharded_raw_submit / umx_infer_image_wait, two slides in flight; im2double on the device, no intensity "
+                 "rescale as in the solo driver); band halo exchange + slab-wise RCCL all-gather of the uint8 stack on every rank")
         if args.resident_only:
             scope = "slide resident in HBM, result left in HBM (kernel-only; NOT the section-8(d) metric)"
         line = {
@@ -560,12 +569,112 @@ def main():
                          "ms_per_step": round(1e3 * res_elapsed / args.steps, 3),
                          "note": "same slide already in HBM as float64, result left in HBM (no H2D / D2H): kernel-only"},
             "host_sync": host_sync, "weak_band": weak_band, "ranks": ranks, "shard_path": shard_path if sharded else None,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "f32": f32, "train": train,
+            "workload_note": "the default workload is the full 16384 x 16384 slide at every N since round 4 (rounds 1-3 quoted its first "
+                             "2048 rows: `weak_band` carries that line)",
         }
         print(json.dumps(line))
     eng.close()
     if sharded:
         dist.destroy_process_group()
+
+
+def crc32_of(t):
+    """CRC-32 of a host tensor's bytes (zlib; 0.4 s per GB): a checksum that depends on every output byte."""
+    import zlib
+    a = t.contiguous().view(-1).numpy()
+    crc = 0
+    step = 1 << 26
+    for i in range(0, a.size, step):
+        crc = zlib.crc32(a[i:i + step].tobytes() if a.dtype.itemsize != 1 else memoryview(a[i:i + step]), crc)
+    return crc & 0xFFFFFFFF
+
+
+def f32_leg(torch, umx, hp, blob, local_rank, batch, host_u16, C_img, W, mean, std, steps=4):
+    """The exact-fp32 MFMA kernels (UMX_PREC_F32: v_mfma_f32_16x16x4_f32, bit for bit an fp32 fma chain) on the first 2048 rows
+    of the same slide, same host path (H2D + D2H inside): what a model that leaves binary16's range falls back to."""
+    Hb = min(2048, host_u16.shape[1])
+    K = hp.nClasses
+    eng = umx.Engine(hp, blob, device=local_rank, max_batch=batch, precision="f32")
+    try:
+        npr, npc, _, _ = eng.tile_grid(Hb, W)
+        band = torch.empty((C_img, Hb, W), dtype=torch.int16).pin_memory()
+        band.copy_(host_u16[:, :Hb])
+        outs = [torch.empty((K, Hb, W), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        inflight = []
+
+        def step(i):
+            slot = i & 1
+            if len(inflight) == 2:
+                eng.infer_image_wait(inflight.pop(0))
+            eng.infer_image_raw_submit(slot, band.data_ptr(), 16, C_img, Hb, W, False, mean, std, outs[slot].data_ptr())
+            inflight.append(slot)
+
+        def drain():
+            while inflight:
+                eng.infer_image_wait(inflight.pop(0))
+            eng.synchronize()
+        step(0)
+        drain()
+        eng.profile_enable(1)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        drain()
+        dt = time.perf_counter() - t0
+        prof = eng.profile_read()
+        eng.profile_enable(False)
+        convs = [p for p in prof if p["kernel"].startswith("conv_")]
+        ms = sum(p["total_ms"] for p in convs)
+        fl = sum(p["flops"] for p in convs)
+        tiles = npr * npc
+        whole = hp.flops_per_tile() * tiles * steps / dt / 1e12
+        return {"value": round(tiles * steps / dt, 2), "unit": "tiles/s", "tiles_per_step": int(tiles), "slide": [int(Hb), int(W)],
+                "steps": steps, "ms_per_step": round(1e3 * dt / steps, 3), "dtype": "f32",
+                "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                             "all_conv_launches": {"achieved": round(fl / (ms * 1e-3) / 1e12, 2),
+                                                   "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)},
+                             "whole_step": {"achieved": round(whole, 2), "frac": round(whole / PEAK_F32_MFMA_TFLOPS, 4)}},
+                "crc32_u8_planes": crc32_of(outs[0]),
+                "note": "exact-fp32 MFMA engine (precision f32) on the first 2048 rows of the same slide, same host path"}
+    finally:
+        eng.close()
+
+
+def train_leg(torch, dev, B=8, steps=100, warmup=10):
+    """BASELINE.json configs[4] inside the default line: forward + backward + Adam on random 256x256x2 batches resident in HBM
+    (the reference's sess.run([optOp ...]), UnMicst1-5.py:483-484), timed like `--workload train-synth256`."""
+    from unmicst_amd import model, trainer
+    hp = model.KNOWN_HP["synthetic-256"]
+    blob = model.random_blob(hp, seed=20260101)
+    tr = trainer.Trainer(hp, blob, trainer.duo_options(), batch=B, device=dev.index or 0)
+    try:
+        g = torch.Generator(device="cpu").manual_seed(20260101)
+        nb = 4
+        data = torch.randn((nb, B, hp.imSize, hp.imSize, hp.nChannels), generator=g).to(dev)
+        cls = torch.randint(0, hp.nClasses, (nb, B, hp.imSize, hp.imSize), generator=g)
+        labels = torch.nn.functional.one_hot(cls, hp.nClasses).float().to(dev)
+        weights = (0.5 + 2.5 * torch.rand((nb, B, hp.imSize, hp.imSize, hp.nClasses), generator=g)).to(dev)
+        torch.cuda.synchronize(dev)
+        for i in range(warmup):
+            tr.step_dev(data[i % nb].data_ptr(), labels[i % nb].data_ptr(), weights[i % nb].data_ptr())
+        first = tr.loss()[0]
+        t0 = time.perf_counter()
+        for i in range(steps):
+            j = (warmup + i) % nb
+            tr.step_dev(data[j].data_ptr(), labels[j].data_ptr(), weights[j].data_ptr())
+        last = tr.loss()[0]                        # synchronises the trainer's stream
+        dt = time.perf_counter() - t0
+        tflops = tr.flops_per_image * B * steps / dt / 1e12
+        return {"value": round(B * steps / dt, 2), "unit": "images/s", "images_per_s": round(B * steps / dt, 2), "batch": B, "steps": steps,
+                "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 3), "flop_per_image": tr.flops_per_image,
+                "loss_first": first, "loss_last": last,
+                "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(tflops / PEAK_F16_MFMA_TFLOPS, 4)},
+                "dtype": "f16x3 convolutions, fp32 / fp64 elsewhere",
+                "note": "forward + backward + Adam, synthetic-256 hp (duo regime), random 256x256x2 batches resident in HBM"}
+    finally:
+        tr.close()
 
 
 def bench_train(args, torch):
@@ -670,7 +779,7 @@ def cpu_baseline_train(hp, blob, data, labels, weights, budget_s):
     t = time.perf_counter()
     to.loss_and_grads(hp, blob, data[:n], labels[:n], weights[:n], o, 0, dtype=torch.float32)
     dt = time.perf_counter() - t
-    return {"value": round(n / dt, 3), "unit": "images/s", "cores": best[1], "kind": "port",
+    return {"value": round(n / dt, 3), "unit": "images/s", "cores": best[1], "threads": best[1], "cores_granted": quota, "kind": "port",
             "sample": "forward+backward of %d image(s) of the same batch at the best of %d swept thread counts (oracle/train_oracle.py, "
                       "torch CPU float32, no optimiser update), %.1f s" % (n, len(sweep), dt),
             "host": host, "sweep": sweep}
@@ -795,12 +904,12 @@ def cpu_baseline(hp, blob, band_f64, mean, std, budget_s):
         pi2d_oracle.single_image_inference(crop2, lambda x: forward(x, fmt), P, hp.nChannels, mean, std, "accumulate", k, B)
     dtf = time.perf_counter() - t
     nft = pi2d_oracle.PI2DOracle(crop2, P, m, "accumulate").num_patches
-    return {"value": round(n / dt, 3), "unit": "tiles/s", "cores": nt, "kind": "port",
+    return {"value": round(n / dt, 3), "unit": "tiles/s", "cores": nt, "threads": nt, "cores_granted": quota, "kind": "port",
             "sample": "best effort: first %d tiles of the same slide at the best of %d swept settings (%d threads, batch %d, %s), one "
                       "pass for all classes (PI2D gather + normalise in numpy, UNet forward %s), %.1f s" % (
                           n, len(sweep), nt, B, fmt or "NHWC", what, dt),
             "host": host, "sweep": sweep,
-            "reference_faithful": {"value": round(nft / dtf, 3), "unit": "tiles/s", "cores": nt,
+            "reference_faithful": {"value": round(nft / dtf, 3), "unit": "tiles/s", "cores": nt, "threads": nt, "cores_granted": quota,
                                    "sample": "the reference's loop on a %d-tile crop: Python PI2D tile loop with float16 "
                                              "patchOutput, one full pass per class (%d passes), same forward and settings, %.1f s" % (
                                                  nft, hp.nClasses, dtf)}}

@@ -226,6 +226,25 @@ UMX_API int umx_infer_image_sharded_dev(umx_ctx* ctx, const double* band_dev, in
                                         int band_rows, double mean, double std, int mode, int stitch, int nslabs,
                                         void* out_full_dev);
 
+/* The sharded schedule fed like the one-GPU line (umx_infer_image_raw_submit; SURVEY section 8(e), no reference counterpart:
+ * UnMicst1-5.py:769 is single-device).  band_host = this rank's raw uint8 / uint16 rows [C_img, band_rows, W] (image rows
+ * [band_row0, band_row0 + band_rows) = need_row0 .. need_row1 of umx_shard_plan), staged piece by piece on the upload stream ahead
+ * of the tiles that read them; im2double happens in the tile gather.  range: NULL = no intensity rescale (the solo driver,
+ * UnMicst1-5.py:816-821); else the (min, max) of EACH WHOLE plane (2 words per plane, as for umx_infer_image_raw_range -- a rank
+ * holds only its band, the caller's reader saw the file) and the gather applies rescale_intensity to (0, 0.983).  Stitched slabs
+ * are cast to the drivers' uint8 (UnMicst1-5.py:848-854 at the identity grid) and all-gathered as uint8; every rank ends up with
+ * the full [nClasses, H, W] uint8 stack in out_full_dev (NULL: a buffer the library owns), and this rank's own rows
+ * [own_row0, own_row1) go down to own_out_host [nClasses, own rows, W] (NULL: no download) on the download stream under the next
+ * slab's tiles.  _submit enqueues on `slot` (0 or 1) and returns; umx_infer_image_wait(ctx, slot) completes it (errors,
+ * UMX_ERR_RANGE included); band_host / own_out_host / out_full_dev must stay valid until then.  Collective over the world of
+ * umx_shard_init.  Bit-identical, row for row, to umx_infer_image_raw[_range] of the whole slide on one GPU. */
+UMX_API int umx_infer_image_sharded_raw_submit(umx_ctx* ctx, int slot, const void* band_host, int bits, int C_img, int H, int W,
+                                               int band_row0, int band_rows, const uint32_t* range, double mean, double std,
+                                               int mode, int nslabs, uint8_t* own_out_host, uint8_t* out_full_dev);
+UMX_API int umx_infer_image_sharded_raw(umx_ctx* ctx, const void* band_host, int bits, int C_img, int H, int W, int band_row0,
+                                        int band_rows, const uint32_t* range, double mean, double std, int mode, int nslabs,
+                                        uint8_t* own_out_host, uint8_t* out_full_dev);
+
 /* Strip / tile decoders of the drivers' own TIFF reader (unmicst_amd/tiffio.py; the reference reads through tifffile /
  * imagecodecs, UnMicst1-5.py:794-797): TIFF 6.0 LZW (compression 5, the OME-TIFF / Bio-Formats default) and PackBits
  * (32773).  Host code, no device needed.  Return the decoded byte count (<= cap) or -1 on a malformed stream. */

@@ -40,7 +40,7 @@ def test_bench_gpus_2_launches_two_ranks():
     assert per[0]["owned_image_rows"][0] == 0 and per[0]["owned_image_rows"][1] == per[1]["owned_image_rows"][0]
     assert per[1]["owned_image_rows"][1] == 16384
     ag = blk["allgather_bytes_per_step"]
-    assert sum(ag["contributed_per_rank"]) == ag["received_per_rank"] == 3 * 16384 * 16384 * 2
+    assert sum(ag["contributed_per_rank"]) == ag["received_per_rank"] == 3 * 16384 * 16384 and ag["element"] == "uint8"   # (uint8 slabs since round 5)
 
 
 def test_bench_rejects_a_world_that_does_not_match_gpus():

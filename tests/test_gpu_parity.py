@@ -350,7 +350,8 @@ def test_native_sharded_entry_point_in_worlds_of_two_and_three(world, nslabs, tm
     routed through umx_shard_init_transport: `world` processes on cuda:0, every send / recv / all-gather staged through host memory
     over gloo behind the SAME function-pointer table umx_shard_init fills with RCCL (which refuses two ranks on one device).  Each
     rank holds only its band; every rank's full result must equal the single-process umx_infer_image bit for bit, in both stitch
-    modes' element sizes (fp16-compat here, fp32 below), for two slides in a row (buffer reuse)."""
+    modes' element sizes (fp16-compat here, fp32 below), for two slides in a row (buffer reuse).  Then the raw entry
+    (umx_infer_image_sharded_raw[_submit]) against umx_infer_image_raw[_range], byte for byte, also with two slides in flight."""
     import subprocess
     import sys
     script = tmp_path / "worker.py"
@@ -405,9 +406,44 @@ with umx.Engine(hp, blob, max_batch=8) as eng:
         same = np.array_equal(got.view(np.uint16 if dt == np.float16 else np.uint32), want.view(np.uint16 if dt == np.float16 else np.uint32))
         ok = ok and same
         print("rank %%d of %%d: %%d x %%d patch rows [%%d, %%d) equal=%%s calls=%%s" %% (rank, world, H, W, pl["patch_row0"], pl["patch_row1"], same, calls), flush=True)
-inner = 0 < rank < world - 1
-assert calls["send"] == (2 if rank < world - 1 else 0) and calls["recv"] == (2 if rank > 0 else 0), calls   # one halo row per slide
-assert calls["all_gather"] >= 2
+    # the raw entry (umx_infer_image_sharded_raw: raw uint16 / uint8 band up from the host, im2double [+ the drivers' rescale to the WHOLE
+    # planes' range] in the tile gather, slabs cast to uint8 before the gather, own rows down to the host) against the one-GPU
+    # umx_infer_image_raw[_range] of the whole slide: the gathered stack on every rank and the rank's own rows, byte for byte --
+    # synchronous, then two slides in flight on the two slots (per-slot gather buffers)
+    K = hp.nClasses
+    for (H, W, dt, rescale) in ((233, 97, np.uint16, False), (150, 120, np.uint16, True), (97, 61, np.uint8, True)):
+        top = 40000 if dt == np.uint16 else 200
+        raw = (np.random.default_rng(H + 1).random((2, H, W)) * top).astype(dt)
+        rng = [(int(raw[c].min()), int(raw[c].max())) for c in range(2)] if rescale else None
+        want = eng.infer_image_raw(raw, rescale, 0.2, 0.2, value_range=rng)
+        pl = eng.shard_plan(H, W, rank, world, nslabs)
+        r0, r1, o0, o1 = pl["need_row0"], pl["need_row1"], pl["own_row0"], pl["own_row1"]
+        band = np.ascontiguousarray(raw[:, r0:r1])                                           # only this rank's rows
+        full = torch.zeros((K, H, W), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        own = eng.infer_image_sharded_raw(band, H, W, r0, rng, 0.2, 0.2, nslabs=nslabs, own_rows=o1 - o0, out_full_ptr=full.data_ptr())
+        torch.cuda.synchronize()
+        same = np.array_equal(full.cpu().numpy(), want) and np.array_equal(own, want[:, o0:o1])
+        # two slides in flight: slot 1 is submitted while slot 0 is still running; the second slide is the first one flipped
+        raw2 = np.ascontiguousarray(raw[:, ::-1])
+        rng2 = rng
+        want2 = eng.infer_image_raw(raw2, rescale, 0.2, 0.2, value_range=rng2)
+        band2 = np.ascontiguousarray(raw2[:, r0:r1])
+        fulls = [torch.zeros((K, H, W), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        owns = [np.zeros((K, o1 - o0, W), np.uint8) for _ in range(2)]
+        torch.cuda.synchronize()
+        for slot, b in ((0, band), (1, band2)):
+            eng.infer_image_sharded_raw_submit(slot, b.ctypes.data if b.size else 0, 8 * b.dtype.itemsize, 2, H, W, r0, b.shape[1], rng, 0.2, 0.2,
+                                               umx.MODE_ACCUMULATE, nslabs, owns[slot].ctypes.data if owns[slot].size else 0, fulls[slot].data_ptr())
+        eng.infer_image_wait(0); eng.infer_image_wait(1)
+        torch.cuda.synchronize()
+        same2 = (np.array_equal(fulls[0].cpu().numpy(), want) and np.array_equal(fulls[1].cpu().numpy(), want2)
+                 and np.array_equal(owns[0], want[:, o0:o1]) and np.array_equal(owns[1], want2[:, o0:o1]))
+        ok = ok and same and same2
+        print("rank %%d of %%d: raw %%s %%d x %%d rescale=%%s own rows [%%d, %%d) equal=%%s in-flight equal=%%s" %% (rank, world, dt.__name__, H, W, rescale, o0, o1, same, same2), flush=True)
+slides = 2 + 3 * 3
+assert calls["send"] == (slides if rank < world - 1 else 0) and calls["recv"] == (slides if rank > 0 else 0), calls   # one halo row per slide
+assert calls["all_gather"] >= slides
 assert ok
 print("rank %%d native transport ok" %% rank, flush=True)
 dist.barrier()

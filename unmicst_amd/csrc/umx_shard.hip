@@ -24,7 +24,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/umx.h"
+#include "umx_internal.h"   // (same shared object: the raw entry stages its band like the host path of umx_host.hip)
 
 // internal accessors exported by umx_engine.hip (hidden visibility: same shared object only)
 hipStream_t umx_internal_stream(umx_ctx* ctx);
@@ -89,9 +89,10 @@ struct Shard {
     std::string tp_err;           // message of the last failed transport call (RCCL: ncclGetErrorString)
     int rank = 0, world = 1;
     hipStream_t comm_stream = nullptr;
-    std::vector<hipEvent_t> events;
-    Buf probs, slab, gathered;
-    std::vector<Buf> send;
+    std::vector<hipEvent_t> events[2];   // per call slot (the raw entry keeps two slides in flight; the device entry uses slot 0)
+    Buf probs, slab;                     // written and read in the order of the context's stream only
+    Buf gathered[2], full_u8[2];         // per slot: the communication stream of slide i may still read them under slide i+1's tiles
+    std::vector<Buf> send[2];
 };
 
 std::map<umx_ctx*, Shard> g_shards;
@@ -122,9 +123,9 @@ int grow(umx_ctx* ctx, Buf* b, size_t bytes) {
 void release(Shard& s) {
     if (s.comm && rccl()->CommDestroy) rccl()->CommDestroy(s.comm);
     if (s.comm_stream) hipStreamDestroy(s.comm_stream);
-    for (auto e : s.events) hipEventDestroy(e);
-    for (Buf* b : {&s.probs, &s.slab, &s.gathered}) if (b->d) hipFree(b->d);
-    for (auto& b : s.send) if (b.d) hipFree(b.d);
+    for (auto& ev : s.events) for (auto e : ev) hipEventDestroy(e);
+    for (Buf* b : {&s.probs, &s.slab, &s.gathered[0], &s.gathered[1], &s.full_u8[0], &s.full_u8[1]}) if (b->d) hipFree(b->d);
+    for (auto& v : s.send) for (auto& b : v) if (b.d) hipFree(b.d);
 }
 
 int rccl_fail(Shard* s, ncclResult_t r, const char* what) {
@@ -298,34 +299,48 @@ int umx_shard_plan(const umx_hparams* hpp, int H, int W, int rank, int world, in
     return UMX_OK;
 }
 
-int umx_infer_image_sharded_dev(umx_ctx* ctx, const double* band_dev, int C_img, int H, int W, int band_row0, int band_rows,
-                                double mean, double stdv, int mode, int stitch, int nslabs, void* out_full_dev) {
-    if (!ctx) return umx_internal_fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
-    if (!out_full_dev || H < 1 || W < 1) return umx_internal_fail(ctx, UMX_ERR_INVALID, "bad out / H / W");
-    Shard* sp;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        auto it = g_shards.find(ctx);
-        if (it == g_shards.end() || !it->second.ready)
-            return umx_internal_fail(ctx, UMX_ERR_INVALID, "call umx_shard_init (or umx_shard_init_transport) on this context first");
-        sp = &it->second;
-    }
-    Shard& s = *sp;
+}  // extern "C"
+
+namespace {
+
+// What one call of the schedule reads and writes.  Source: a float64 band on the device, or a raw integer band (the tile gather
+// converts, umx_conv_f16.hip gather_split_kernel) that is still on its way up -- then `band_host` is staged piece by piece on
+// `up_s` ahead of the tiles that read it.  Result: the stitched slabs as they are (fp16 / fp32), or cast to the drivers' uint8
+// (UnMicst1-5.py:848-854 at the identity grid) before they are gathered; optionally this rank's own rows also go down to
+// the host on `dn_s` as soon as their slab is final.
+struct RunIO {
+    const double* band_f64 = nullptr;
+    const void* raw_dev = nullptr;
+    int raw_bits = 0;
+    const unsigned* mm = nullptr;          // raw source with intensity rescale: the planes' (min, max) words, 16 apart
+    const void* band_host = nullptr;       // raw source: host rows to stage into raw_dev (NULL: raw_dev is complete)
+    hipStream_t up_s = nullptr, dn_s = nullptr;
+    int u8 = 0;
+    void* out_full = nullptr;              // [K, H, W] on the device, every rank
+    uint8_t* own_host = nullptr;           // u8 only: [K, own rows, W] on the host, this rank's rows
+    int slot = 0;
+    bool join = true;                      // the context's stream waits for the gathers at the end (device entry)
+    hipEvent_t* ev_gathered = nullptr;     // out: recorded on the communication stream behind the last scatter copy
+    hipEvent_t* ev_cs_end = nullptr;       // out: recorded on the context's stream behind the call's last kernel
+};
+
+int sharded_run(umx_ctx* ctx, Shard& s, const RunIO& io, int C_img, int H, int W, int band_row0, int band_rows, double mean,
+                double stdv, int mode, int stitch, int nslabs) {
     const umx_shard_transport& tp = s.tp;
 #define S_TP(ctx, expr)                                                                                       \
     do {                                                                                                      \
         s.tp_err.clear();                                                                                     \
         if ((expr) != 0) return fail(ctx, UMX_ERR_HIP, s.tp_err.empty() ? std::string(#expr " failed") : s.tp_err); \
     } while (0)
-    S_HIP(ctx, hipSetDevice(umx_internal_device(ctx)));
     hipStream_t cs = umx_internal_stream(ctx), ms = s.comm_stream;
     umx_hparams hp;
     umx_internal_hp(ctx, &hp);
     int npr = 0, npc = 0, rc;
     if ((rc = umx_tile_grid(ctx, H, W, &npr, &npc, nullptr, nullptr))) return rc;
     const int P = hp.imSize, K = hp.nClasses, margin = P / 8, sub = P - 2 * margin;
-    const size_t el = stitch == UMX_STITCH_FP32 ? 4 : 2;
-    const int world = s.world, rank = s.rank;
+    const size_t sel = stitch == UMX_STITCH_FP32 ? 4 : 2;   // element of the stitched slab
+    const size_t el = io.u8 ? 1 : sel;                      // element that is gathered
+    const int world = s.world, rank = s.rank, slot = io.slot;
     std::vector<int> A(world), B(world);
     std::vector<int> active;
     int n = std::max(1, nslabs);
@@ -340,22 +355,54 @@ int umx_infer_image_sharded_dev(umx_ctx* ctx, const double* band_dev, int C_img,
     const size_t tile_f = (size_t)P * P * K, row_f = tile_f * npc;
     if ((rc = grow(ctx, &s.probs, std::max<size_t>(1, (size_t)std::max(pb - lo, 0)) * row_f * sizeof(float)))) return rc;
     float* const probs = (float*)s.probs.d;
-    const int nev = 4 + 2 * n;
-    while ((int)s.events.size() < nev) {
+    std::vector<hipEvent_t>& evs = s.events[slot];
+    const int nev = 6 + 4 * n;
+    while ((int)evs.size() < nev) {
         hipEvent_t e;
         S_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        s.events.push_back(e);
+        evs.push_back(e);
     }
-    hipEvent_t ev_in = s.events[0], ev_last = s.events[1], ev_halo = s.events[2], ev_done = s.events[3];
+    hipEvent_t ev_in = evs[0], ev_last = evs[1], ev_halo = evs[2], ev_done = evs[3], ev_end = evs[4];
     // the communication stream starts behind whatever the caller queued on the context's stream
     S_HIP(ctx, hipEventRecord(ev_in, cs));
     S_HIP(ctx, hipStreamWaitEvent(ms, ev_in, 0));
+    // staged upload of a raw band: the rows of the band's LAST patch row go first (its tiles run first), then the rows of the slabs
+    // from the top; what is up = [band_row0, head) and [tail, band end)
+    const int band_end = band_row0 + band_rows;
+    int head = band_row0, tail = band_end, nup = 0;
+    const size_t in_b = io.raw_bits ? (size_t)io.raw_bits / 8 : sizeof(double);
+    auto stage = [&](int pr0, int pr1) -> int {
+        if (!io.band_host || pr1 <= pr0) return UMX_OK;
+        int a = std::max(band_row0, std::max(0, pr0 * sub - margin)), b = std::min(band_end, std::min(H, (pr1 - 1) * sub + P - margin));
+        a = std::max(a, head);
+        b = std::min(b, tail);
+        if (b <= a) return UMX_OK;
+        if (a > head && b < tail) a = head;          // (never with this schedule: keep the two intervals contiguous anyway)
+        for (int c = 0; c < C_img; ++c) {
+            const size_t off = ((size_t)c * band_rows + (a - band_row0)) * W * in_b;
+            S_HIP(ctx, hipMemcpyAsync((unsigned char*)io.raw_dev + off, (const unsigned char*)io.band_host + off, (size_t)(b - a) * W * in_b,
+                                      hipMemcpyHostToDevice, io.up_s));
+        }
+        if (a == head) head = b; else tail = a;
+        if (io.up_s != cs) {
+            hipEvent_t e = evs[6 + 2 * n + std::min(nup++, 2 * n - 1)];
+            S_HIP(ctx, hipEventRecord(e, io.up_s));
+            S_HIP(ctx, hipStreamWaitEvent(cs, e, 0));
+        }
+        return UMX_OK;
+    };
+    const umx::TileGeom g = umx::geom_of(hp, H, W);
     auto tiles = [&](int r0, int r1) -> int {
         if (r1 <= r0) return UMX_OK;
-        return umx_band_tiles_dev(ctx, band_dev, C_img, H, W, band_row0, band_rows, mean, stdv, r0, r1,
-                                  probs + (size_t)(r0 - lo) * row_f);
+        if ((rc = stage(r0, r1))) return rc;
+        float* const dst = probs + (size_t)(r0 - lo) * row_f;
+        if (io.raw_dev)
+            return umx::tiles_range(ctx, nullptr, C_img, g, band_row0, band_rows, mean, stdv, r0 * g.npc, r1 * g.npc, dst, io.raw_dev, io.raw_bits, io.mm);
+        return umx_band_tiles_dev(ctx, io.band_f64, C_img, H, W, band_row0, band_rows, mean, stdv, r0, r1, dst);
     };
-    if (pa < pb && (rc = tiles(pb - 1, pb))) return rc;            // last patch row first: the next rank waits for it
+    // last patch row first where a next rank waits for it (the last band -- and a world of one -- runs its rows in order: no odd
+    // launch group of one patch row)
+    if (has_next && (rc = tiles(pb - 1, pb))) return rc;
     S_HIP(ctx, hipEventRecord(ev_last, cs));
     S_HIP(ctx, hipStreamWaitEvent(ms, ev_last, 0));
     if (has_next || has_prev) {
@@ -366,7 +413,11 @@ int umx_infer_image_sharded_dev(umx_ctx* ctx, const double* band_dev, int C_img,
         if (tp.group_end) S_TP(ctx, tp.group_end(tp.user));
     }
     S_HIP(ctx, hipEventRecord(ev_halo, ms));
-    if ((int)s.send.size() < n) s.send.resize(n);
+    std::vector<Buf>& send = s.send[slot];
+    Buf& gathered = s.gathered[slot];
+    if ((int)send.size() < n) send.resize(n);
+    int own0 = 0, own1 = 0;
+    umx_geom::owned(pa, pb, npr, sub, margin, H, &own0, &own1);
     {   // size the slab / gather buffers for the largest slab up front (no reallocation between enqueued operations)
         int mx_all = 1, own_max = 1;
         for (int i = 0; i < n; ++i)
@@ -376,15 +427,15 @@ int umx_infer_image_sharded_dev(umx_ctx* ctx, const double* band_dev, int C_img,
                 mx_all = std::max(mx_all, b - a);
                 if (q == rank) own_max = std::max(own_max, b - a);
             }
-        if ((rc = grow(ctx, &s.gathered, (size_t)world * K * mx_all * W * el))) return rc;
-        if ((rc = grow(ctx, &s.slab, (size_t)K * own_max * W * el))) return rc;
+        if ((rc = grow(ctx, &gathered, (size_t)world * K * mx_all * W * el))) return rc;
+        if ((rc = grow(ctx, &s.slab, (size_t)K * own_max * W * sel))) return rc;
         // the send buffers too: a grow() in the slab loop would synchronise the device and free memory between enqueued
         // collectives when a later slide is larger.  (Their padded tails stay uninitialised: the scatter never reads them.)
         for (int i = 0; i < n; ++i)
-            if ((rc = grow(ctx, &s.send[i], (size_t)K * mx_all * W * el))) return rc;
+            if ((rc = grow(ctx, &send[i], (size_t)K * mx_all * W * el))) return rc;
     }
     for (int i = 0; i < n; ++i) {
-        if (pa < pb && (rc = tiles(umx_geom::cut(pa, pb, n, i), std::min(umx_geom::cut(pa, pb, n, i + 1), pb - 1)))) return rc;
+        if (pa < pb && (rc = tiles(umx_geom::cut(pa, pb, n, i), std::min(umx_geom::cut(pa, pb, n, i + 1), has_next ? pb - 1 : pb)))) return rc;
         if (i == 0) S_HIP(ctx, hipStreamWaitEvent(cs, ev_halo, 0));   // the previous rank's last patch row feeds this band's first rows
         int s0, s1;
         umx_geom::slab(pa, pb, npr, sub, margin, H, n, i, &s0, &s1);
@@ -397,25 +448,181 @@ int umx_infer_image_sharded_dev(umx_ctx* ctx, const double* band_dev, int C_img,
         const size_t plane_b = (size_t)mx * W * el, send_b = (size_t)K * plane_b;
         if (s1 > s0) {
             if ((rc = umx_stitch_dev(ctx, probs, lo, pb, H, W, mode, stitch, s0, s1, s.slab.d))) return rc;
-            for (int k = 0; k < K; ++k)     // compact [K][rows][W] -> padded [K][mx][W]
-                S_HIP(ctx, hipMemcpyAsync((char*)s.send[i].d + k * plane_b, (char*)s.slab.d + (size_t)k * (s1 - s0) * W * el,
-                                          (size_t)(s1 - s0) * W * el, hipMemcpyDeviceToDevice, cs));
+            for (int k = 0; k < K; ++k) {   // compact [K][rows][W] -> padded [K][mx][W]
+                const size_t rows_e = (size_t)(s1 - s0) * W;
+                if (io.u8)   // the drivers' cast on the way: np.uint8(255 * pm), identity resize, np.uint8(255 * .)
+                    S_HIP(ctx, umx::launch_half_to_u8((char*)s.slab.d + k * rows_e * sel, rows_e, (unsigned char*)send[i].d + k * plane_b, cs));
+                else
+                    S_HIP(ctx, hipMemcpyAsync((char*)send[i].d + k * plane_b, (char*)s.slab.d + k * rows_e * sel, rows_e * sel,
+                                              hipMemcpyDeviceToDevice, cs));
+            }
         }
-        hipEvent_t ev_s = s.events[4 + 2 * i];
+        hipEvent_t ev_s = evs[6 + 2 * i];
         S_HIP(ctx, hipEventRecord(ev_s, cs));
         S_HIP(ctx, hipStreamWaitEvent(ms, ev_s, 0));
-        // (one gather buffer, reused slab after slab: gather i+1 is queued behind the scatter copies of gather i)
-        S_TP(ctx, tp.all_gather(tp.user, s.send[i].d, s.gathered.d, send_b, ms));
+        if (io.own_host && s1 > s0) {   // this rank's rows of the slab: down to the host under the next slab's tiles
+            if (io.dn_s != cs) S_HIP(ctx, hipStreamWaitEvent(io.dn_s, ev_s, 0));
+            const size_t own_rows = (size_t)(own1 - own0);
+            for (int k = 0; k < K; ++k)
+                S_HIP(ctx, hipMemcpyAsync(io.own_host + ((size_t)k * own_rows + (size_t)(s0 - own0)) * W, (char*)send[i].d + k * plane_b,
+                                          (size_t)(s1 - s0) * W, hipMemcpyDeviceToHost, io.dn_s));
+        }
+        // (one gather buffer per slot, reused slab after slab: gather i+1 is queued behind the scatter copies of gather i)
+        S_TP(ctx, tp.all_gather(tp.user, send[i].d, gathered.d, send_b, ms));
         for (int q = 0; q < world; ++q)
             for (int k = 0; k < K && rb[q] > ra[q]; ++k)
-                S_HIP(ctx, hipMemcpyAsync((char*)out_full_dev + ((size_t)k * H + ra[q]) * W * el,
-                                          (char*)s.gathered.d + (size_t)q * send_b + k * plane_b,
+                S_HIP(ctx, hipMemcpyAsync((char*)io.out_full + ((size_t)k * H + ra[q]) * W * el,
+                                          (char*)gathered.d + (size_t)q * send_b + k * plane_b,
                                           (size_t)(rb[q] - ra[q]) * W * el, hipMemcpyDeviceToDevice, ms));
     }
     S_HIP(ctx, hipEventRecord(ev_done, ms));
-    S_HIP(ctx, hipStreamWaitEvent(cs, ev_done, 0));   // the result is complete for whatever the caller queues next
+    if (io.join) S_HIP(ctx, hipStreamWaitEvent(cs, ev_done, 0));   // the result is complete for whatever the caller queues next
+    S_HIP(ctx, hipEventRecord(ev_end, cs));
+    if (io.ev_gathered) *io.ev_gathered = ev_done;
+    if (io.ev_cs_end) *io.ev_cs_end = ev_end;
 #undef S_TP
     return UMX_OK;
+}
+
+Shard* shard_of(umx_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_shards.find(ctx);
+    return it == g_shards.end() || !it->second.ready ? nullptr : &it->second;
+}
+
+}  // namespace
+
+extern "C" {
+
+int umx_infer_image_sharded_dev(umx_ctx* ctx, const double* band_dev, int C_img, int H, int W, int band_row0, int band_rows,
+                                double mean, double stdv, int mode, int stitch, int nslabs, void* out_full_dev) {
+    if (!ctx) return umx_internal_fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    if (!out_full_dev || H < 1 || W < 1) return umx_internal_fail(ctx, UMX_ERR_INVALID, "bad out / H / W");
+    Shard* sp = shard_of(ctx);
+    if (!sp) return umx_internal_fail(ctx, UMX_ERR_INVALID, "call umx_shard_init (or umx_shard_init_transport) on this context first");
+    S_HIP(ctx, hipSetDevice(umx_internal_device(ctx)));
+    RunIO io;
+    io.band_f64 = band_dev;
+    io.out_full = out_full_dev;
+    return sharded_run(ctx, *sp, io, C_img, H, W, band_row0, band_rows, mean, stdv, mode, stitch, nslabs);
+}
+
+// The same schedule fed the way the one-GPU line is fed (umx_infer_image_raw_submit): this rank's raw uint8 / uint16 rows come up
+// from the host piece by piece on the upload stream ahead of the tiles that read them, the tile gather converts (im2double, and
+// with `range` the drivers' rescale_intensity to the whole planes' (min, max), which the caller's reader knows -- a rank sees only
+// its band), stitched slabs are cast to the drivers' uint8 before they are gathered (a quarter of the fp32 bytes over xGMI), and
+// the rank's own rows go down to the host on the download stream under the next slab's tiles.  Two slides may be in flight.
+static int sharded_raw_submit(umx_ctx* ctx, int slot, const void* band_host, int bits, int C_img, int H, int W, int band_row0,
+                              int band_rows, const uint32_t* range, double mean, double stdv, int mode, int nslabs,
+                              uint8_t* own_out_host, uint8_t* out_full_dev) {
+    using namespace umx;
+    Shard* sp = shard_of(ctx);
+    if (!sp) return fail(ctx, UMX_ERR_INVALID, "call umx_shard_init (or umx_shard_init_transport) on this context first");
+    Shard& s = *sp;
+    umx_ctx::HostSlot& hs = ctx->hs[slot];
+    if (!hs.done) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&hs.done, hipEventDisableTiming));
+        HIP_TRY(ctx, hipHostMalloc((void**)&hs.flag_host, 64, hipHostMallocDefault));
+    }
+    if (!ctx->up_stream) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->dn_stream, hipStreamNonBlocking));
+    }
+    const size_t in_b = (size_t)bits / 8, K = ctx->hp.nClasses;
+    const size_t raw_b = (size_t)C_img * std::max(band_rows, 0) * W * in_b;
+    const size_t mm_off = (raw_b + 255) & ~(size_t)255;
+    int rc;
+    if ((rc = grow(ctx, &hs.d_out, &hs.out_cap, mm_off + 64 * (size_t)std::max(C_img, 1) + 256))) return rc;
+    unsigned char* const base = (unsigned char*)hs.d_out;
+    unsigned* const mm = (unsigned*)(base + mm_off);
+    if (!out_full_dev) {
+        if ((rc = ::grow(ctx, &s.full_u8[slot], K * (size_t)H * W))) return rc;
+        out_full_dev = (uint8_t*)s.full_u8[slot].d;
+    }
+    const int fw = 16 * (slot + 1);
+    if (ctx->d_flag) HIP_TRY(ctx, hipMemsetAsync(ctx->d_flag + fw, 0, sizeof(int), ctx->stream));
+    ctx->flag_word = fw;
+    RunIO io;
+    io.slot = slot;
+    io.u8 = 1;
+    io.out_full = out_full_dev;
+    io.own_host = own_out_host;
+    io.up_s = ctx->up_stream;
+    io.dn_s = ctx->dn_stream;
+    io.join = false;
+    hipEvent_t ev_gathered = nullptr, ev_end = nullptr;
+    io.ev_gathered = &ev_gathered;
+    io.ev_cs_end = &ev_end;
+    if (range)
+        for (int c = 0; c < C_img; ++c) {
+            HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(mm + 16 * c), (int)range[2 * c], 1, ctx->stream));
+            HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)(mm + 16 * c + 1), (int)range[2 * c + 1], 1, ctx->stream));
+        }
+    if (gathers_raw(ctx)) {
+        io.raw_dev = base;
+        io.raw_bits = bits;
+        io.mm = range ? mm : nullptr;
+        io.band_host = band_host;
+    } else {
+        // an engine whose gather reads float64 (exact-fp32 precision): the band goes up whole and is converted first
+        if ((rc = grow(ctx, (void**)&hs.d_image, &hs.image_cap, (size_t)C_img * std::max(band_rows, 1) * W * sizeof(double)))) return rc;
+        if (raw_b) HIP_TRY(ctx, hipMemcpyAsync(base, band_host, raw_b, hipMemcpyHostToDevice, ctx->stream));
+        for (int c = 0; c < C_img && band_rows > 0; ++c)
+            HIP_TRY(ctx, launch_raw_convert(base + (size_t)c * band_rows * W * in_b, bits, (size_t)band_rows * W, range ? 1 : 0, mm + 16 * c,
+                                            hs.d_image + (size_t)c * band_rows * W, ctx->stream));
+        io.band_f64 = hs.d_image;
+    }
+    rc = sharded_run(ctx, s, io, C_img, H, W, band_row0, band_rows, mean, stdv, mode, UMX_STITCH_FP16_COMPAT, nslabs);
+    ctx->flag_word = 0;
+    if (rc) return rc;
+    // `done`: the gathers and scatters (communication stream), this rank's downloads and the range flag behind the last kernel
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->dn_stream, ev_gathered, 0));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->dn_stream, ev_end, 0));
+    if (ctx->d_flag) HIP_TRY(ctx, hipMemcpyAsync(hs.flag_host, ctx->d_flag + fw, sizeof(int), hipMemcpyDeviceToHost, ctx->dn_stream));
+    else *hs.flag_host = 0;
+    HIP_TRY(ctx, hipEventRecord(hs.done, ctx->dn_stream));
+    hs.busy = true;
+    return UMX_OK;
+}
+
+int umx_infer_image_sharded_raw_submit(umx_ctx* ctx, int slot, const void* band_host, int bits, int C_img, int H, int W,
+                                       int band_row0, int band_rows, const uint32_t* range, double mean, double stdv, int mode,
+                                       int nslabs, uint8_t* own_out_host, uint8_t* out_full_dev) {
+    using namespace umx;
+    if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    if (slot < 0 || slot > 1) return fail(ctx, UMX_ERR_INVALID, "slot must be 0 or 1");
+    if (H < 1 || W < 1 || C_img < 1 || band_rows < 0 || band_row0 < 0 || band_row0 + band_rows > H || (band_rows > 0 && !band_host))
+        return fail(ctx, UMX_ERR_INVALID, "bad band / H / W");
+    if (bits != 8 && bits != 16) return fail(ctx, UMX_ERR_INVALID, "raw planes must be uint8 or uint16 (bits = %d)", bits);
+    if (C_img != 1 && C_img != ctx->hp.nChannels)
+        return fail(ctx, UMX_ERR_INVALID, "image has %d channels, model wants 1 or %d", C_img, ctx->hp.nChannels);
+    if (!(stdv != 0.0)) return fail(ctx, UMX_ERR_INVALID, "std must be non-zero");
+    if (mode != UMX_MODE_ACCUMULATE && mode != UMX_MODE_REPLACE) return fail(ctx, UMX_ERR_INVALID, "bad mode %d", mode);
+    const uint32_t top = bits == 8 ? 255u : 65535u;
+    for (int c = 0; range && c < C_img; ++c)
+        if (range[2 * c] > range[2 * c + 1] || range[2 * c + 1] > top)
+            return fail(ctx, UMX_ERR_INVALID, "plane %d: range (%u, %u) is not a (min, max) of %d-bit samples", c, range[2 * c], range[2 * c + 1], bits);
+    if (ctx->hs[slot].busy) return fail(ctx, UMX_ERR_INVALID, "slot %d still holds a submitted call: wait for it first", slot);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int rc = sharded_raw_submit(ctx, slot, band_host, bits, C_img, H, W, band_row0, band_rows, range, mean, stdv, mode, nslabs,
+                                      own_out_host, out_full_dev);
+    ctx->flag_word = 0;
+    if (rc) {   // an error in the middle of enqueueing: drain what references the caller's buffers before returning
+        const std::string msg = ctx->err;
+        if (ctx->up_stream) hipStreamSynchronize(ctx->up_stream);
+        hipStreamSynchronize(ctx->stream);
+        if (ctx->dn_stream) hipStreamSynchronize(ctx->dn_stream);
+        ctx->err = msg;
+    }
+    return rc;
+}
+
+int umx_infer_image_sharded_raw(umx_ctx* ctx, const void* band_host, int bits, int C_img, int H, int W, int band_row0, int band_rows,
+                                const uint32_t* range, double mean, double stdv, int mode, int nslabs, uint8_t* own_out_host,
+                                uint8_t* out_full_dev) {
+    const int rc = umx_infer_image_sharded_raw_submit(ctx, 0, band_host, bits, C_img, H, W, band_row0, band_rows, range, mean, stdv, mode,
+                                                      nslabs, own_out_host, out_full_dev);
+    return rc ? rc : umx_infer_image_wait(ctx, 0);
 }
 
 }  // extern "C"

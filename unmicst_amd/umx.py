@@ -27,7 +27,7 @@ EXPORTS = [
     "umx_forward_tiles", "umx_forward_tiles_dev", "umx_tile_grid", "umx_infer_image", "umx_infer_image_dev",
     "umx_infer_image_raw", "umx_infer_image_raw_range", "umx_plane_range", "umx_infer_image_raw_scaled", "umx_infer_image_raw_outlier", "umx_infer_image_raw_submit", "umx_infer_image_wait", "umx_tiff_lzw_decode",
     "umx_tiff_packbits_decode", "umx_shard_unique_id", "umx_shard_init", "umx_shard_init_transport", "umx_shard_fini", "umx_shard_plan",
-    "umx_infer_image_sharded_dev",
+    "umx_infer_image_sharded_dev", "umx_infer_image_sharded_raw", "umx_infer_image_sharded_raw_submit",
     "umx_band_tiles_dev", "umx_stitch_dev", "umx_profile_enable", "umx_profile_read", "umx_prof_entry_size", "umx_test_double_to_half",
     "umx_describe", "umx_describe_graph", "umx_version",
 ]
@@ -192,6 +192,12 @@ def load(path: Optional[str] = None):
     L.umx_infer_image_sharded_dev.restype = c_int
     L.umx_infer_image_sharded_dev.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_int,
                                               c_int, c_int, c_void_p]
+    L.umx_infer_image_sharded_raw_submit.restype = c_int
+    L.umx_infer_image_sharded_raw_submit.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                                     c_double, c_double, c_int, c_int, c_void_p, c_void_p]
+    L.umx_infer_image_sharded_raw.restype = c_int
+    L.umx_infer_image_sharded_raw.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                              c_double, c_double, c_int, c_int, c_void_p, c_void_p]
     for fn in (L.umx_tiff_lzw_decode, L.umx_tiff_packbits_decode):
         fn.restype = ctypes.c_longlong
         fn.argtypes = [c_void_p, ctypes.c_size_t, c_void_p, ctypes.c_size_t]
@@ -416,6 +422,35 @@ class Engine:
         self._check(self._L.umx_infer_image_sharded_dev(self._ctx, ctypes.c_void_p(band_ptr), C, H, W, int(band_row0),
                                                         int(band_rows), float(mean), float(std), int(mode), int(stitch),
                                                         int(nslabs), ctypes.c_void_p(out_full_ptr)))
+
+    def infer_image_sharded_raw_submit(self, slot: int, band_ptr: int, bits: int, C: int, H: int, W: int, band_row0: int,
+                                       band_rows: int, value_range, mean: float, std: float, mode: int, nslabs: int,
+                                       own_out_ptr: int = 0, out_full_ptr: int = 0) -> None:
+        """umx_infer_image_sharded_raw_submit: this rank's raw rows (host pointer) in, uint8 planes out -- the rank's own rows to
+        ``own_out_ptr`` (host, [K, own rows, W]) and the gathered stack to ``out_full_ptr`` (device, [K, H, W]); 0 = none / the
+        library's buffer.  ``value_range``: None, or per plane (min, max) of the WHOLE plane (the drivers' rescale).
+        ``infer_image_wait(slot)`` completes the call."""
+        rng = None
+        if value_range is not None:
+            rng = (ctypes.c_uint32 * (2 * C))(*[int(v) for pair in value_range for v in pair])
+        self._check(self._L.umx_infer_image_sharded_raw_submit(
+            self._ctx, int(slot), ctypes.c_void_p(band_ptr), int(bits), C, H, W, int(band_row0), int(band_rows), rng, float(mean),
+            float(std), int(mode), int(nslabs), ctypes.c_void_p(own_out_ptr or None), ctypes.c_void_p(out_full_ptr or None)))
+
+    def infer_image_sharded_raw(self, band: np.ndarray, H: int, W: int, band_row0: int, value_range, mean: float, std: float,
+                                mode: int = MODE_ACCUMULATE, nslabs: int = 2, own_rows: int = 0, out_full_ptr: int = 0):
+        """Synchronous form on a numpy band [C, rows, W] (or [rows, W]) of uint8 / uint16: returns this rank's own rows as uint8
+        [K, own_rows, W] (``own_rows`` from shard_plan: own_row1 - own_row0)."""
+        b = np.ascontiguousarray(band)
+        if b.ndim == 2:
+            b = b[None]
+        if b.dtype not in (np.uint8, np.uint16):
+            raise TypeError("raw planes must be uint8 or uint16")
+        out = np.empty((self.hp.nClasses, int(own_rows), W), dtype=np.uint8)
+        self.infer_image_sharded_raw_submit(0, b.ctypes.data, 8 * b.dtype.itemsize, b.shape[0], H, W, band_row0, b.shape[1], value_range,
+                                            mean, std, mode, nslabs, out.ctypes.data if out.size else 0, out_full_ptr)
+        self.infer_image_wait(0)
+        return out
 
     def set_stream(self, hip_stream) -> None:
         """Run the engine's launches on the caller's HIP stream (a non-zero hipStream_t handle, e.g.
