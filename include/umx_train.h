@@ -71,6 +71,15 @@ UMX_API int umx_trainer_read(umx_trainer* tr, int which, float* out, size_t n_fl
 /* softmax output of the last step's forward pass [B,P,P,nClasses] (the reference evaluates its pixel errors on it,
  * UnMicst1-5.py:386-397) */
 UMX_API int umx_trainer_probs(umx_trainer* tr, float* probs_host);
+/* Diagnostics of the last step's forward pass (what sess.run would fetch by tensor name): `name` is
+ *   "ld<i>.z" | "lb.z" | "lu<i>.z" | "lt.z"   the convolution output in front of that layer's BatchNorm, [B,H,W,C];
+ *   "<layer>.stat"                            its batch statistics [4][C] = mean | rstd | scale = gamma rstd | shift = beta - mean scale
+ *                                             (BN output = z * scale + shift: the value the LeakyReLU / max-pool decisions are taken on);
+ *   "lu<i>.us"                                the up-sampled tensor behind its LeakyReLU (UnMicst1-5.py:192-195), [B,2h,2h,C];
+ *   "ds<i>"                                   input of down layer i (ds0 = the batch; pooled + dropped output of layer i-1).
+ * *n_floats in: capacity of `out`; out: the tensor's size (out == NULL just queries it).  Synchronises the trainer's stream.
+ * The parity tests use it to take the oracle's gradient at the SAME activation / pooling decisions (tests/test_gpu_train.py). */
+UMX_API int umx_trainer_read_tensor(umx_trainer* tr, const char* name, float* out, size_t* n_floats);
 /* Session.run(UNet2D.nn / errors, feed_dict={tfData: batchData, tfTraining: 0}) with the trainer's current variables
  * (the validation and test passes of UNet2D.train, UnMicst1-5.py:501-502,564-565): moving statistics, no dropout.
  * data [B,P,P,nChannels] and probs [B,P,P,nClasses] are HOST buffers; synchronous. */

@@ -199,23 +199,50 @@ def _drop(x, rate, o, step, layer_id, training):
     return x * torch.from_numpy(m).permute(0, 3, 1, 2).to(x.dtype)
 
 
-def forward(hp, P: Dict[str, torch.Tensor], data_nhwc: torch.Tensor, o: TrainOptions, step: int, training: bool):
-    """-> (softmax probabilities NHWC, BN batch statistics per layer)."""
+def _leaky(a, site, decisions, trace):
+    """LeakyReLU(0.2) -- or, with `decisions[site]` (a tensor of slopes 1 / 0.2 shaped like `a`), the same function with every
+    branch TAKEN AS GIVEN: a * slope.  Where the given branch is the one this run would take the two are identical; where an
+    activation is within rounding distance of 0 the value moves by < |a| while the gradient is the given branch's."""
+    if trace is not None:
+        trace[site] = a.detach()
+    if decisions is not None and site in decisions:
+        return a * decisions[site]
+    return F.leaky_relu(a, LEAK)
+
+
+def _pool(a, site, decisions, trace):
+    """max_pool2d(2) -- or, with `decisions[site]` (int64 [B,C,H/2,W/2], window element 2*dy + dx), the given element of every window."""
+    if trace is not None:
+        trace[site] = a.detach()
+    if decisions is not None and site in decisions:
+        B, C, H, W = a.shape
+        win = a.reshape(B, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(B, C, H // 2, W // 2, 4)
+        return torch.gather(win, 4, decisions[site].unsqueeze(-1)).squeeze(-1)
+    return F.max_pool2d(a, 2)
+
+
+def forward(hp, P: Dict[str, torch.Tensor], data_nhwc: torch.Tensor, o: TrainOptions, step: int, training: bool,
+            decisions=None, trace=None):
+    """-> (softmax probabilities NHWC, BN batch statistics per layer).
+
+    decisions (test aid, tests/test_gpu_train.py): {"ld<i>" | "lb" | "lu<i>" | "us<i>": slopes, "pool<i>": window elements} -- the
+    LeakyReLU branches and max-pool choices of ANOTHER evaluation of the same step (the HIP kernels'), so that two implementations
+    are compared on the same smooth piece of the loss; trace: dict that receives the tensor in front of every such decision."""
     L = hp.nLayers
     stats: Dict[str, tuple] = {}
     x = data_nhwc.permute(0, 3, 1, 2)
     ds = [x]
     for i in range(L):
         z = _conv_same(ds[i], P["ld%d.w1" % i]) + _conv_same(ds[i], P["ld%d.wshort" % i])
-        a = F.leaky_relu(_bn(z, P, "ld%d" % i, training, stats), LEAK)
+        a = _leaky(_bn(z, P, "ld%d" % i, training, stats), "ld%d" % i, decisions, trace)
         a = _drop(a, o.drop_down_step * i, o, step, LAYER_DOWN + i, training)
-        ds.append(F.max_pool2d(a, 2))
-    b = F.leaky_relu(_bn(_conv_same(ds[L], P["lb.w"]), P, "lb", training, stats), LEAK)
+        ds.append(_pool(a, "pool%d" % i, decisions, trace))
+    b = _leaky(_bn(_conv_same(ds[L], P["lb.w"]), P, "lb", training, stats), "lb", decisions, trace)
     cur = _drop(b, o.drop_bottom, o, step, LAYER_BOTTOM, training)
     for idx in range(L - 1, -1, -1):
-        us = F.leaky_relu(_conv_transpose_s2(cur, P["lu%d.wt" % idx]), LEAK)
+        us = _leaky(_conv_transpose_s2(cur, P["lu%d.wt" % idx]), "us%d" % idx, decisions, trace)
         cc = torch.cat([ds[idx], us], dim=1)
-        cv = F.leaky_relu(_bn(_conv_same(cc, P["lu%d.w2" % idx]), P, "lu%d" % idx, training, stats), LEAK)
+        cv = _leaky(_bn(_conv_same(cc, P["lu%d.w2" % idx]), P, "lu%d" % idx, training, stats), "lu%d" % idx, decisions, trace)
         cur = _drop(cv, o.drop_up0 - o.drop_up_step * idx, o, step, LAYER_UP + idx, training)
     t = _bn(_conv_same(cur, P["lt.w"]), P, "lt", training, stats)
     return torch.softmax(t, dim=1).permute(0, 2, 3, 1), stats
@@ -254,14 +281,15 @@ class TrainState:
             self.v = np.zeros_like(self.blob)
 
 
-def loss_and_grads(hp, blob, data, labels, weights, o: TrainOptions, step: int, dtype=torch.float64):
-    """-> (loss, data_term, reg, grads as a blob-shaped float64 vector (0 for the moving statistics), probs, stats)."""
+def loss_and_grads(hp, blob, data, labels, weights, o: TrainOptions, step: int, dtype=torch.float64, decisions=None, trace=None):
+    """-> (loss, data_term, reg, grads as a blob-shaped float64 vector (0 for the moving statistics), probs, stats).
+    decisions / trace: see forward()."""
     T = split_blob(hp, np.asarray(blob, dtype=np.float64))
     P = {k: torch.tensor(v, dtype=dtype, requires_grad=trainable(k)) for k, v in T.items()}
     d = torch.tensor(np.asarray(data), dtype=dtype)
     y = torch.tensor(np.asarray(labels), dtype=dtype)
     w = torch.tensor(np.asarray(weights), dtype=dtype)
-    probs, stats = forward(hp, P, d, o, step, training=True)
+    probs, stats = forward(hp, P, d, o, step, training=True, decisions=decisions, trace=trace)
     loss, data_term, reg = loss_of(hp, P, probs, y, w, o)
     loss.backward()
     grads = {k: (P[k].grad.numpy() if trainable(k) and P[k].grad is not None else np.zeros(T[k].shape)) for k in T}

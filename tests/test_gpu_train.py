@@ -60,6 +60,64 @@ def _per_tensor(hp, got, want, what, rel=LOOSE, top=TIGHT):
     return worst
 
 
+def _hip_decisions(tr, hp, opts, step, B):
+    """The LeakyReLU branches and max-pool choices the HIP kernels took in their last forward pass, rebuilt from the tensors they
+    were taken on (umx_trainer_read_tensor): BN output = z * scale + shift evaluated exactly (float64 product of two float32 +
+    one rounding: the sign of the kernels' fused multiply-add), the pooled element = first maximum of act(v) * dropout in float32
+    like act_fwd_kernel.  Given to the oracle (train_oracle.forward(decisions=...)) the two implementations differentiate the SAME
+    smooth piece of the loss, so every gradient tensor can be held to TIGHT -- at any size, however many activations sit within
+    rounding distance of zero."""
+    import torch
+    from oracle import train_oracle as to
+    n, L, S = hp.nOutX, hp.nLayers, hp.imSize
+    dec = {}
+
+    def nchw(a):
+        return torch.from_numpy(np.ascontiguousarray(a.transpose(0, 3, 1, 2)))
+
+    def bn_value(layer, S, C):
+        z = tr.read_tensor(layer + ".z").reshape(B, S, S, C).astype(np.float64)
+        st = tr.read_tensor(layer + ".stat").reshape(4, C).astype(np.float64)
+        return z * st[2] + st[3]
+
+    for i in range(L):
+        C = n[i + 1]
+        v = bn_value("ld%d" % i, S, C)
+        dec["ld%d" % i] = nchw(np.where(v > 0, 1.0, to.LEAK))
+        v32 = v.astype(np.float32)
+        y = np.where(v32 > 0, v32, np.float32(0.2) * v32).astype(np.float32)
+        m = to.dropout_mask(opts.seed, step, to.LAYER_DOWN + i, (B, S, S, C), opts.drop_down_step * i).astype(np.float32)
+        y = y * m
+        win = y.reshape(B, S // 2, 2, S // 2, 2, C).transpose(0, 1, 3, 5, 2, 4).reshape(B, S // 2, S // 2, C, 4)   # element 2 dy + dx
+        dec["pool%d" % i] = torch.from_numpy(np.ascontiguousarray(win.argmax(-1).transpose(0, 3, 1, 2))).long()
+        S //= 2
+    dec["lb"] = nchw(np.where(bn_value("lb", S, n[L + 1]) > 0, 1.0, to.LEAK))
+    for idx in range(L - 1, -1, -1):
+        S *= 2
+        C = n[idx + 1]
+        us = tr.read_tensor("lu%d.us" % idx).reshape(B, S, S, C)
+        dec["us%d" % idx] = nchw(np.where(us > 0, 1.0, to.LEAK))
+        dec["lu%d" % idx] = nchw(np.where(bn_value("lu%d" % idx, S, C) > 0, 1.0, to.LEAK))
+    return dec
+
+
+def _count_flips(dec, trace):
+    """Per site: decisions of `dec` (the kernels') that differ from what the oracle's own values (trace) would take."""
+    import torch
+    from oracle import train_oracle as to
+    flips = {}
+    for site, d in dec.items():
+        a = trace[site]
+        if site.startswith("pool"):
+            B, C, H, W = a.shape
+            win = a.reshape(B, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(B, C, H // 2, W // 2, 4)
+            own = win.argmax(-1)
+        else:
+            own = torch.where(a > 0, 1.0, to.LEAK)
+        flips[site] = (int((own != d).sum()), int(d.numel()))
+    return flips
+
+
 CASES = [("v2_solo_like", 4, "solo"), ("v2_duo_like", 4, "duo"), ("v2_deep", 3, "duo"), ("v2_wide", 2, "solo"),
          ("v2_wide", 2, "duo"), ("v2_k5", 3, "duo")]
 
@@ -323,7 +381,12 @@ def test_the_two_convolution_routes_agree_step_for_step(monkeypatch):
 
 def test_baseline_config_256x256x2_batch8_against_the_oracle():
     """BASELINE.json configs[4] at full size: synthetic-256 hyper-parameters (duo widths 36..1152, 5 levels), batch 8 of
-    256 x 256 x 2, duo regime -- loss and every gradient tensor against the float64 oracle (about a minute of CPU)."""
+    256 x 256 x 2, duo regime -- loss and EVERY gradient tensor against the float64 oracle at TIGHT (about a minute of CPU).
+
+    4.7 M LeakyReLU decisions per full-resolution tensor: some sit within rounding distance of zero and fall the other way in
+    float64, and every gradient below such a flip moves by 1e-4 .. 3e-2 of its scale (rounds 1-4 therefore held this size to 0.1 --
+    a band that would also hide a wrong weight gradient in a deep layer).  Here the oracle differentiates the loss ON THE KERNELS'
+    OWN DECISIONS (_hip_decisions): the same smooth piece of the function, so nothing is excused -- and the flips are counted."""
     import torch
     from oracle import train_oracle as to
     hp = model.KNOWN_HP["synthetic-256"]
@@ -333,19 +396,62 @@ def test_baseline_config_256x256x2_batch8_against_the_oracle():
     tr = trainer.Trainer(hp, blob, opts, batch=8)
     loss, data_term, reg = tr.step(data, labels, weights, apply_update=False)
     g = tr.grads()
+    dec = _hip_decisions(tr, hp, opts, 0, 8)
     tr.close()
     torch.set_num_threads(max(1, torch.get_num_threads()))
-    want = to.loss_and_grads(hp, blob, data, labels, weights, _oracle_opts(opts), step=0)
+    trace = {}
+    want = to.loss_and_grads(hp, blob, data, labels, weights, _oracle_opts(opts), step=0, decisions=dec, trace=trace)
     assert loss == pytest.approx(want[0], rel=1e-5)
     assert reg == pytest.approx(want[2], rel=1e-5)
-    # 4.7 M LeakyReLU decisions per full-resolution tensor: some flip between fp32 and fp64 even in the top up layer, so
-    # only the tensors above the last LeakyReLU (lt.*) are held to TIGHT here
-    # (measured: HIP up to 2.6e-2 of a tensor's scale, the oracle in float32 up to 1.7e-2 -- profiles/r01/train_parity_report.log)
-    worst = _per_tensor(hp, g, want[3], "grads at 256x256x2, batch 8", rel=0.1, top=0.1)
-    G, W = to.split_blob(hp, g), to.split_blob(hp, want[3])
-    for name in ("lt.w", "lt.bn.gamma", "lt.bn.beta"):
-        assert np.abs(G[name] - W[name]).max() <= TIGHT * np.abs(W[name]).max(), name
-    print("worst relative gradient error %.2e" % worst)
+    flips = _count_flips(dec, trace)
+    total = sum(f for f, _ in flips.values())
+    for site, (f, n) in flips.items():
+        assert f <= 1e-4 * n + 2, (site, f, n)      # rounding-distance events only: a broken reconstruction flips percents
+    worst = _per_tensor(hp, g, want[3], "grads at 256x256x2, batch 8, on the kernels' decisions", rel=TIGHT, top=TIGHT)
+    print("worst relative gradient error %.2e with %d of %d decisions differing from the float64 run's (%s)" % (
+        worst, total, sum(n for _, n in flips.values()), ", ".join("%s %d" % (k, f) for k, (f, _) in flips.items() if f)))
+
+
+def test_weight_gradient_of_a_deep_layer_against_finite_differences_of_the_kernels_own_loss():
+    """Independent of any oracle: the bottom layer's filter gradient (lb.w, 576 -> 1152 channels at 8 x 8: wgrad_f16x3 on a deep
+    layer, K split and all) at the BASELINE size against a central finite difference of the HIP step's OWN loss along the
+    gradient's direction: (L(w + h d) - L(w - h d)) / 2h = <g, d> = |g| for d = g / |g|.  The loss comes back as float64 sums of a
+    float32-equivalent forward pass (1e-7 relative noise); h moves it by 2e-3 of itself, so the difference quotient is good to
+    ~1e-4 plus curvature; a wrong scale, a dropped tap or a mis-reduced K slice moves it by O(1)."""
+    from oracle import train_oracle as to
+    hp = model.KNOWN_HP["synthetic-256"]
+    opts = trainer.duo_options()
+    blob = model.random_blob(hp, seed=20260101).astype(np.float32)
+    data, labels, weights = _batch(hp, 8, 11)
+    tr = trainer.Trainer(hp, blob, opts, batch=8)
+    loss0 = tr.step(data, labels, weights, apply_update=False)[0]
+    g = tr.grads()
+    tr.close()
+    off = {}
+    pos = 0
+    for name, shape in to.tensor_specs(hp):
+        off[name] = (pos, int(np.prod(shape)))
+        pos += int(np.prod(shape))
+    for name in ("lb.w", "lu4.w2"):
+        a, n = off[name]
+        G = g[a:a + n].astype(np.float64)
+        norm = float(np.sqrt((G * G).sum()))
+        d = G / norm
+        h = 2e-3 * abs(loss0) / norm
+        L = []
+        for sgn in (+1.0, -1.0):
+            b2 = blob.astype(np.float64).copy()
+            b2[a:a + n] += sgn * h * d
+            t2 = trainer.Trainer(hp, b2.astype(np.float32), opts, batch=8)
+            L.append(t2.step(data, labels, weights, apply_update=False)[0])
+            t2.close()
+        # (the perturbed blobs are rounded to float32: the realised step is what the two blobs actually differ by)
+        bp = (blob.astype(np.float64)[a:a + n] + h * d).astype(np.float32).astype(np.float64)
+        bm = (blob.astype(np.float64)[a:a + n] - h * d).astype(np.float32).astype(np.float64)
+        realised = float(((bp - bm) * d).sum())          # = 2h up to the rounding of the blobs
+        fd = (L[0] - L[1]) / realised
+        assert fd == pytest.approx(norm, rel=5e-3), (name, fd, norm, loss0, h)
+        print("%s: finite difference %.6e, |gradient| %.6e (%.2e relative)" % (name, fd, norm, abs(fd / norm - 1)))
 
 
 @pytest.mark.parametrize("hp_args,B", [

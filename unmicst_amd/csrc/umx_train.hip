@@ -120,6 +120,7 @@ struct umx_trainer {
     float* d_split2 = nullptr;                            // ... of those enqueued on the side stream
     float* d_split3 = nullptr;                            // ... on the aux stream
     // forward / input-gradient convolutions on conv_f16x3 (UMX_TRAIN_CONV_F32=1: the exact-fp32 kernels of rounds 1-3)
+    bool range_pending = false;         // a training step raised the range flag and an eval pass cleared it before umx_trainer_loss saw it
     bool hconv = true;
     bool wg_planes = true;              // the split-precision weight gradient stages from the planes (UMX_TRAIN_WGRAD_FP32_STAGE=1: from fp32)
     umx_ctx* pctx = nullptr;            // owner of the planner's device allocations (stage tables, weight slabs, constants)
@@ -758,7 +759,9 @@ int enqueue_step(umx_trainer* tr, const float* data, const float* labels, const 
     if (update && tr->step > 0 && tr->wscale_every > 0 && tr->step % tr->wscale_every == 0) T_TRY(refresh_wscales(tr));
     if (tr->prof) T_HIP(tr, hipEventRecord(tr->ev[0], st));
     T_HIP(tr, hipMemsetAsync(tr->d_loss, 0, 2 * sizeof(double), st));
-    T_HIP(tr, hipMemsetAsync(tr->d_maxw, 0, (tr->n_maxw + 1) * sizeof(unsigned), st));
+    // (the range flag behind the max words is NOT cleared here: it stays up until umx_trainer_loss / umx_trainer_eval has
+    // reported it, so an overflow in a step whose loss is never read is not lost under the next step -- ADVICE r4)
+    T_HIP(tr, hipMemsetAsync(tr->d_maxw, 0, tr->n_maxw * sizeof(unsigned), st));
     if (tr->overlap) {
         // the side stream is idle until the first weight gradient: it packs the backward pass's operands and sums the regularisation
         // loss (both need nothing but this step's weights) while the main stream runs the forward pass
@@ -1411,6 +1414,11 @@ int umx_trainer_loss(umx_trainer* tr, double* loss3) {
     T_HIP(tr, hipMemcpyAsync(h, tr->d_loss, sizeof h, hipMemcpyDeviceToHost, tr->stream));
     T_HIP(tr, hipMemcpyAsync(&flag, tr->d_maxw + tr->n_maxw, sizeof flag, hipMemcpyDeviceToHost, tr->stream));
     T_HIP(tr, hipStreamSynchronize(tr->stream));
+    if (flag || tr->range_pending) {   // sticky: raised by any step since the last report; reported once, then cleared
+        flag = 1;
+        tr->range_pending = false;
+        T_HIP(tr, hipMemset(tr->d_maxw + tr->n_maxw, 0, sizeof(unsigned)));
+    }
     if (flag)
         return tfail(tr, UMX_ERR_RANGE, "an operand of a split-precision convolution or weight gradient left the binary16 range "
                                         "(|v| >= 6e4 after scaling or not finite): a diverging run, or a filter that outgrew its scale "
@@ -1443,6 +1451,15 @@ int umx_trainer_eval(umx_trainer* tr, const float* data, float* probs_host) {
     T_TRY(fold_profile(tr));
     const size_t npx = (size_t)tr->B * tr->P * tr->P;
     float* own = tr->ds[0];
+    // the range flag is shared with the training steps: what is up now belongs to a step whose loss was not read yet -- remember it
+    // for umx_trainer_loss, so that the flag this pass raises (repack + split-precision forward) is this pass's own
+    unsigned before = 0, flag = 0;
+    T_HIP(tr, hipMemcpyAsync(&before, tr->d_maxw + tr->n_maxw, sizeof before, hipMemcpyDeviceToHost, tr->stream));
+    T_HIP(tr, hipStreamSynchronize(tr->stream));
+    if (before) {
+        tr->range_pending = true;
+        T_HIP(tr, hipMemset(tr->d_maxw + tr->n_maxw, 0, sizeof(unsigned)));
+    }
     T_HIP(tr, hipMemcpyAsync(own, data, npx * tr->n[0] * sizeof(float), hipMemcpyHostToDevice, tr->stream));
     T_TRY(pack_all(tr, tr->stream, 0));
     const int rc = forward_pass(tr, own, false, false);
@@ -1450,7 +1467,13 @@ int umx_trainer_eval(umx_trainer* tr, const float* data, float* probs_host) {
     T_TRY(rc);
     T_HIP(tr, launch_softmax_only(tr->bn_t.z, tr->bn_t.stat, npx, tr->K, tr->d_probs, tr->stream));
     T_HIP(tr, hipMemcpyAsync(probs_host, tr->d_probs, npx * tr->K * sizeof(float), hipMemcpyDeviceToHost, tr->stream));
+    T_HIP(tr, hipMemcpyAsync(&flag, tr->d_maxw + tr->n_maxw, sizeof flag, hipMemcpyDeviceToHost, tr->stream));
     T_HIP(tr, hipStreamSynchronize(tr->stream));
+    if (flag) {
+        T_HIP(tr, hipMemset(tr->d_maxw + tr->n_maxw, 0, sizeof(unsigned)));
+        return tfail(tr, UMX_ERR_RANGE, "an operand of the split-precision forward pass of umx_trainer_eval left the binary16 range (|v| >= 6e4 or "
+                                        "not finite): the probabilities are not valid; UMX_TRAIN_CONV_F32=1 selects the exact-fp32 kernels");
+    }
     return UMX_OK;
 }
 
@@ -1463,6 +1486,46 @@ int umx_trainer_read(umx_trainer* tr, int which, float* out, size_t n_floats) {
     T_HIP(tr, hipSetDevice(tr->device));
     T_HIP(tr, hipStreamSynchronize(tr->stream));
     T_HIP(tr, hipMemcpy(out, src, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+    return UMX_OK;
+}
+
+int umx_trainer_read_tensor(umx_trainer* tr, const char* name, float* out, size_t* n_floats) {
+    if (!tr || !name || !n_floats) return tfail(tr, UMX_ERR_INVALID, "null argument");
+    const std::string nm(name);
+    const size_t dot = nm.find('.');
+    const std::string layer = nm.substr(0, dot), what = dot == std::string::npos ? "" : nm.substr(dot + 1);
+    const float* src = nullptr;
+    size_t n = 0;
+    auto index_of = [&](const char* prefix, int count) -> int {   // "<prefix><i>" -> i, or -1
+        const size_t pl = strlen(prefix);
+        if (layer.compare(0, pl, prefix) != 0 || layer.size() == pl) return -1;
+        for (size_t k = pl; k < layer.size(); ++k) if (layer[k] < '0' || layer[k] > '9') return -1;
+        const int i = atoi(layer.c_str() + pl);
+        return i < count ? i : -1;
+    };
+    const BnSite* site = nullptr;
+    int i;
+    if (layer == "lb") site = &tr->bn_b;
+    else if (layer == "lt") site = &tr->bn_t;
+    else if ((i = index_of("ld", tr->L)) >= 0) site = &tr->bn_d[i];
+    else if ((i = index_of("lu", tr->L)) >= 0) site = &tr->bn_u[i];
+    if (site && what == "z") { src = site->z; n = (size_t)tr->B * site->H * site->W * site->C; }
+    else if (site && what == "stat") { src = site->stat; n = 4 * (size_t)site->C; }
+    else if (what == "us" && (i = index_of("lu", tr->L)) >= 0) {
+        const int S = tr->P >> i;
+        src = tr->us[i]; n = (size_t)tr->B * S * S * tr->n[i + 1];
+    } else if (what.empty() && (i = index_of("ds", tr->L + 1)) >= 0) {
+        const int S = tr->P >> i;
+        src = tr->ds[i]; n = (size_t)tr->B * S * S * tr->n[i];
+    }
+    if (!src) return tfail(tr, UMX_ERR_INVALID, "unknown tensor %s", name);
+    const size_t cap = *n_floats;
+    *n_floats = n;
+    if (!out) return UMX_OK;
+    if (cap < n) return tfail(tr, UMX_ERR_INVALID, "%s has %zu floats, the buffer holds %zu", name, n, cap);
+    T_HIP(tr, hipSetDevice(tr->device));
+    T_HIP(tr, hipStreamSynchronize(tr->stream));
+    T_HIP(tr, hipMemcpy(out, src, n * sizeof(float), hipMemcpyDeviceToHost));
     return UMX_OK;
 }
 

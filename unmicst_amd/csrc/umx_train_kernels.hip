@@ -810,7 +810,10 @@ hipError_t launch_bn_bwd_apply_max(float* g, const float* z, const float* stat, 
                                    int* overflow, hipStream_t stream) {
     const size_t n = N * C;
     const unsigned blocks = (unsigned)std::min<size_t>(1024, (n + 255) / 256);
-    if (hi && n < 0xFFFFFFF0ull) {
+    // (planes asked for on a tensor the 32-bit-index kernel cannot address: refuse -- the caller's convolutions and weight
+    // gradients would read planes and an inverse scale nobody wrote.  Batch x resolution x channels >= 2^32: not a shape of this graph)
+    if (hi && n >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+    if (hi) {
         const unsigned bv = (unsigned)std::min<size_t>(2048, (n / 4 + 255) / 256 + 1);
         if (C % 4 == 0 && Cs % 4 == 0)
             hipLaunchKernelGGL(bn_bwd_apply_planes_kernel<true>, dim3(bv), dim3(256), 0, stream, g, z, stat, m12, (unsigned)n, C, Cs, gmax,

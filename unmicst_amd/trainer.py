@@ -26,7 +26,7 @@ TV_PARAMS, TV_GRADS, TV_SLOT_M, TV_SLOT_V = 0, 1, 2, 3
 EXPORTS = [
     "umx_train_options_solo", "umx_train_options_duo", "umx_trainer_create", "umx_trainer_destroy",
     "umx_trainer_last_error", "umx_train_step", "umx_train_step_dev", "umx_trainer_loss", "umx_trainer_read",
-    "umx_trainer_probs", "umx_trainer_eval", "umx_trainer_step_count", "umx_trainer_batch", "umx_trainer_flops_per_image",
+    "umx_trainer_probs", "umx_trainer_read_tensor", "umx_trainer_eval", "umx_trainer_step_count", "umx_trainer_batch", "umx_trainer_flops_per_image",
     "umx_trainer_profile",
 ]
 
@@ -106,6 +106,8 @@ def _bind(L):
     L.umx_trainer_read.argtypes = [c_void_p, c_int, c_void_p, ctypes.c_size_t]
     L.umx_trainer_probs.restype = c_int
     L.umx_trainer_probs.argtypes = [c_void_p, c_void_p]
+    L.umx_trainer_read_tensor.restype = c_int
+    L.umx_trainer_read_tensor.argtypes = [c_void_p, ctypes.c_char_p, c_void_p, ctypes.POINTER(ctypes.c_size_t)]
     L.umx_trainer_eval.restype = c_int
     L.umx_trainer_eval.argtypes = [c_void_p, c_void_p, c_void_p]
     L.umx_trainer_step_count.restype = ctypes.c_int64
@@ -210,6 +212,15 @@ class Trainer:
 
     def slots(self):
         return self._read(TV_SLOT_M), self._read(TV_SLOT_V)
+
+    def read_tensor(self, name: str) -> np.ndarray:
+        """A tensor of the last step's forward pass as a flat float32 array (umx_trainer_read_tensor: "ld0.z", "ld0.stat", "lu1.us",
+        "ds2", ...; NHWC order)."""
+        n = ctypes.c_size_t(0)
+        self._check(self._lib.umx_trainer_read_tensor(self._h, name.encode(), None, ctypes.byref(n)))
+        out = np.empty(n.value, dtype=np.float32)
+        self._check(self._lib.umx_trainer_read_tensor(self._h, name.encode(), out.ctypes.data, ctypes.byref(n)))
+        return out
 
     def probs(self) -> np.ndarray:
         hp = self.hp
