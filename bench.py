@@ -288,6 +288,11 @@ def main():
 
     if args.batch <= 0:
         args.batch = umx.auto_batch(hp)
+    # the training leg of the default N = 1 line (BASELINE configs[4]) runs FIRST, on an idle chip like `--workload train-synth256`
+    # does: its step is a chain of short launches whose time follows the clock, and behind a minute of inference at the package
+    # power cap the same leg measured 9 % lower (1 413 vs 1 578 - 1 599 images/s on one box)
+    legs = world == 1 and not sharded and args.workload == "wsi-synth256" and not args.no_legs and not args.resident_only
+    train = train_leg(torch, dev) if legs else None
     eng = umx.Engine(hp, blob, device=local_rank, max_batch=args.batch, precision=args.precision)
     # every engine launch, torch op and RCCL call of this process is ordered on ONE non-default stream
     work = torch.cuda.Stream(dev)
@@ -534,14 +539,12 @@ def main():
             cpu = cpu_baseline(hp, blob, band_f64, mean, std, args.cpu_seconds)
         # two short legs the default line carries at N = 1: the exact-fp32 engine on the 2048-row band and the
         # training step of BASELINE configs[4]; `--no-legs` (or any non-default workload / N > 1) skips them
-        f32 = train = None
-        if world == 1 and not sharded and args.workload == "wsi-synth256" and not args.no_legs and not args.resident_only:
+        f32 = None
+        if legs and eng.precision != "f32":
             eng.close()
             del band_f64
             torch.cuda.empty_cache()
-            if eng.precision != "f32":
-                f32 = f32_leg(torch, umx, hp, blob, local_rank, args.batch, host_u16, C_img, W, mean, std)
-            train = train_leg(torch, dev)
+            f32 = f32_leg(torch, umx, hp, blob, local_rank, args.batch, host_u16, C_img, W, mean, std)
         up_b = C_img * H * W * 2
         dn_b = K * H * W
         scope = ("H2D+D2H inside the timed region: uint16 planes up (%.0f MB), uint8 probability planes down (%.0f MB), "

@@ -112,9 +112,9 @@ def _count_flips(dec, trace):
             B, C, H, W = a.shape
             win = a.reshape(B, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(B, C, H // 2, W // 2, 4)
             own = win.argmax(-1)
-        else:
-            own = torch.where(a > 0, 1.0, to.LEAK)
-        flips[site] = (int((own != d).sum()), int(d.numel()))
+            flips[site] = (int((own != d).sum()), int(d.numel()))
+        else:   # (slopes: 1 on the positive branch, 0.2 on the other)
+            flips[site] = (int(((a > 0) != (d > 0.5)).sum()), int(d.numel()))
     return flips
 
 
