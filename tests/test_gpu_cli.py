@@ -166,13 +166,16 @@ def test_raw_fast_path_is_bit_identical_to_the_host_recipe(workspace, monkeypatc
         monkeypatch.setenv("UMX_HOST_RANGE", "0")
         assert np.array_equal(eng.infer_image_raw(big, True, mean, std), plain)
         monkeypatch.delenv("UMX_HOST_RANGE")
-        # ... and the rescale inside the raw tile gather (default) against the float64 image made by a pass of its own
-        monkeypatch.setenv("UMX_NO_RAW_RESCALE", "1")
-        assert np.array_equal(eng.infer_image_raw(big, True, mean, std), plain)
-        flat = np.full((300, 280), 1234, np.uint16)          # min == max: np.clip branch of rescale_intensity
-        want_flat = eng.infer_image_raw(flat, True, mean, std)
-        monkeypatch.delenv("UMX_NO_RAW_RESCALE")
+        # ... and the rescale inside the raw tile gather against the float64 image the host recipe makes (min == max: the np.clip
+        # branch of rescale_intensity)
+        flat = np.full((300, 280), 1234, np.uint16)
+        pre = driver.preprocess(flat, 1, -1)[1]
+        pm = eng.infer_image(pre, mean, std)
+        want_flat = np.stack([imtools.to_uint8_via_resize(pm[k], flat.shape) for k in range(hp.nClasses)])
         assert np.array_equal(eng.infer_image_raw(flat, True, mean, std), want_flat)
+        pre_big = driver.preprocess(big, 1, -1)[1]
+        pm = eng.infer_image(pre_big, mean, std)
+        assert np.array_equal(plain, np.stack([imtools.to_uint8_via_resize(pm[k], big.shape) for k in range(hp.nClasses)]))
 
 
 def test_two_slides_in_flight_equal_the_synchronous_calls(workspace):

@@ -1,6 +1,12 @@
-"""Every planner / layout / host-path switch libumx still reads from the environment (and the `lanes` option), exercised on the GPU:
-the same tiles and the same slide must come out within the parity tolerance of the oracle -- or equal to the default path,
-where the switch changes scheduling only.  A switch without a test here does not exist in the library."""
+"""Every planner switch libumx still reads from the environment (and the `lanes` option), exercised on the GPU: the same tiles
+and the same slide must come out within the parity tolerance of the oracle -- or equal to the default path, where the switch
+changes scheduling only.  A switch without a test here does not exist in the library.
+
+Round 5 retired the A/B switches whose answer is settled: UMX_PLANAR, UMX_XCD_ORDER, UMX_NO_{KSTEP_CARRY,
+FUSED_HEAD, FUSED_CONVT, FIRST, FOLD, CONVT3, NT_TRIAL, D2S_SKIP, D2S, PACKED_TILE, RAW_GATHER, RAW_RESCALE}, UMX_HOST_SLABS.  The kernel
+forms they selected are still reached by shape (tests/test_gpu_parity.py's graphs, D2S_SHAPES below: fused-phase, per-phase and
+depth-to-space transposed convolutions; packed and plain last N-tiles; dense-K and generic first layers) and every one is held
+to the oracle there.  What is left: precision, activation headroom, and the planner's debug overrides."""
 import numpy as np
 import pytest
 
@@ -17,24 +23,8 @@ HP = model.HParams(model.GRAPH_V2, 64, 2, 3, 28, 3, 3, 0, 2)
 
 SWITCHES = [
     {},                                     # the default plan (reference for the scheduling-only switches)
-    {"UMX_PLANAR": "0"},                    # NHWC activations everywhere
-    {"UMX_PLANAR": "1"},                    # octet-planar wherever eligible (also behind per-phase transposed convolutions)
-    {"UMX_XCD_ORDER": "0"},                 # plain workgroup id -> tile order
-    {"UMX_XCD_ORDER": "2"},                 # one-dimensional grids with (N-block, phase) fastest inside an XCD wherever a layer has several
-    {"UMX_NO_KSTEP_CARRY": "1"},            # k-steps padded per chunk instead of carried into the next chunk
-    {"UMX_NO_FUSED_HEAD": "1"},             # 1x1 head + softmax as its own kernel on an fp32 tensor
-    {"UMX_NO_FUSED_CONVT": "1"},            # transposed convolutions one sub-pixel phase per workgroup
-    {"UMX_NO_FIRST": "1"},                  # first layer on conv_f16x3 instead of the dense-K kernel (and therefore no fold)
-    {"UMX_NO_FOLD": "1"},                   # two-group top convolution, input tiles as (hi, lo) planes
-    {"UMX_NO_CONVT3": "1"},                 # narrow fused transposed convolution at two workgroups per CU
-    {"UMX_NO_NT_TRIAL": "1"},               # per-phase transposed convolutions keep the widest N-block whatever their k-step fill
-    {"UMX_NO_D2S_SKIP": "1"},               # depth-to-space form: the k-steps of row -1 taps also multiply the odd rows' (zero) N-tiles
-    {"UMX_NO_D2S": "1"},                    # narrow transposed convolutions on the fused-phase kernel instead of the depth-to-space form
-    {"UMX_NO_PACKED_TILE": "1"},            # last N-tile of <= 8 real channels as (hi, lo) images and 3 products instead of packed [hi | lo] and 2
-    {"UMX_NO_PACKED_TILE": "convt"},        # ... in the fused-phase transposed convolutions only
     {"UMX_PLAN_OVERRIDE": "lu0.conv:3:2,ld1.conv:1:1:12"},   # forced (octets per chunk, k-steps per stage[, piece-index array])
     {"UMX_PLAN_NT": "ld0.conv:1"},          # a first layer in two N-blocks: no dense-K kernel -> the graph is rebuilt without the raw-skip fold (not failed into fp32)
-    {"UMX_NO_D2S": "1", "UMX_NO_FUSED_CONVT": "1"},   # every transposed convolution one phase per workgroup, the top one with the raw-skip append
     {"UMX_PLAN_NT": "lu2.convT:4"},         # forced N-tiles per workgroup of one layer (here 8 padded N-tiles in two blocks instead of 7 in one)
     {"UMX_PRECISION": "f32"},               # default precision from the environment
     {"UMX_ACT_SHIFT": "2"},                 # activations stored times 4
@@ -81,30 +71,24 @@ def _kernels_run(eng, x, key="kernel"):
     return {p["name"]: p[key] for p in prof if p["kernel"].startswith("conv_f16x3")}
 
 
-def test_forced_xcd_order_2_really_runs(reference, monkeypatch):
-    """UMX_XCD_ORDER used to be latched at the first launch of the process, so a later `=2` never took effect (and the
-    parametrised case above ran order 1).  The profile entry now carries the order a site's last launch used."""
+def test_workgroup_order_2_is_chosen_by_rule(reference):
+    """Workgroup order 2 ((N-block, phase) fastest inside an XCD) is taken per launch where the rule of run_launch_f16 asks for it
+    -- plain convolutions of 2 - 4 N-blocks and halo-bound many-block layers on >= 64 tiles -- and nowhere on a handful of tiles;
+    the profile entry carries the order a site's last launch used, and the results do not depend on it."""
     blob, x, img, ref = reference
-    with umx.Engine(HP, blob, max_batch=5) as eng:
-        base = eng.forward_tiles(x)
-        assert 2 not in _kernels_run(eng, x, "xcd_order").values()     # (5 tiles: below the automatic rule's 64)
-    monkeypatch.setenv("UMX_XCD_ORDER", "2")
-    with umx.Engine(HP, blob, max_batch=5) as eng:
-        got = eng.forward_tiles(x)
-        orders = _kernels_run(eng, x, "xcd_order")
-    assert sum(1 for o in orders.values() if o == 2) >= 2, orders      # every layer with more than one (N-block, phase)
-    assert np.abs(got - ref).max() <= TILE_TOL and np.array_equal(got, base)
-
-
-@pytest.mark.parametrize("slabs", ["1", "2"])
-def test_host_slab_count_does_not_change_the_result(slabs, reference, monkeypatch):
-    """UMX_HOST_SLABS: how many upload / download slabs the host entry points cut a slide into (1 = unpipelined)."""
-    blob, x, img, ref = reference
-    with umx.Engine(HP, blob, max_batch=2) as eng:
-        base = eng.infer_image(img, 0.3, 0.2)
-        monkeypatch.setenv("UMX_HOST_SLABS", slabs)
-        got = eng.infer_image(img, 0.3, 0.2)
-    assert np.array_equal(got.view(np.uint16), base.view(np.uint16))
+    hp = model.HParams(model.GRAPH_V2, 32, 2, 3, 40, 3, 3, 0, 2)      # 160 / 320 output channels: layers of 2 and 3 N-blocks
+    b2 = model.random_blob(hp, seed=2)
+    few = np.random.default_rng(1).normal(size=(5, 32, 32, 2)).astype(np.float32)
+    many = np.random.default_rng(1).normal(size=(80, 32, 32, 2)).astype(np.float32)
+    many[:5] = few
+    with umx.Engine(hp, b2, max_batch=5) as eng:
+        small = eng.forward_tiles(few)
+        assert 2 not in _kernels_run(eng, few, "xcd_order").values()     # (5 tiles: below the rule's 64)
+    with umx.Engine(hp, b2, max_batch=80) as eng:
+        big = eng.forward_tiles(many)
+        orders = _kernels_run(eng, many, "xcd_order")
+    assert sum(1 for o in orders.values() if o == 2) >= 2, orders
+    assert np.array_equal(big[:5], small)
 
 
 def test_two_lanes_option_equals_one_lane(reference):
@@ -150,9 +134,8 @@ D2S_SHAPES = [
 
 @pytest.mark.parametrize("shape", D2S_SHAPES, ids=lambda s: "n%d_c%d_k%d_s%d" % s)
 def test_depth_to_space_transposed_convolution_shapes(shape):
-    """conv_f16x3's D2S form against the oracle, and against the fused-phase form of the same engine (UMX_NO_D2S), on graphs chosen
-    to hit every branch of its N layout; the profile must show that the depth-to-space kernel actually ran."""
-    import os
+    """conv_f16x3's D2S form against the oracle on graphs chosen to hit every branch of its N layout; the profile must show that the
+    depth-to-space kernel actually ran."""
     from oracle import oracle
     n0, C, ks, S = shape
     hp = model.HParams(model.GRAPH_V2, S, C, 3, n0, 2, ks, 0, 2)
@@ -166,31 +149,24 @@ def test_depth_to_space_transposed_convolution_shapes(shape):
     assert np.abs(got - want).max() <= TILE_TOL, shape
     d2s = [n for n, k in kernels.items() if k.startswith("conv_f16x3") and k.endswith(", true>")]
     assert d2s and all("convT" in n for n in d2s), kernels
-    os.environ["UMX_NO_D2S"] = "1"
-    try:
-        with umx.Engine(hp, blob, max_batch=3, precision="f16x3") as eng:
-            base = eng.forward_tiles(x)
-    finally:
-        del os.environ["UMX_NO_D2S"]
-    assert np.abs(got - base).max() <= 2e-6, shape   # same arithmetic, other summation order
 
 
 @pytest.mark.parametrize("dtype", [np.uint16, np.uint8])
-def test_raw_gather_equals_the_float64_image_path(dtype, reference, monkeypatch):
-    """UMX_NO_RAW_GATHER: without an intensity rescale the tile gather reads the raw planes and converts as it reads (one multiply,
-    never fused with the normalisation); with the switch the slide goes through the float64 image first.  Same bytes out, and the
-    same bytes as the float64 entry point fed with the host's im2double."""
+def test_raw_gather_equals_the_float64_image_path(dtype, reference):
+    """The tile gather reads the raw planes and converts as it reads (im2double as one multiply, never fused with the
+    normalisation; with `rescale` the drivers' rescale_intensity too): the same bytes as the float64 entry point fed with the
+    host's own im2double [+ rescale] (toolbox/imtools.py:42-53, UnMicst.py:618-633)."""
     blob, x, img, ref = reference
     raw = np.random.default_rng(5).integers(0, np.iinfo(dtype).max + 1, size=(2, 150, 210)).astype(dtype)
+    I = raw.astype(np.float64) * (1.0 / np.iinfo(dtype).max)
+    R = np.stack([(np.clip(p, p.min(), p.max()) - p.min()) / (p.max() - p.min()) * 0.983 for p in I])
     with umx.Engine(HP, blob, max_batch=3) as eng:
         direct = eng.infer_image_raw(raw, False, 0.3, 0.2)
-        rescaled = eng.infer_image_raw(raw, True, 0.3, 0.2)          # (rescale keeps the float64 image: min / max come first)
-        monkeypatch.setenv("UMX_NO_RAW_GATHER", "1")
-        staged = eng.infer_image_raw(raw, False, 0.3, 0.2)
-        rescaled2 = eng.infer_image_raw(raw, True, 0.3, 0.2)
-        planes = eng.infer_image(raw.astype(np.float64) * (1.0 / np.iinfo(dtype).max), 0.3, 0.2)
-    assert np.array_equal(direct, staged) and np.array_equal(rescaled, rescaled2)
-    # the reference's double uint8 cast of the float16 planes (umx_kernels.hip half_to_u8_kernel)
-    first = (np.float16(255) * planes).astype(np.uint8)
-    want = (255.0 * (first.astype(np.float64) * (1.0 / 255))).astype(np.uint8)
-    assert np.array_equal(direct, want)
+        rescaled = eng.infer_image_raw(raw, True, 0.3, 0.2)
+        planes = eng.infer_image(I, 0.3, 0.2)
+        planes_r = eng.infer_image(R, 0.3, 0.2)
+    for got, pl in ((direct, planes), (rescaled, planes_r)):
+        # the reference's double uint8 cast of the float16 planes (umx_kernels.hip half_to_u8_kernel)
+        first = (np.float16(255) * pl).astype(np.uint8)
+        want = (255.0 * (first.astype(np.float64) * (1.0 / 255))).astype(np.uint8)
+        assert np.array_equal(got, want)

@@ -135,17 +135,15 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
         // per XCD none of it is shared: if those bytes over the layer's matrix time (its executed FLOPs at 0.9 PFLOP/s) exceed
         // 4 TB/s the halo goes through ONE L2 instead.  (Settled per launch: the batch decides.  The solo model's 4 x 4 ... 16 x 16
         // pixel transposed convolutions: 5.9 - 7 TB/s, -13 ... -30 %; the 9-tile layers of the 256-pixel graph: 2.4 - 2.8 TB/s, and
-        // order 2 costs them 8 - 17 % -- their weight slabs then compete for the L2.)  UMX_XCD_ORDER=2 forces it wherever there
-        // is more than one (N-block, phase); =1 keeps order 1.
+        // order 2 costs them 8 - 17 % -- their weight slabs then compete for the L2: hence a rule, not a switch -- the A/B
+        // environment variable of rounds 3-4 is retired.)
         const int ntiles = ((ns + p.imgs - 1) / p.imgs) * p.tiles_y * p.tiles_x;
         const int YZ = p.nblocks * (p.fused_phases ? 1 : p.nphase);
-        const char* const xo = getenv("UMX_XCD_ORDER");   // (read per launch: a switch set after the first launch of the process must count)
-        const bool force2 = xo && !strcmp(xo, "2");
-        bool want2 = force2;
+        bool want2 = false;
         // (plain convolutions of 2 - 4 N-blocks: the blocks of a tile share its halo through the L2 and only 2 - 4 weight slabs
         // compete for it -- the solo model's lu1.conv / lu2.conv -9 / -7 %, the 256-pixel graph's lu3.conv / lu4.conv -2 / -1 %)
-        if (!xo && !p.fused_phases && p.nphase == 1 && YZ >= 2 && YZ <= 4 && ntiles >= 64) want2 = true;
-        if (!xo && !want2 && YZ >= 4 && ntiles >= 64) {
+        if (!p.fused_phases && p.nphase == 1 && YZ >= 2 && YZ <= 4 && ntiles >= 64) want2 = true;
+        if (!want2 && YZ >= 4 && ntiles >= 64) {
             double octets = 0.0;
             for (int gi = 0; gi < L.ngroups; ++gi) octets += (double)((L.g[gi].C + 7) / 8);
             const double halo_bytes = 1.3 * (double)p.nhalo * octets * 32.0 * (double)ntiles * YZ;   // (1.3: 128-byte lines of short rows)
@@ -303,7 +301,7 @@ TileGeom geom_of(const umx_hparams& hp, int H, int W) {
 // tiles [t0, t1) of the slide (row-major tile index) -> probs_dev (tile t0 first): gather + normalise + UNet, in launch
 // groups of <= max_batch tiles
 bool gathers_raw(const umx_ctx* ctx) {
-    return ctx->precision == UMX_PREC_F16X3 && ctx->hp.nChannels <= 8 && ctx->bufs[0].Cs == 8 && !getenv("UMX_NO_RAW_GATHER");
+    return ctx->precision == UMX_PREC_F16X3 && ctx->hp.nChannels <= 8 && ctx->bufs[0].Cs == 8;
 }
 
 int tiles_range(umx_ctx* ctx, const double* image_dev, int C_img, const TileGeom& g, int band_row0, int band_rows,
@@ -517,10 +515,10 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
     c->stream = c->own_stream;
 
     struct { std::vector<size_t> buf_floats; std::vector<std::pair<int, int>> buf_geom; size_t pos = 0; } b;
-    // (the raw-skip fold of the split-precision plan: UMX_NO_FOLD=1 keeps the two-group top convolution, for A/B)
-    // and only where the first layer takes the dense-K kernel: the input tiles are then stored once, in the compact form both read)
+    // (the raw-skip fold of the split-precision plan:
+    // only where the first layer takes the dense-K kernel: the input tiles are then stored once, in the compact form both read)
     static thread_local bool t_no_fold = false;   // (set for the one retry below)
-    const bool fold = precision == UMX_PREC_F16X3 && conv_first_eligible(*hp) && !getenv("UMX_NO_FOLD") && !t_no_fold;
+    const bool fold = precision == UMX_PREC_F16X3 && conv_first_eligible(*hp) && !t_no_fold;
     build_graph(*hp, weight_blob, &c->plan, &b.buf_floats, &b.buf_geom, &b.pos, fold);
     if (b.pos != blob_floats) { umx_destroy(ctx.release()); return fail(nullptr, UMX_ERR_BLOB, "internal blob walk mismatch"); }
     c->bufs.resize(b.buf_floats.size());
@@ -540,12 +538,11 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
         // Same bytes per image either way, so batches slice identically.  With 8 stored channels the two forms coincide.
         // Not for the output of a transposed convolution that runs one sub-pixel phase per workgroup (> 5 N-tiles): its
         // stores are every second pixel of a row, 16 bytes at a 32-byte stride in the planar form (lu2.convT +19 %).
-        const int planar_mode = getenv("UMX_PLANAR") ? atoi(getenv("UMX_PLANAR")) : 2;   // 0: NHWC everywhere, 1: planar wherever eligible, 2: the rule below
         bool phase_written = false;
         for (const Launch& Lp : c->plan)
             if (Lp.dst == (int)i && Lp.nphase == 4 && !(Lp.o_mul == 2 && Lp.ngroups == 1 && (Lp.Cout + 15) / 16 <= 5 && Lp.H >= 8 && Lp.W >= 16))
                 phase_written = true;
-        B.planar = planar_mode != 0 && !(planar_mode == 2 && phase_written) && !B.as_f32 && i != 0 && B.S >= 16 && B.Cs > 8 &&
+        B.planar = !phase_written && !B.as_f32 && i != 0 && B.S >= 16 && B.Cs > 8 &&
                    (size_t)B.S * B.S * 16 < (1u << 24);   // (the kernels form octet offsets with 24-bit multiplies)
         // (hi, lo) binary16 planes with Cs channels take 4*Cs bytes per pixel
         const size_t bytes_per_tile = B.as_f32 ? B.floats_per_tile * sizeof(float) : (size_t)B.S * B.S * B.Cs * 4;

@@ -86,7 +86,7 @@ static int host_submit_impl(umx_ctx* ctx, int slot, bool sync_call, const void* 
     // raw planes: the tile gather converts (and, with `rescale`, rescales to the plane's (min, max) words, ready in stream order
     // before the first tile) as it reads -- the float64 image, 8 bytes written and 14 read per pixel and channel, is never made, and
     // not allocated either: 4.3 GB for a two-channel 16384 x 16384 slide
-    const bool raw_gather = src_bits != 0 && gathers_raw(ctx) && !(rescale && getenv("UMX_NO_RAW_RESCALE"));
+    const bool raw_gather = src_bits != 0 && gathers_raw(ctx);
     if (!raw_gather && (rc = grow(ctx, (void**)&hs.d_image, &hs.image_cap, plane * C_img * sizeof(double)))) return rc;
     if ((rc = grow(ctx, &hs.d_out, &hs.out_cap, mm_off + 64 * (size_t)C_img))) return rc;
     if ((rc = grow(ctx, (void**)&hs.d_probs, &hs.probs_cap, (size_t)g.npr * g.npc * g.P * g.P * K * sizeof(float)))) return rc;
@@ -96,10 +96,9 @@ static int host_submit_impl(umx_ctx* ctx, int slot, bool sync_call, const void* 
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->dn_stream, hipStreamNonBlocking));
     }
     // slabs = the launch groups of the tile loop (equal groups of <= max_batch tiles, exactly what umx_infer_image_dev
-    // runs), so that pipelining the transfers does not change a single kernel launch; UMX_HOST_SLABS=1: no overlap
+    // runs), so that pipelining the transfers does not change a single kernel launch
     const int T = g.npr * g.npc;
-    int S = std::max(1, (T + ctx->max_batch - 1) / ctx->max_batch);
-    if (const char* e = getenv("UMX_HOST_SLABS")) S = std::max(1, std::min(atoi(e), S));
+    const int S = std::max(1, (T + ctx->max_batch - 1) / ctx->max_batch);
     // A synchronous call on a slide of one launch group has nothing to overlap: its upload, kernels and download go down ONE
     // stream in order, without the copy streams and the events that hand slabs from one stream to the next (a 1024 x 1024
     // slide is a 1 - 3 ms call).  Submitted calls keep the copy streams: slide i+1's upload rides under slide i's kernels --

@@ -15,8 +15,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     // halo chunk next to 8 N-tiles of weights) fills its k-steps with 1 - 2 (tap, octet) pairs of 4 in the phases that have 1 - 2
     // taps: 640 executed k-steps for 360.  Narrower N-blocks leave LDS for two octets per chunk (400 k-steps; lu3.convT -16 %,
     // the solo step -1.6 %): dry-run the search for every N-tile count with the same padding and take a >= 20 % shorter K loop.
-    if (!dry && !L.force_nt16 && L.nphase == 4 && !L.d2s && !L.train && !getenv("UMX_PLAN_NT") && !getenv("UMX_PLAN_OVERRIDE") &&
-        !getenv("UMX_NO_NT_TRIAL")) {
+    if (!dry && !L.force_nt16 && L.nphase == 4 && !L.d2s && !L.train && !getenv("UMX_PLAN_NT") && !getenv("UMX_PLAN_OVERRIDE")) {
         const int t16 = (L.Cout + 15) / 16;
         int base_k = 0, base_nt = 0, best_k = 0, best_nt = 0;
         for (int c = std::min(t16, kMaxNT16); c >= 4; --c) {   // (narrower than 4 N-tiles re-reads the halo too often)
@@ -36,7 +35,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     // stride-2 transposed convolution with few output channels: all four sub-pixel phases in one workgroup (the input
     // halo is read once instead of four times; 4 accumulator sets limit it to 5 N-tiles and 128 input pixels)
     const bool fused = L.nphase == 4 && L.o_mul == 2 && L.ngroups == 1 && !out_f32 && t16 <= 5 && L.H >= 8 && L.W >= 16 &&
-                       !L.train && !getenv("UMX_NO_FUSED_CONVT");
+                       !L.train;
     h.fused_phases = fused ? 1 : 0;
     if (fused) {
         const int THg = 1 << g.th_log2, TWg = 1 << g.twm_log2;   // >= 8 and == 16 under the conditions above
@@ -73,12 +72,9 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     h.NT = nt16; h.nblocks = Np16 / (16 * nt16);
     // packed last N-tile (conv_f16x3's PK form): <= 8 real channels in the last of 2..5 N-tiles of a single N-block
     const int last_real = L.Cout - (nt16 - 1) * 16;
-    // (UMX_NO_PACKED_TILE=1: nowhere; =convt: not in the fused-phase transposed convolutions)
-    const char* const nopk = getenv("UMX_NO_PACKED_TILE");
-    const bool pk_off = nopk && (!strcmp(nopk, "1") || (fused && !strcmp(nopk, "convt")));
     h.d2s = L.d2s;
     h.d2s_mix = L.d2s && L.d2s_R > 0;
-    h.pk = (!L.d2s && !L.train && h.nblocks == 1 && nt16 >= 2 && nt16 <= 5 && last_real >= 1 && last_real <= 8 && !pk_off && !getenv("UMX_DEBUG_STAMPS")) ? 1 : 0;
+    h.pk = (!L.d2s && !L.train && h.nblocks == 1 && nt16 >= 2 && nt16 <= 5 && last_real >= 1 && last_real <= 8 && !getenv("UMX_DEBUG_STAMPS")) ? 1 : 0;
     h.outH = L.outH; h.outW = L.outW; h.pool = L.pool; h.act = L.act;
     if (h.nhalo > kHaloChunks * 64) { *why = "halo too large for the split-precision kernel"; return UMX_ERR_INVALID; }
     h.plane_slots = round_up(h.nhalo, 16);
@@ -127,7 +123,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         const int nt3 = 40 * 1024;      // 4 workgroups per CU (the <= 3-tile kernels are built for 128 VGPRs)
         if (fused) {   // (4 pieces per wave and chunk where the halo fits them: 8 index registers and two thirds of the prologue less)
             attempts.clear();
-            if (nt16 <= 3 && !getenv("UMX_NO_CONVT3")) attempts.push_back({4, narrow, 1 << 30});   // 164 registers: three workgroups per CU where the LDS allows
+            if (nt16 <= 3) attempts.push_back({4, narrow, 1 << 30});   // 164 registers: three workgroups per CU where the LDS allows
             attempts.push_back({4, kMaxLdsPerWG, 1 << 30});
             if (nt16 <= 3) attempts.push_back({12, kMaxLdsPerWG, 1 << 30});
         }
@@ -159,7 +155,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     // the previous chunk's halo slot is still resident then (its reload is issued at the start of the next chunk's LAST
     // stage, so the next chunk must have >= 2 stages).  Not across the phases of the fused kernel (other accumulators).
     struct Pair { int gi, ph, tap, oct, slot, k; };   // slot: halo slot (0/1) of the chunk; k: octet inside the chunk
-    const bool carry_ok = !fused && !L.train && !getenv("UMX_NO_KSTEP_CARRY");   // (training plans: every chunk stands alone -- the K split cuts between chunks)
+    const bool carry_ok = !fused && !L.train;   // (training plans: every chunk stands alone -- the K split cuts between chunks)
     auto npairs_of = [&](const Chunk& k, int ph) { return (int)L.g[k.gi].taps[ph].size() * (k.o1 - k.o0); };
     auto plan_list = [&](int OC, int S, int list, std::vector<HStage>* stages_out,
                          std::vector<std::vector<Pair>>* steps_out, int* nchunks) {
@@ -295,21 +291,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     h.lo_off = bestSlots * h.slot_bytes;
     h.b_off = 2 * h.lo_off;
     h.wbuf_bytes = 64 + S * nt16 * 2048;
-    {   // XCD-aware tile order (default on; UMX_XCD_ORDER=0 off, or a comma list of layer-name prefixes to limit it)
-        h.xcd_order = 1;
-        if (const char* e = getenv("UMX_XCD_ORDER")) {
-            std::string spec(e);
-            h.xcd_order = (spec == "1" || spec == "2" || spec == "all") ? 1 : 0;   // ("2": run_launch_f16 turns 1 into 2)
-            size_t pos = 0;
-            while (pos < spec.size()) {
-                const size_t end = spec.find(',', pos);
-                const std::string tok = spec.substr(pos, end == std::string::npos ? std::string::npos : end - pos);
-                if (tok.size() > 1 && L.name.compare(0, tok.size(), tok) == 0) h.xcd_order = 1;
-                if (end == std::string::npos) break;
-                pos = end + 1;
-            }
-        }
-    }
+    h.xcd_order = 1;   // XCD-aware tile order (run_launch_f16 turns it into order 2 where its rule says so)
     h.lds_bytes = h.b_off + 2 * h.wbuf_bytes;
 
     std::vector<HStage> stages;
@@ -340,7 +322,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
             size_t k0 = 0;
             for (int si = h.ph[list].stage0; si < (int)stages.size(); ++si) { ks_of.push_back(k0); k0 += (size_t)stages[si].nk; }
         }
-        const bool d2s_skip = L.d2s && L.d2s_npb == 4 && !getenv("UMX_NO_D2S_SKIP");
+        const bool d2s_skip = L.d2s && L.d2s_npb == 4;
         std::atomic<bool> bad_slot{false};
         const int nst = (int)stages.size() - h.ph[list].stage0;
         auto fill_task = [&](int task) {
@@ -423,7 +405,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         const float oscale = out_f32 ? 1.f : std::ldexp(1.f, act_shift);
         const int nb16 = nt16 * 16;
         // a fused softmax head needs every channel of a pixel in one workgroup; it replaces the fp32 store of this layer
-        const bool fuse_head = head && out_f32 && h.nblocks == 1 && head->head_K <= 4 && !fused && !getenv("UMX_NO_FUSED_HEAD");
+        const bool fuse_head = head && out_f32 && h.nblocks == 1 && head->head_K <= 4 && !fused;
         h.head_K = fuse_head ? head->head_K : 0;
         const size_t per_blk = (fuse_head ? (size_t)(4 + h.head_K) * nb16 + 16 : (size_t)4 * nb16) + (L.d2s ? 64 : 0);
         std::vector<float> ec((size_t)h.nblocks * per_blk, 0.f);
@@ -547,7 +529,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
 // x channel slots fit two k-steps; everything else stays on conv_f16x3.  Reuses plan_f16's weight shift and epilogue
 // constants, so the two kernels differ only in the summation order inside the (now single) k-step.
 bool conv_first_eligible(const umx_hparams& hp) {
-    if (getenv("UMX_NO_FIRST") || hp.nExtraConvs != 0 || hp.nChannels < 1 || hp.nChannels > 4 || hp.imSize < 16 || hp.nOut0 > 80) return false;
+    if (hp.nExtraConvs != 0 || hp.nChannels < 1 || hp.nChannels > 4 || hp.imSize < 16 || hp.nOut0 > 80) return false;
     const int CW = hp.nChannels == 1 ? 1 : hp.nChannels == 2 ? 2 : 4;
     return conv_first_supported((hp.nOut0 + 15) / 16, CW, (hp.ks * hp.ks * CW + 31) / 32);
 }
@@ -555,7 +537,6 @@ bool conv_first_eligible(const umx_hparams& hp) {
 int plan_first(umx_ctx* ctx, Launch& L, int act_shift, std::string* why) {
     (void)why;
     L.use_first = false;
-    if (getenv("UMX_NO_FIRST")) return UMX_OK;   // A/B aid: the layer stays on conv_f16x3
     const HConvParams& h = L.hcp;
     if (L.ngroups != 1 || L.g[0].src != 0 || L.nphase != 1 || !L.pool || h.head_K > 0 || h.nblocks != 1) return UMX_OK;
     const int Ci = L.g[0].C, P = L.H;
@@ -624,7 +605,6 @@ int plan_first(umx_ctx* ctx, Launch& L, int act_shift, std::string* why) {
 // One block of all four phases if that is <= 9 N-tiles, else two blocks by output row parity (the pu = 1 block has no dy = -1
 // taps: half the K loop); wider layers stay on the per-phase / fused-phase forms.
 bool make_d2s(Launch& L) {
-    if (getenv("UMX_NO_D2S")) return false;
     if (L.head || L.nphase != 4 || L.o_mul != 2 || L.ngroups != 1 || L.pool || L.H < 2) return false;   // (M-tile pairs = row pairs of an image)
     for (int ph = 0; ph < 4; ++ph)
         if (L.oy_off[ph] != (ph >> 1) || L.ox_off[ph] != (ph & 1) || L.g[0].taps[ph].empty() || L.g[0].packed[ph].empty()) return false;

@@ -49,7 +49,7 @@ struct H16 {                         // (hi, lo) binary16 NHWC planes of one ten
     int Cs = 0;
 };
 
-constexpr int kSlots = 4;   // dz / gS buffers the main stream may run ahead of the weight gradients by (UMX_TRAIN_SLOTS: 2 .. 4)
+constexpr int kSlots = 4;   // dz / gS buffers the main stream may run ahead of the weight gradients by
 
 struct TapSet {
     std::vector<std::pair<int, int>> off;   // (dy, dx) input offsets
@@ -100,7 +100,7 @@ struct umx_trainer {
     float* GS2[kSlots] = {};   // while the main stream moves on to layers l+1 .. l+nslots-1
     int nslots = kSlots;
     hipStream_t side = nullptr;
-    hipStream_t side2 = nullptr;          // a second side stream: the dz / gS slots alternate between the two (UMX_TRAIN_ONE_SIDE=1: one)
+    hipStream_t side2 = nullptr;          // a second side stream: the dz / gS slots alternate between the two
     hipEvent_t ev_join2 = nullptr;
     hipEvent_t ev_dz[kSlots] = {}, ev_gs[kSlots] = {}, ev_side[kSlots] = {}, ev_join = nullptr;
     hipStream_t aux = nullptr;                    // the skip connections' input gradients: needed only on the way back down the U, so
@@ -122,7 +122,7 @@ struct umx_trainer {
     // forward / input-gradient convolutions on conv_f16x3 (UMX_TRAIN_CONV_F32=1: the exact-fp32 kernels of rounds 1-3)
     bool range_pending = false;         // a training step raised the range flag and an eval pass cleared it before umx_trainer_loss saw it
     bool hconv = true;
-    bool wg_planes = true;              // the split-precision weight gradient stages from the planes (UMX_TRAIN_WGRAD_FP32_STAGE=1: from fp32)
+    bool wg_planes = true;              // the split-precision weight gradient stages from the planes
     umx_ctx* pctx = nullptr;            // owner of the planner's device allocations (stage tables, weight slabs, constants)
     const float* h_blob = nullptr;      // (during build) the initial parameters on the host: weight scales
     std::vector<umx::Launch> hls;
@@ -262,7 +262,7 @@ int setup_hconv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int 
         L.g[g].src = g;
         L.g[g].C = gs[g].C;
         for (int ph = 0; ph < nphase; ++ph) L.g[g].taps[ph] = gs[g].taps[ph].off;
-        if (gs[g].npar > 1 && gs[g].Cblk % 8 == 0 && !getenv("UMX_TRAIN_KEEP_ZERO_PAIRS")) {
+        if (gs[g].npar > 1 && gs[g].Cblk % 8 == 0) {
             const int noct = (gs[g].C + 7) / 8;
             for (int ph = 0; ph < nphase; ++ph) {
                 const TapSet& ts = gs[g].taps[ph];
@@ -294,7 +294,7 @@ int setup_hconv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int 
     // The planner's references address the packed fp32 operand [tap][Cp][Np]; rewritten here into the master tensor's own
     // coordinates (the index arithmetic of pack_weights_kernel, done once on the host), the per-step repack reads the parameters
     // directly and this convolution needs no fp32 operand at all.  An octet that straddles two parity blocks keeps the packed route.
-    bool direct = !getenv("UMX_TRAIN_PACKED_REPACK");
+    bool direct = true;
     for (int ph = 0; ph < nphase && direct; ++ph)
         for (const umx::HWRef& r : L.wrefs[ph]) {
             const GroupSpec& G = gs[r.arr];
@@ -348,10 +348,9 @@ int setup_hconv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int 
     {   // K split: enough workgroups to occupy the chip (two per CU) where a batch of 8 leaves a deep layer a few dozen
         HConvParams& h = L.hcp;
         const long wgs = (long)((tr->B + h.imgs - 1) / h.imgs) * h.tiles_y * h.tiles_x * h.nblocks * nphase;
-        const char* e1 = getenv("UMX_TRAIN_HSPLIT_WGS");
         // (one workgroup per CU: 512 / 768 / 1024 lose 3 / 7 / 10 % of the step to the ordered reduce over more partial sums, 128 / 192
         // lose 1 % to idle CUs -- profiles/r04/train_ksplit_sweep.txt)
-        const long target = e1 ? atol(e1) : 256;
+        const long target = 256;
         int S = (int)std::min<long>(kMaxKSplit, wgs > 0 ? (target + wgs - 1) / wgs : 1);
         if (getenv("UMX_TRAIN_NO_KSPLIT") || wgs * 2 > target) S = 1;
         std::vector<std::vector<int>> starts(nphase);   // per phase: stage indices (relative) where a halo chunk begins
@@ -436,9 +435,7 @@ int setup_conv(umx_trainer* tr, TConv& tc, const char* what, int H, int W, int C
         int min_chunks = 1 << 30;
         for (int g = 0; g < ngroups; ++g) min_chunks = std::min(min_chunks, (round_up(gs[g].C, 4) + kCC - 1) / kCC);
         int S = 1;
-        const char* e1 = getenv("UMX_TRAIN_KSPLIT_WGS");
-        const char* e2 = getenv("UMX_TRAIN_KSPLIT_MAX");
-        const long target = e1 ? atol(e1) : 1536, smax = e2 ? atol(e2) : 8;
+        const long target = 1536, smax = 8;
         if (wgs < target / 2 && !getenv("UMX_TRAIN_NO_KSPLIT"))
             S = (int)std::max<long>(1, std::min<long>(std::min<long>(smax, target / wgs), min_chunks / 4));
         p.ksplit = S;
@@ -1007,7 +1004,6 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
     tr->ds.assign(L + 1, nullptr);
     tr->bn_d.resize(L); tr->bn_u.resize(L);
     tr->us.assign(L, nullptr); tr->cv.assign(L, nullptr); tr->dskip.assign(L, nullptr);
-    if (const char* e = getenv("UMX_TRAIN_SLOTS")) tr->nslots = std::max(2, std::min(kSlots, atoi(e)));
     size_t max_act = (size_t)B * P * P * std::max(n[0], K);
     int S = P;
     for (int i = 0; i < L; ++i) {
@@ -1072,7 +1068,7 @@ int build_trainer(umx_trainer* tr, const float* blob, size_t blob_floats) {
     // ---- split-precision route of the forward / input-gradient convolutions: planes of every tensor they read
     tr->hconv = !getenv("UMX_TRAIN_CONV_F32");
     if (const char* e = getenv("UMX_TRAIN_WSCALE_EVERY")) tr->wscale_every = atoi(e);
-    tr->wg_planes = tr->hconv && !getenv("UMX_TRAIN_WGRAD_FP32_STAGE");
+    tr->wg_planes = tr->hconv;
     tr->h_blob = blob;
     if (tr->hconv) {
         tr->pctx = new umx_ctx();
@@ -1344,11 +1340,11 @@ int umx_trainer_create(const umx_hparams* hp, const float* weight_blob, size_t b
         for (int i = 0; i < 4; ++i)
             if (hipEventCreate(&tr->ev[i]) != hipSuccess) rc = tfail(tr, UMX_ERR_HIP, "hipEventCreate failed");
     if (rc == UMX_OK) {
-        tr->overlap = !getenv("UMX_TRAIN_NO_OVERLAP");
+        tr->overlap = true;
         if (hipStreamCreateWithFlags(&tr->side, hipStreamNonBlocking) != hipSuccess) rc = tfail(tr, UMX_ERR_HIP, "hipStreamCreate failed");
-        if (!getenv("UMX_TRAIN_ONE_SIDE") && hipStreamCreateWithFlags(&tr->side2, hipStreamNonBlocking) != hipSuccess)
+        if (hipStreamCreateWithFlags(&tr->side2, hipStreamNonBlocking) != hipSuccess)
             rc = tfail(tr, UMX_ERR_HIP, "hipStreamCreate failed");
-        if (!getenv("UMX_TRAIN_NO_AUX") && hipStreamCreateWithFlags(&tr->aux, hipStreamNonBlocking) != hipSuccess)
+        if (hipStreamCreateWithFlags(&tr->aux, hipStreamNonBlocking) != hipSuccess)
             rc = tfail(tr, UMX_ERR_HIP, "hipStreamCreate failed");
         tr->ev_skip.assign(32, nullptr);
         std::vector<hipEvent_t*> evs = {&tr->ev_join, &tr->ev_begin, &tr->ev_packed, &tr->ev_join2};

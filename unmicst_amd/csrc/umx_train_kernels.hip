@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256) chan_stats_v4_kernel(const float* __restr
 }
 
 hipError_t launch_chan_stats(const float* x, size_t N, int C, double* part, int nblk, hipStream_t stream) {
-    if (C % 4 == 0 && N < 0x7fffffffull && !getenv("UMX_TRAIN_ACT_SCALAR")) {
+    if (C % 4 == 0 && N < 0x7fffffffull) {
         const int Q = C / 4, Qb = std::min(Q, 256), R = std::max(1, 256 / Qb), cbl = (Q + 255) / 256;
         hipLaunchKernelGGL(chan_stats_v4_kernel, dim3((unsigned)nblk, (unsigned)cbl), dim3(256), 0, stream, x, (unsigned)N, C, Qb, R, part);
         return hipGetLastError();
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(256) act_fwd_v4_kernel(const ActParams a, floa
 hipError_t launch_act_fwd(const ActParams& a, float* out, unsigned* omax, _Float16* hi, _Float16* lo, int Cs, int* overflow,
                           hipStream_t stream) {
     const size_t nout = (size_t)a.B * (a.pool ? a.H / 2 : a.H) * (a.pool ? a.W / 2 : a.W) * a.C;
-    if (a.C % 4 == 0 && (!hi || Cs % 4 == 0) && nout < 0xfffffff0ull && !getenv("UMX_TRAIN_ACT_SCALAR")) {
+    if (a.C % 4 == 0 && (!hi || Cs % 4 == 0) && nout < 0xfffffff0ull) {
         const unsigned nq = (unsigned)(nout / 4);
         const unsigned blocks = std::min<unsigned>(4096, (nq + 255) / 256);
         hipLaunchKernelGGL(act_fwd_v4_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, a, out, nq, omax, hi, lo, Cs, overflow);
@@ -680,7 +680,7 @@ hipError_t launch_act_bwd(const ActParams& a, const float* dy0, const float* dy1
                           unsigned* gx, hipStream_t stream) {
     const ChanLayout l = chan_layout(a.C);
     const size_t rows = (size_t)a.B * (a.pool ? a.H / 2 : a.H) * (a.pool ? a.W / 2 : a.W);
-    if (a.C % 4 == 0 && rows < 0x7fffffffull && !getenv("UMX_TRAIN_ACT_SCALAR")) {
+    if (a.C % 4 == 0 && rows < 0x7fffffffull) {
         const int Q = a.C / 4, Qb = std::min(Q, 256), R = std::max(1, 256 / Qb), cbl = (Q + 255) / 256;
         hipLaunchKernelGGL(act_bwd_v4_kernel, dim3((unsigned)nblk, (unsigned)cbl), dim3(256), 0, stream, a, dy0, dy1, g, (unsigned)rows,
                            Qb, R, part, gx);
@@ -873,7 +873,7 @@ __global__ void __launch_bounds__(256) leaky_bwd_s2d_v4_kernel(const float4* __r
 hipError_t launch_leaky_bwd_s2d_max(const float* d_us, const float* us, int B, int S, int C, float* gS, unsigned* gmax,
                                     hipStream_t stream) {
     const size_t n = (size_t)B * S * S * 4 * C;
-    if (C % 4 == 0 && n < 0xffffffffull && !getenv("UMX_TRAIN_ACT_SCALAR")) {
+    if (C % 4 == 0 && n < 0xffffffffull) {
         const unsigned n4 = (unsigned)(n / 4);
         const unsigned blocks = std::min(2048u, (n4 + 255u) / 256u);
         hipLaunchKernelGGL(leaky_bwd_s2d_v4_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, stream, reinterpret_cast<const float4*>(d_us),
@@ -1908,7 +1908,7 @@ bool wgrad_setup(WgradParams* p, std::string* why) {
     }
     p->f16 = 0;
     p->thin = 0;
-    if (p->Cx <= 4 && p->ngroups == 1 && p->Cg <= 128 && (p->W & (p->W - 1)) == 0 && !getenv("UMX_TRAIN_WGRAD_NO_THIN")) {
+    if (p->Cx <= 4 && p->ngroups == 1 && p->Cg <= 128 && (p->W & (p->W - 1)) == 0) {
         // whole rows per workgroup, ~1024 workgroups, the strip's halo + the partial sums inside 64 KB of LDS
         int R = 1;
         while (R * 2 <= p->H && p->H % (R * 2) == 0 && (long)p->B * p->H / (R * 2) >= 1024) R *= 2;
@@ -1942,8 +1942,7 @@ bool wgrad_setup(WgradParams* p, std::string* why) {
             // ~384 workgroups a launch (A/B on the box: 128 -> 1162 images/s at batch 8, 256 -> 1293, 384 -> 1294, 512 -> 1279,
             // 1024 -> 1247, 2048 -> 1172): fewer slices mean fewer prologues / accumulator flushes and a shorter reduce; below
             // one workgroup per CU the launch no longer fills the chip beside the main stream's kernels
-            const char* const et = getenv("UMX_TRAIN_WG_TARGET");
-            const int target = et ? std::max(64, atoi(et)) : 384;
+            const int target = 384;
             int nslices = std::max(1, std::min(p->ntiles, target / std::max(1, chunks)));
             p->tiles_per_slice = (p->ntiles + nslices - 1) / nslices;
             p->nslices = (p->ntiles + p->tiles_per_slice - 1) / p->tiles_per_slice;
@@ -2021,7 +2020,7 @@ hipError_t launch_wgrad(const WgradParams& p, hipStream_t stream) {
             attr_set = true;
         }
         const unsigned chunks = (unsigned)(((p.Cx + kHwC - 1) / kHwC) * ((p.Cg + kHwC - 1) / kHwC));
-        bool oc = p.planes && p.XCs % 8 == 0 && p.GCs % 8 == 0 && p.imgs * p.hh * ((p.hw + 1) / 2) * 6 <= 3 * 256 && !getenv("UMX_TRAIN_WGRAD_QUAD");
+        bool oc = p.planes && p.XCs % 8 == 0 && p.GCs % 8 == 0 && p.imgs * p.hh * ((p.hw + 1) / 2) * 6 <= 3 * 256;
         for (int sb = 0; sb < p.nslab && oc; ++sb) oc = p.coff[sb] % 8 == 0;
         if (oc)
             hipLaunchKernelGGL((wgrad_f16x3<true, true>), dim3((unsigned)p.nslices, chunks, (unsigned)p.ngroups), dim3(256), wgrad_f16_lds(p),
