@@ -79,12 +79,12 @@ def test_workgroup_order_2_is_chosen_by_rule(reference):
     hp = model.HParams(model.GRAPH_V2, 32, 2, 3, 40, 3, 3, 0, 2)      # 160 / 320 output channels: layers of 2 and 3 N-blocks
     b2 = model.random_blob(hp, seed=2)
     few = np.random.default_rng(1).normal(size=(5, 32, 32, 2)).astype(np.float32)
-    many = np.random.default_rng(1).normal(size=(80, 32, 32, 2)).astype(np.float32)
+    many = np.random.default_rng(1).normal(size=(320, 32, 32, 2)).astype(np.float32)    # 8 x 8-pixel layers: 4 images per workgroup tile
     many[:5] = few
     with umx.Engine(hp, b2, max_batch=5) as eng:
         small = eng.forward_tiles(few)
         assert 2 not in _kernels_run(eng, few, "xcd_order").values()     # (5 tiles: below the rule's 64)
-    with umx.Engine(hp, b2, max_batch=80) as eng:
+    with umx.Engine(hp, b2, max_batch=320) as eng:
         big = eng.forward_tiles(many)
         orders = _kernels_run(eng, many, "xcd_order")
     assert sum(1 for o in orders.values() if o == 2) >= 2, orders
