@@ -411,7 +411,8 @@ with umx.Engine(hp, blob, max_batch=8) as eng:
     # umx_infer_image_raw[_range] of the whole slide: the gathered stack on every rank and the rank's own rows, byte for byte --
     # synchronous, then two slides in flight on the two slots (per-slot gather buffers)
     K = hp.nClasses
-    for (H, W, dt, rescale) in ((233, 97, np.uint16, False), (150, 120, np.uint16, True), (97, 61, np.uint8, True)):
+    # (the last slide has two patch rows: in a world of three the third rank's band is empty -- it still takes part in every collective)
+    for (H, W, dt, rescale) in ((233, 97, np.uint16, False), (150, 120, np.uint16, True), (97, 61, np.uint8, True), (40, 75, np.uint16, False)):
         top = 40000 if dt == np.uint16 else 200
         raw = (np.random.default_rng(H + 1).random((2, H, W)) * top).astype(dt)
         rng = [(int(raw[c].min()), int(raw[c].max())) for c in range(2)] if rescale else None
@@ -442,8 +443,10 @@ with umx.Engine(hp, blob, max_batch=8) as eng:
         ok = ok and same and same2
         print("rank %%d of %%d: raw %%s %%d x %%d rescale=%%s own rows [%%d, %%d) equal=%%s in-flight equal=%%s" %% (rank, world, dt.__name__, H, W, rescale, o0, o1, same, same2), flush=True)
 slides = 2 + 3 * 3
-assert calls["send"] == (slides if rank < world - 1 else 0) and calls["recv"] == (slides if rank > 0 else 0), calls   # one halo row per slide
-assert calls["all_gather"] >= slides
+# one halo row per slide between neighbouring NON-EMPTY bands; the three 40-row slides have two patch rows: rank 0 -> rank 1 only
+assert calls["send"] == (slides if rank < world - 1 else 0) + (3 if rank == 0 else 0), calls
+assert calls["recv"] == (slides if rank > 0 else 0) + (3 if rank == 1 else 0), calls
+assert calls["all_gather"] >= slides + 3
 assert ok
 print("rank %%d native transport ok" %% rank, flush=True)
 dist.barrier()

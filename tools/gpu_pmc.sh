@@ -6,7 +6,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/$1; shift; mkdir -p $O
 D=/tmp/umx_prof; rm -rf $D; mkdir -p $D
-rocprofv3 --kernel-trace --stats -d $D/stats -o run -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 "$@" > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $D/stats -o run -- python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-legs "$@" > $O/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $D/pmc_sq -o run -- python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 --resident-only "$@" > $O/pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $D/pmc_tcc -o run -- python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 --resident-only "$@" > $O/pmc_tcc.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $D/pmc_fetch -o run -- python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 --resident-only "$@" > $O/pmc_fetch.log 2>&1
