@@ -392,17 +392,29 @@ int sharded_run(umx_ctx* ctx, Shard& s, const RunIO& io, int C_img, int H, int W
         return UMX_OK;
     };
     const umx::TileGeom g = umx::geom_of(hp, H, W);
-    auto tiles = [&](int r0, int r1) -> int {
-        if (r1 <= r0) return UMX_OK;
-        if ((rc = stage(r0, r1))) return rc;
-        float* const dst = probs + (size_t)(r0 - lo) * row_f;
-        if (io.raw_dev)
-            return umx::tiles_range(ctx, nullptr, C_img, g, band_row0, band_rows, mean, stdv, r0 * g.npc, r1 * g.npc, dst, io.raw_dev, io.raw_bits, io.mm);
-        return umx_band_tiles_dev(ctx, io.band_f64, C_img, H, W, band_row0, band_rows, mean, stdv, r0, r1, dst);
+    // tiles [t0, t1) of the slide (row-major tile index) -> their place in `probs` (tile lo * npc first)
+    auto tiles = [&](int t0, int t1) -> int {
+        if (t1 <= t0) return UMX_OK;
+        if ((rc = stage(t0 / g.npc, (t1 - 1) / g.npc + 1))) return rc;
+        float* const dst = probs + (size_t)(t0 - lo * g.npc) * tile_f;
+        return umx::tiles_range(ctx, io.raw_dev ? nullptr : io.band_f64, C_img, g, band_row0, band_rows, mean, stdv, t0, t1, dst, io.raw_dev,
+                                io.raw_bits, io.mm);
     };
-    // last patch row first where a next rank waits for it (the last band -- and a world of one -- runs its rows in order: no odd
-    // launch group of one patch row)
-    if (has_next && (rc = tiles(pb - 1, pb))) return rc;
+    // Launch groups.  The next rank waits for this band's LAST patch row, so it is computed first -- but not as a launch group of
+    // its own (86 tiles of the 16384-wide slide fill a third of the chip's workgroup slots on the deep layers and still cost every
+    // layer a generation): the first group is the band's last F tiles, F = the remainder of the band's tile count over the launch
+    // group size (raised by whole groups until it holds the last row), and every later group is a full one, whatever slab it
+    // belongs to.  11 patch rows of 86 tiles at 256 per group: 178 + 3 x 256 instead of 86 + 4 x 215 -- the same number of
+    // workgroup generations as an unsharded band.  The last band (nobody waits) runs in order.
+    const int Bt = std::max(1, ctx->max_batch), T0 = pa * g.npc, T1 = pb * g.npc;
+    int F = 0;
+    if (has_next) {
+        F = (T1 - T0) % Bt;
+        while (F < g.npc) F += Bt;
+        F = std::min(F, T1 - T0);
+    }
+    if ((rc = tiles(T1 - F, T1))) return rc;
+    int done = T0;   // tiles [T0, done) and [T1 - F, T1) are enqueued
     S_HIP(ctx, hipEventRecord(ev_last, cs));
     S_HIP(ctx, hipStreamWaitEvent(ms, ev_last, 0));
     if (has_next || has_prev) {
@@ -435,7 +447,13 @@ int sharded_run(umx_ctx* ctx, Shard& s, const RunIO& io, int C_img, int H, int W
             if ((rc = grow(ctx, &send[i], (size_t)K * mx_all * W * el))) return rc;
     }
     for (int i = 0; i < n; ++i) {
-        if (pa < pb && (rc = tiles(umx_geom::cut(pa, pb, n, i), std::min(umx_geom::cut(pa, pb, n, i + 1), has_next ? pb - 1 : pb)))) return rc;
+        // the launch groups slab i still lacks: every tile of the patch rows below its last image row (full groups: one may run into the next slab)
+        const int need = pa < pb ? std::min(umx_geom::cut(pa, pb, n, i + 1) * g.npc, T1 - F) : T0;
+        while (done < need) {
+            const int t1 = std::min(done + Bt, T1 - F);
+            if ((rc = tiles(done, t1))) return rc;
+            done = t1;
+        }
         if (i == 0) S_HIP(ctx, hipStreamWaitEvent(cs, ev_halo, 0));   // the previous rank's last patch row feeds this band's first rows
         int s0, s1;
         umx_geom::slab(pa, pb, npr, sub, margin, H, n, i, &s0, &s1);
