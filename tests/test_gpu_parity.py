@@ -442,7 +442,24 @@ with umx.Engine(hp, blob, max_batch=8) as eng:
                  and np.array_equal(owns[0], want[:, o0:o1]) and np.array_equal(owns[1], want2[:, o0:o1]))
         ok = ok and same and same2
         print("rank %%d of %%d: raw %%s %%d x %%d rescale=%%s own rows [%%d, %%d) equal=%%s in-flight equal=%%s" %% (rank, world, dt.__name__, H, W, rescale, o0, o1, same, same2), flush=True)
-slides = 2 + 3 * 3
+# an engine whose tile gather reads float64 (exact-fp32 precision): the raw entry uploads the band whole and converts it first
+with umx.Engine(hp, blob, max_batch=8, precision="f32") as eng:
+    eng.shard_init_transport(send, recv, all_gather, rank, world, group_start=lambda: None, group_end=group_end)
+    H, W = 120, 88
+    raw = (np.random.default_rng(5).random((2, H, W)) * 50000).astype(np.uint16)
+    rng = [(int(raw[c].min()), int(raw[c].max())) for c in range(2)]
+    want = eng.infer_image_raw(raw, True, 0.2, 0.2, value_range=rng)
+    pl = eng.shard_plan(H, W, rank, world, nslabs)
+    r0, r1, o0, o1 = pl["need_row0"], pl["need_row1"], pl["own_row0"], pl["own_row1"]
+    full = torch.zeros((hp.nClasses, H, W), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    own = eng.infer_image_sharded_raw(np.ascontiguousarray(raw[:, r0:r1]), H, W, r0, rng, 0.2, 0.2, nslabs=nslabs, own_rows=o1 - o0,
+                                      out_full_ptr=full.data_ptr())
+    torch.cuda.synchronize()
+    same = np.array_equal(full.cpu().numpy(), want) and np.array_equal(own, want[:, o0:o1])
+    ok = ok and same
+    print("rank %%d of %%d: raw entry on the f32 engine equal=%%s" %% (rank, world, same), flush=True)
+slides = 2 + 3 * 3 + 1
 # one halo row per slide between neighbouring NON-EMPTY bands; the three 40-row slides have two patch rows: rank 0 -> rank 1 only
 assert calls["send"] == (slides if rank < world - 1 else 0) + (3 if rank == 0 else 0), calls
 assert calls["recv"] == (slides if rank > 0 else 0) + (3 if rank == 1 else 0), calls

@@ -518,6 +518,8 @@ int umx_infer_image_sharded_dev(umx_ctx* ctx, const double* band_dev, int C_img,
     if (!out_full_dev || H < 1 || W < 1) return umx_internal_fail(ctx, UMX_ERR_INVALID, "bad out / H / W");
     Shard* sp = shard_of(ctx);
     if (!sp) return umx_internal_fail(ctx, UMX_ERR_INVALID, "call umx_shard_init (or umx_shard_init_transport) on this context first");
+    if (ctx->hs[0].busy || ctx->hs[1].busy)   // (slot 0's gather buffers are this entry's too)
+        return umx_internal_fail(ctx, UMX_ERR_INVALID, "a submitted call is still in flight on this context: wait for it first");
     S_HIP(ctx, hipSetDevice(umx_internal_device(ctx)));
     RunIO io;
     io.band_f64 = band_dev;
