@@ -17,6 +17,6 @@ if line is None:
     print("%-28s FAILED" % sys.argv[2]); sys.exit(0)
 j = json.loads(line)
 r = j.get("roofline") or {}
-print("%-28s %9.1f tiles/s %8.3f ms/step  dom %s frac %.4f  checksum %.9f" % (sys.argv[2], j["value"], j["ms_per_step"], r.get("kernel"), r.get("frac", 0), j["config"].get("checksum", 0)))
+print("%-28s %9.1f tiles/s %8.3f ms/step  dom %s frac %.4f  checksum %s" % (sys.argv[2], j["value"], j["ms_per_step"], r.get("kernel"), r.get("frac", 0), j["config"].get("checksum")))
 PY
 done < $2

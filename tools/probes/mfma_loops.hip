@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -201,6 +202,96 @@ __global__ void __launch_bounds__(256, 2) k_wino_split(const _Float16* src, floa
     if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = s1.c0 - s0.c0; clk[1] = s1.r0 - s0.r0; }
 }
 
+// ---- the same trip inside conv_f16x3's STAGE structure, nothing else of the kernel (no prologue index arithmetic, no epilogue,
+// no tile loop): per k-step one s_waitcnt vmcnt(0) + barrier, the next k-step's weight block (9 N-tiles x (hi, lo) x 1 KiB = 18 KiB per
+// workgroup) streamed from a global slab into the other of two LDS weight buffers by LDS-DMA, one 1-KiB piece per N-tile iteration and
+// wave like wq_one(), and every 3rd k-step a halo chunk (13 pieces of 1 KiB: the bytes per k-step of a 3-octet chunk of 324 pixels x
+// (hi, lo) every 7 k-steps) into one of two halo slots -- 71 KiB of LDS, two workgroups per CU like the 80 000-byte production plans.  Workgroups that share an N-block walk the same slab (L2 hits, as in a layer); halo chunks are private (HBM / Infinity Cache).
+// The weight fragments the MFMAs consume are read from the buffer the previous k-step filled; the pixel fragments from a static
+// region.  What it prices: the steady state of the production pipeline against the bare trip above.
+__global__ void __launch_bounds__(256, 2) k_conv9_staged(const _Float16* src, const uint4* wslab, const uint4* act, size_t act_units,
+                                                         float* out, long long* clk, int iters) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 lds[];
+    constexpr int kStatic = 8 * 1024, kWbuf = 64 + 9 * 2048, kHalo = 13 * 1024;   // bytes
+    unsigned char* const base8 = reinterpret_cast<unsigned char*>(lds);
+    for (int i = threadIdx.x; i < kStatic / 16; i += blockDim.x) reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(src)[i + blockIdx.x % 7 * 64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char* const wb = base8 + kStatic;
+    unsigned char* const hb = wb + 2 * kWbuf;
+    constexpr int kSteps = 81;                                   // k-steps of one pass over the slab (ld4.conv / lu3.conv have 81)
+    const uint4* const wsrc = wslab + (size_t)(blockIdx.x & 3) * kSteps * (9 * 2048 / 16);   // this workgroup's N-block
+    const uint4* const asrc = act + ((size_t)blockIdx.x * 97 * 31 * 64) % (act_units - (size_t)31 * 64 * 16);
+    f32x4 acc[4][9];
+    for (int m = 0; m < 4; ++m) for (int n = 0; n < 9; ++n) acc[m][n] = (f32x4){0, 0, 0, 0};
+#define GLDS16(g, l) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g), (__attribute__((address_space(3))) void*)(l), 16, 0, 0)
+    auto wpiece = [&](int step, int buf, int c) {                // the wave's c-th 1-KiB piece of k-step `step`'s block
+        const int pc = wave + 4 * c;
+        if (pc < 18) GLDS16(wsrc + ((size_t)(step % kSteps) * 18 + pc) * 64 + lane, wb + buf * kWbuf + 64 + pc * 1024);
+    };
+    for (int c = 0; c < 5; ++c) wpiece(0, 0, c);
+    __syncthreads();
+    const Stamp s0 = stamp();
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (it % 3 == 0)                                         // a halo chunk into the slot the previous chunk's k-steps have left
+            for (int j = wave; j < 13; j += 4) GLDS16(asrc + ((size_t)(it / 3 % 32) * 13 + j) * 64 + lane, hb + ((it / 3) & 1) * kHalo + j * 1024);
+        const unsigned char* const wl = wb + (it & 1) * kWbuf + 64 + lane * 16;
+        const _Float16* abase = lds + ((it * 3 + wave) & 3) * 512 + lane * 8;
+        h8 ah[4], al[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            ah[m] = *reinterpret_cast<const h8*>(abase + (2 * m % 4) * 512);
+            al[m] = *reinterpret_cast<const h8*>(abase + ((2 * m + 1) % 4) * 512);
+        }
+#pragma unroll
+        for (int n = 0; n < 9; ++n) {
+            if (n < 5) wpiece(it + 1, (it + 1) & 1, n);
+            __builtin_amdgcn_iglp_opt(0);
+            const h8 bh = *reinterpret_cast<const h8*>(wl + n * 2048);
+            const h8 bl = *reinterpret_cast<const h8*>(wl + n * 2048 + 1024);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                f32x4 c = acc[m][n];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[m], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[m], c, 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[m], c, 0, 0, 0);
+            }
+        }
+    }
+    const Stamp s1 = stamp();
+#undef GLDS16
+    float s = 0;
+    for (int m = 0; m < 4; ++m) for (int n = 0; n < 9; ++n) s += acc[m][n][0] + acc[m][n][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = s1.c0 - s0.c0; clk[1] = s1.r0 - s0.r0; }
+}
+
+static void run_staged(int wgs_per_cu, int iters, const _Float16* src, const uint4* wslab, const uint4* act, size_t act_units, float* out,
+                       long long* clk) {
+    const int grid = 256 * wgs_per_cu;
+    const int lds = 8 * 1024 + 2 * (64 + 9 * 2048) + 2 * 13 * 1024;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv9_staged), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    float ms = 0;
+    hipEventRecord(e0);
+    do {
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k_conv9_staged, dim3(grid), dim3(256), lds, 0, src, wslab, act, act_units, out, clk, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    } while (ms < 2000.f);
+    const int reps = 50;
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_conv9_staged, dim3(grid), dim3(256), lds, 0, src, wslab, act, act_units, out, clk, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+    long long c[2];
+    hipMemcpy(c, clk, sizeof c, hipMemcpyDeviceToHost);
+    const double mfmas = (double)grid * 4 * iters * 108.0;
+    const double tflops = mfmas * 2.0 * 16 * 16 * 32 * reps / (ms * 1e-3) / 1e12;
+    printf("%-28s %d WG/CU  %8.3f ms/launch  %8.1f TFLOP/s issued  wave cycles per MFMA %6.2f  in-kernel clock %.2f GHz\n",
+           "conv_f16x3<9,4,1> stage loop", wgs_per_cu, ms / reps, tflops, (double)c[0] / ((double)iters * 108.0), (double)c[0] / (double)c[1] * 0.1);
+}
+
 template <typename K>
 static void run(const char* name, K kern, int wgs_per_cu, int iters, double mfma_per_trip_per_wave, double flop_per_mfma,
                 const _Float16* src, float* out, long long* clk) {
@@ -246,6 +337,16 @@ int main() {
         run("conv_f16x3<9,4,1>-shaped", k_conv9, wgs, iters / 4, 108, 2.0 * 16 * 16 * 32, src, out, clk);
         run("winograd F(2x2,3x3)-shaped", k_wino, wgs, iters / 4, 96, 2.0 * 16 * 16 * 32, src, out, clk);
         run("winograd, positions per wave", k_wino_split, wgs, iters / 4, 96, 2.0 * 16 * 16 * 32, src, out, clk);
+    }
+    {   // the stage-loop skeleton: weight slab of 4 N-blocks x 81 k-steps x 18 KiB (5.8 MB, random binary16), 256 MB of halo source
+        const size_t wunits = (size_t)4 * 81 * 18 * 64, aunits = (size_t)256 * 1024 * 1024 / 16;
+        std::vector<_Float16> hw(wunits * 8);
+        for (auto& v : hw) v = (_Float16)((rand() / (float)RAND_MAX) * 2.f - 1.f);
+        uint4 *wslab, *act;
+        hipMalloc(&wslab, wunits * 16); hipMalloc(&act, aunits * 16);
+        hipMemcpy(wslab, hw.data(), wunits * 16, hipMemcpyHostToDevice);
+        for (size_t o = 0; o < aunits * 16; o += wunits * 16) hipMemcpy((char*)act + o, hw.data(), std::min(wunits * 16, aunits * 16 - o), hipMemcpyHostToDevice);
+        for (int wgs = 1; wgs <= 2; ++wgs) run_staged(wgs, 81 * 12, src, wslab, act, aunits, out, clk);
     }
     return 0;
 }
