@@ -182,9 +182,9 @@ def train(hp_dict: dict, imPath, validPath, testPath, logPath, modelPath, pmPath
     perm = np.arange(nTrain)
     np.random.shuffle(perm)
     Train, LTrain, WTrain = load_split(imPath, nTrain, perm, hp, rec)
-    permV = np.arange(nValid)
-    np.random.shuffle(permV)
-    Valid, LValid, WValid = load_split(validPath, nValid, permV, hp, rec)
+    valid_order = np.arange(nValid)
+    np.random.shuffle(valid_order)
+    Valid, LValid, WValid = load_split(validPath, nValid, valid_order, hp, rec)
     Test, LTest, _ = load_split(testPath, nTest, np.arange(nTest), hp, rec)
 
     opts = rec.options()
@@ -200,64 +200,66 @@ def train(hp_dict: dict, imPath, validPath, testPath, logPath, modelPath, pmPath
     train_log = _Scalars(os.path.join(logPath, "Train"), K)
     valid_log = _Scalars(os.path.join(logPath, "Valid"), K)
 
-    batchData = np.zeros((B, P, P, C))
-    batchLabels = np.zeros((B, P, P, K))
-    batchWeights = np.zeros((B, P, P, K))
-    permT = np.arange(nTrain)
-    np.random.shuffle(permT)
-    permV = np.arange(nValid)
-    np.random.shuffle(permV)
-    maxBrig = 1 * rec.dataset_stdev
-    maxCont = 0.1 * rec.dataset_stdev
+    x_batch = np.zeros((B, P, P, C))
+    y_batch = np.zeros((B, P, P, K))
+    w_batch = np.zeros((B, P, P, K))
+    train_order = np.arange(nTrain)
+    np.random.shuffle(train_order)
+    valid_order = np.arange(nValid)
+    np.random.shuffle(valid_order)
+    brightness_span = 1 * rec.dataset_stdev
+    contrast_span = 0.1 * rec.dataset_stdev
     jT = jV = 0
-    epochCounter = 1
-    lowestError = np.inf
+    epoch = 1
+    best_error = np.inf
     history = []
     saved = False
     try:
         for i in range(nSteps):
             for j in range(B):
-                fBrig = maxBrig * np.float_power(-1, np.random.rand() < 0.5) * np.random.rand()
-                fCont = 1 + maxCont * np.float_power(-1, np.random.rand() < 0.5) * np.random.rand()
+                # (brightness shift and contrast gain of one image: a random sign times a uniform fraction of the span,
+                # the reference's augmentation UnMicst1-5.py:472-475)
+                shift = (-1.0 if np.random.rand() < 0.5 else 1.0) * brightness_span * np.random.rand()
+                gain = 1.0 + (-1.0 if np.random.rand() < 0.5 else 1.0) * contrast_span * np.random.rand()
                 if rec.all_channels:
                     for c in range(C):
-                        batchData[j, :, :, c] = Train[permT[jT + j], :, :, math.floor(A * np.random.rand()), c] * fCont + fBrig
+                        x_batch[j, :, :, c] = Train[train_order[jT + j], :, :, math.floor(A * np.random.rand()), c] * gain + shift
                 else:
-                    batchData[j] = Train[permT[jT + j], :, :, 0, :] * fCont + fBrig
-                batchLabels[j] = LTrain[permT[jT + j]]
-                batchWeights[j] = WTrain[permT[jT + j]]
+                    x_batch[j] = Train[train_order[jT + j], :, :, 0, :] * gain + shift
+                y_batch[j] = LTrain[train_order[jT + j]]
+                w_batch[j] = WTrain[train_order[jT + j]]
             lr = opts.lr0 * opts.decay_rate ** (tr.step_count // opts.decay_steps)
-            loss = tr.step(batchData, batchLabels, batchWeights)[0]
+            loss = tr.step(x_batch, y_batch, w_batch)[0]
             jT += B
             if jT > (nTrain - B - 1):
                 jT = 0
-                np.random.shuffle(permT)
-                epochCounter += 1
+                np.random.shuffle(train_order)
+                epoch += 1
             if i % rec.summary_every == 0:
-                train_log.add(i, loss, pixel_errors(tr.probs(), batchLabels), lr)
+                train_log.add(i, loss, pixel_errors(tr.probs(), y_batch), lr)
 
             for j in range(B):
                 if rec.valid_channel0_only:
-                    batchData[j] = 0
-                    batchData[j, :, :, 0] = Valid[permV[jV + j], :, :, math.floor(A * np.random.rand()), 0]
+                    x_batch[j] = 0
+                    x_batch[j, :, :, 0] = Valid[valid_order[jV + j], :, :, math.floor(A * np.random.rand()), 0]
                 else:
-                    batchData[j] = Valid[permV[jV + j], :, :, 0, :]
-                batchLabels[j] = LValid[permV[jV + j]]
-                batchWeights[j] = WValid[permV[jV + j]]
-            es = pixel_errors(tr.eval(batchData), batchLabels)
+                    x_batch[j] = Valid[valid_order[jV + j], :, :, 0, :]
+                y_batch[j] = LValid[valid_order[jV + j]]
+                w_batch[j] = WValid[valid_order[jV + j]]
+            es = pixel_errors(tr.eval(x_batch), y_batch)
             jV += B
             if jV > (nValid - B - 1):
                 jV = 0
-                np.random.shuffle(permV)
+                np.random.shuffle(valid_order)
             if i % rec.summary_every == 0:
                 valid_log.add(i, float("nan"), es, lr)
             e = float(np.mean(es))
-            print("step %05d, e: %f" % (i, e) + ", epoch: " + str(epochCounter))
+            print("step %05d, e: %f" % (i, e) + ", epoch: " + str(epoch))
             history.append((loss, e))
             if i == 0:
-                lowestError = e if restoreVariables else np.inf
-            if i % 50 == 0 and e < lowestError:
-                lowestError = e
+                best_error = e if restoreVariables else np.inf
+            if i % 50 == 0 and e < best_error:
+                best_error = e
                 out = model.save_converted(model.ModelArtefacts(hp, tr.blob(), rec.dataset_mean, rec.dataset_stdev), modelPath)
                 saved = True
                 print("Model saved in file: %s" % out)
@@ -278,17 +280,17 @@ def train(hp_dict: dict, imPath, validPath, testPath, logPath, modelPath, pmPath
                 for i in range(nTest):
                     j = i % B
                     if rec.valid_channel0_only:
-                        batchData[j] = 0
-                        batchData[j, :, :, 0] = Test[i, :, :, a, 0]
+                        x_batch[j] = 0
+                        x_batch[j, :, :, 0] = Test[i, :, :, a, 0]
                     else:
-                        batchData[j] = Test[i, :, :, 0, :]
-                    batchLabels[j] = LTest[i]
+                        x_batch[j] = Test[i, :, :, 0, :]
+                    y_batch[j] = LTest[i]
                     if j == B - 1 or i == nTest - 1:
-                        output = te.eval(batchData)
+                        output = te.eval(x_batch)
                         for k in range(j + 1):
-                            im = np.sqrt(normalize(batchData[k, :, :, 0]))
+                            im = np.sqrt(normalize(x_batch[k, :, :, 0]))
                             for cls, tag in ((2, "Nuc"), (1, "Con")):
-                                pane = np.concatenate((im, np.concatenate((output[k, :, :, cls], batchLabels[k, :, :, cls]), axis=1)), axis=1)
+                                pane = np.concatenate((im, np.concatenate((output[k, :, :, cls], y_batch[k, :, :, cls]), axis=1)), axis=1)
                                 name = ("I%05d_%d_%s.png" % (i - j + k + 1, a, tag)) if rec.png_aug_suffix else \
                                     ("I%05d%s.png" % (i - j + k + 1, tag))
                                 png_write(os.path.join(pmPath, name), np.uint8(255 * pane))
@@ -315,16 +317,16 @@ def deploy(imPath, nImages, modelPath, pmPath, gpuIndex, pmIndex, engine_factory
     eng = make(hp, art.blob, max(int(gpuIndex), 0), B)
     print("Model restored.")
     os.makedirs(pmPath, exist_ok=True)
-    batchData = np.zeros((B, P, P, C))
+    x_batch = np.zeros((B, P, P, C))
     try:
         for i in range(nImages):
             print(i, nImages)
             j = i % B
-            batchData[j] = Data[i]
+            x_batch[j] = Data[i]
             if j == B - 1 or i == nImages - 1:
-                output = eng.forward_tiles(batchData[:j + 1].astype(np.float32))
+                output = eng.forward_tiles(x_batch[:j + 1].astype(np.float32))
                 for k in range(j + 1):
-                    im = np.sqrt(normalize(batchData[k, :, :, 0]))
+                    im = np.sqrt(normalize(x_batch[k, :, :, 0]))
                     png_write("%s/I%05d_Im.png" % (pmPath, i - j + k + 1), np.uint8(255 * im))
                     png_write("%s/I%05d_PM.png" % (pmPath, i - j + k + 1), np.uint8(255 * output[k, :, :, pmIndex]))
     finally:
