@@ -270,8 +270,9 @@ dist.destroy_process_group()
 def test_native_sharded_entry_point_world_of_one():
     """umx_infer_image_sharded_dev (RCCL inside libumx: communicator from umx_shard_unique_id / umx_shard_init, band tiles,
     slab-wise ncclAllGather on the library's communication stream) in a world of one rank, 1 and 3 slabs, fp16-compat and
-    fp32 stitch: bit-equal to umx_infer_image.  (Its band geometry is checked against the torch.distributed schedule on
-    CPU, tests/test_sharding_cpu.py; RCCL refuses two ranks on one device, so worlds > 1 are the driver's 8-GPU run.)"""
+    fp32 stitch: bit-equal to umx_infer_image; then umx_infer_image_sharded_raw[_submit] over the same communicator.  (The band
+    geometry is checked against the torch.distributed schedule on CPU, tests/test_sharding_cpu.py; RCCL refuses two ranks on one
+    device, so worlds > 1 are the driver's 8-GPU run.)"""
     import subprocess
     import sys
     script = r'''
@@ -294,6 +295,33 @@ with umx.Engine(hp, blob, max_batch=8) as eng:
                                         out.data_ptr())
             eng.synchronize()
             assert np.array_equal(out.cpu().numpy().view(np.uint8), want.view(np.uint8)), (stitch, nslabs)
+    # the raw entry over the same RCCL communicator (ncclAllGather of the uint8 slabs in a world of one), synchronous and two slides in
+    # flight, with and without the drivers' rescale: byte for byte umx_infer_image_raw[_range]
+    K = hp.nClasses
+    raw = (np.random.default_rng(3).random((2, H, W)) * 60000).astype(np.uint16)
+    for rescale in (False, True):
+        rng = [(int(raw[c].min()), int(raw[c].max())) for c in range(2)] if rescale else None
+        want = eng.infer_image_raw(raw, rescale, 0.2, 0.2, value_range=rng)
+        for nslabs in (1, 3):
+            full = torch.zeros((K, H, W), dtype=torch.uint8, device="cuda")
+            own = eng.infer_image_sharded_raw(raw, H, W, 0, rng, 0.2, 0.2, nslabs=nslabs, own_rows=H, out_full_ptr=full.data_ptr())
+            assert np.array_equal(own, want) and np.array_equal(full.cpu().numpy(), want), (rescale, nslabs)
+        owns = [np.zeros((K, H, W), np.uint8) for _ in range(2)]
+        for slot in (0, 1):
+            eng.infer_image_sharded_raw_submit(slot, raw.ctypes.data, 16, 2, H, W, 0, H, rng, 0.2, 0.2, umx.MODE_ACCUMULATE, 2,
+                                               owns[slot].ctypes.data, 0)          # (gathered stack into the library's own buffer)
+        eng.infer_image_wait(0); eng.infer_image_wait(1)
+        assert np.array_equal(owns[0], want) and np.array_equal(owns[1], want), rescale
+    try:                                                # the device entry refuses to run under a submitted call
+        eng.infer_image_sharded_raw_submit(0, raw.ctypes.data, 16, 2, H, W, 0, H, None, 0.2, 0.2, umx.MODE_ACCUMULATE, 2, owns[0].ctypes.data, 0)
+        refused = False
+        try:
+            eng.infer_image_sharded_dev(band.data_ptr(), 2, H, W, 0, H, 0.2, 0.2, umx.MODE_ACCUMULATE, umx.STITCH_FP16_COMPAT, 1, out.data_ptr())
+        except umx.UmxError:
+            refused = True
+        assert refused
+    finally:
+        eng.infer_image_wait(0)
 print("native sharded ok")
 ''' % (helpers.ROOT, helpers.ROOT)
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
