@@ -760,9 +760,18 @@ int umx_band_tiles_dev(umx_ctx* ctx, const double* image_dev, int C_img, int H, 
 int umx_stitch_dev(umx_ctx* ctx, const float* probs_dev, int tpr0, int tpr1, int H, int W, int mode, int stitch, int y0,
                    int y1, void* out_dev) {
     if (!ctx) return fail(nullptr, UMX_ERR_INVALID, "ctx is NULL");
+    if (stitch != UMX_STITCH_FP16_COMPAT && stitch != UMX_STITCH_FP32) return fail(ctx, UMX_ERR_INVALID, "bad stitch %d", stitch);
+    return umx::stitch_rows(ctx, probs_dev, tpr0, tpr1, H, W, mode, stitch, y0, y1, out_dev, 0);
+}
+
+}  // extern "C"
+
+namespace umx {
+// (umx_stitch_dev + the internal forms: stitch = kStitchU8 writes the drivers' uint8 planes, plane_rows > 0 a padded destination)
+int stitch_rows(umx_ctx* ctx, const float* probs_dev, int tpr0, int tpr1, int H, int W, int mode, int stitch, int y0, int y1,
+                void* out_dev, int plane_rows) {
     if (!probs_dev || !out_dev || H < 1 || W < 1) return fail(ctx, UMX_ERR_INVALID, "bad probs/out/H/W");
     if (mode != UMX_MODE_ACCUMULATE && mode != UMX_MODE_REPLACE) return fail(ctx, UMX_ERR_INVALID, "bad mode %d", mode);
-    if (stitch != UMX_STITCH_FP16_COMPAT && stitch != UMX_STITCH_FP32) return fail(ctx, UMX_ERR_INVALID, "bad stitch %d", stitch);
     const TileGeom g = geom_of(ctx->hp, H, W);
     if (y0 < 0 || y1 > H || y0 > y1) return fail(ctx, UMX_ERR_INVALID, "rows [%d,%d) outside the image", y0, y1);
     if (y0 == y1) return UMX_OK;
@@ -777,10 +786,13 @@ int umx_stitch_dev(umx_ctx* ctx, const float* probs_dev, int tpr0, int tpr1, int
     if (ctx->site_stitch < 0) ctx->site_stitch = site_of(ctx, "pi2d.stitch", "stitch");
     const int K = ctx->hp.nClasses;
     ProfScope ps(ctx, ctx->site_stitch, 0.0,
-                 (double)(y1 - y0) * W * K * (4.0 * ((double)g.P / g.sub) * ((double)g.P / g.sub) + (stitch == 0 ? 2.0 : 4.0)));
-    HIP_TRY(ctx, launch_stitch(probs_dev, tpr0, tpr1, g, K, mode, stitch, y0, y1, out_dev, ctx->stream));
+                 (double)(y1 - y0) * W * K * (4.0 * ((double)g.P / g.sub) * ((double)g.P / g.sub) + (stitch == 0 ? 2.0 : stitch == kStitchU8 ? 1.0 : 4.0)));
+    HIP_TRY(ctx, launch_stitch(probs_dev, tpr0, tpr1, g, K, mode, stitch, y0, y1, out_dev, ctx->stream, plane_rows));
     return UMX_OK;
 }
+}  // namespace umx
+
+extern "C" {
 
 int umx_infer_image_dev(umx_ctx* ctx, const double* image_dev, int C_img, int H, int W, double mean, double stdv,
                         int mode, int stitch, void* out_dev) {

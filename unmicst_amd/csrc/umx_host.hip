@@ -228,8 +228,10 @@ static int host_submit_impl(umx_ctx* ctx, int slot, bool sync_call, const void* 
             // the stitch writes a compact slab [K][rows][W]; slabs sit one after the other in the device buffer
             const size_t rows = (size_t)(y1 - y_done), slab_e = K * (size_t)y_done * W;
             unsigned char* const d_slab = base + slab_e * oel;
-            if ((rc = umx_stitch_dev(ctx, hs.d_probs, 0, cut[s + 1], H, W, mode, stitch, y_done, y1, d_slab))) return rc;
-            if (out_u8) HIP_TRY(ctx, launch_half_to_u8(d_slab, K * rows * W, base + pm_b + slab_e, ctx->stream));
+            // (uint8 out: the cast rides in the stitch -- no float16 slab is written and read back)
+            if ((rc = stitch_rows(ctx, hs.d_probs, 0, cut[s + 1], H, W, mode, out_u8 ? kStitchU8 : stitch, y_done, y1,
+                                  out_u8 ? (void*)(base + pm_b + slab_e) : (void*)d_slab, 0)))
+                return rc;
             if (!single) {
                 HIP_TRY(ctx, hipEventRecord(ev_dn[s], ctx->stream));
                 HIP_TRY(ctx, hipStreamWaitEvent(ctx->dn_stream, ev_dn[s], 0));

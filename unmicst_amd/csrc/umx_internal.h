@@ -276,6 +276,9 @@ inline _Float16* hi_of(const Buffer& b) { return reinterpret_cast<_Float16*>(b.d
 inline _Float16* lo_of(const Buffer& b, int n) { return reinterpret_cast<_Float16*>(b.d) + (size_t)n * b.S * b.S * b.Cs; }
 
 int check_range_flag(umx_ctx* ctx);   // call with the stream idle
+// umx_stitch_dev's body with the internal forms: stitch = kStitchU8 (uint8 planes), plane_rows > 0 (rows per class plane of `out_dev`)
+int stitch_rows(umx_ctx* ctx, const float* probs_dev, int tpr0, int tpr1, int H, int W, int mode, int stitch, int y0, int y1,
+                void* out_dev, int plane_rows);
 TileGeom geom_of(const umx_hparams& hp, int H, int W);
 // tiles [t0, t1) of the slide (row-major tile index) -> probs_dev (tile t0 first): gather + normalise + UNet
 // (raw_dev / raw_bits: the same planes as raw uint8 / uint16 values, for an engine that gathers from them -- gathers_raw())

@@ -194,8 +194,9 @@ hipError_t launch_gather_normalise(const double* image, int C_img, int band_row0
 hipError_t launch_head_softmax(const float* x, size_t npix, int C, int K, const float* w /*[C][K]*/,
                                const float* scale, const float* bias, float* probs, hipStream_t stream);
 
+constexpr int kStitchU8 = 2;   // (internal; beside UMX_STITCH_FP16_COMPAT = 0 / UMX_STITCH_FP32 = 1) the fp16-compat result as the drivers' uint8
 hipError_t launch_stitch(const float* probs, int tpr0, int tpr1, const TileGeom& g, int K, int mode, int stitch,
-                         int y0, int y1, void* out, hipStream_t stream);
+                         int y0, int y1, void* out, hipStream_t stream, int plane_rows = 0 /* rows per class plane of `out`; 0: y1 - y0 */);
 
 // driver-side pre/post-processing at scalingFactor 1 (raw integer planes in, uint8 probability planes out)
 hipError_t launch_raw_to_double(const void* raw, int bits, size_t n, int rescale, unsigned* mm /*2 words*/, double* out,

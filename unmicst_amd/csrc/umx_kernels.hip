@@ -475,11 +475,23 @@ __device__ __forceinline__ uint16_t d2h_rne(double d) {
     return __half_as_ushort(__float2half_rn(f));
 }
 
+// the drivers' uint8 cast of one float16 probability (reference UnMicst1-5.py:848-854 at the identity grid; the same IEEE operations
+// as half_to_u8_kernel below, one rounding each): np.uint8(255 * pm) in float16, resize = u8 * (1 / 255) in float64, np.uint8(255 * .)
+__device__ __forceinline__ unsigned char u8_of_half(__half pm) {
+    const __half p255 = __hmul(__float2half_rn(255.f), pm);
+    const unsigned char first = (unsigned char)(int)__half2float(p255);
+    const double f = (double)first * (1.0 / 255);
+    return (unsigned char)(int)(255.0 * f);
+}
+
+// stitch: 0 = float16 planes (the reference's accumulators), 1 = float32, 2 = the float16 result cast to the drivers' uint8 on the way
+// out (the raw entry points: no float16 plane is written and read back).  plane_rows: rows per class plane of the destination
+// (>= y1 - y0: the sharded schedule writes straight into its padded gather buffer).
 template <int K>
 __global__ void __launch_bounds__(256) stitch_kernel(const float* __restrict__ probs, int tpr0, int tpr1, TileGeom g,
-                                                    int mode, int stitch, int y0, int y1, void* __restrict__ out) {
-    const int rows = y1 - y0;
-    const size_t total = (size_t)rows * g.W;
+                                                    int mode, int stitch, int y0, int y1, int plane_rows, void* __restrict__ out) {
+    const int rows = plane_rows;
+    const size_t total = (size_t)(y1 - y0) * g.W;
     const int two_m = 2 * g.margin;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(e % g.W);
@@ -503,12 +515,13 @@ __global__ void __launch_bounds__(256) stitch_kernel(const float* __restrict__ p
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 if (stitch == 0) ((__half*)out)[((size_t)k * rows + (y - y0)) * g.W + x] = __float2half_rn(pp[k]);
+                else if (stitch == 2) ((unsigned char*)out)[((size_t)k * rows + (y - y0)) * g.W + x] = u8_of_half(__float2half_rn(pp[k]));
                 else ((float*)out)[((size_t)k * rows + (y - y0)) * g.W + x] = pp[k];
             }
             continue;
         }
 
-        if (stitch == 0) {
+        if (stitch != 1) {
             uint16_t cnt = 0;
             uint16_t o[K];
 #pragma unroll
@@ -527,7 +540,8 @@ __global__ void __launch_bounds__(256) stitch_kernel(const float* __restrict__ p
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const float q = __half2float(__ushort_as_half(o[k])) / cf;   // IEEE float32 division
-                ((__half*)out)[((size_t)k * rows + (y - y0)) * g.W + x] = __float2half_rn(q);
+                if (stitch == 2) ((unsigned char*)out)[((size_t)k * rows + (y - y0)) * g.W + x] = u8_of_half(__float2half_rn(q));
+                else ((__half*)out)[((size_t)k * rows + (y - y0)) * g.W + x] = __float2half_rn(q);
             }
         } else {
             double cnt = 0.0;
@@ -550,14 +564,16 @@ __global__ void __launch_bounds__(256) stitch_kernel(const float* __restrict__ p
 }
 
 hipError_t launch_stitch(const float* probs, int tpr0, int tpr1, const TileGeom& g, int K, int mode, int stitch,
-                         int y0, int y1, void* out, hipStream_t stream) {
+                         int y0, int y1, void* out, hipStream_t stream, int plane_rows) {
     if (y1 <= y0) return hipSuccess;
+    if (plane_rows <= 0) plane_rows = y1 - y0;
+    if (plane_rows < y1 - y0) return hipErrorInvalidValue;
     const size_t total = (size_t)(y1 - y0) * g.W;
     const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 256 * 16);
     switch (K) {
-        case 2: hipLaunchKernelGGL(stitch_kernel<2>, dim3(blocks), dim3(256), 0, stream, probs, tpr0, tpr1, g, mode, stitch, y0, y1, out); break;
-        case 3: hipLaunchKernelGGL(stitch_kernel<3>, dim3(blocks), dim3(256), 0, stream, probs, tpr0, tpr1, g, mode, stitch, y0, y1, out); break;
-        case 4: hipLaunchKernelGGL(stitch_kernel<4>, dim3(blocks), dim3(256), 0, stream, probs, tpr0, tpr1, g, mode, stitch, y0, y1, out); break;
+        case 2: hipLaunchKernelGGL(stitch_kernel<2>, dim3(blocks), dim3(256), 0, stream, probs, tpr0, tpr1, g, mode, stitch, y0, y1, plane_rows, out); break;
+        case 3: hipLaunchKernelGGL(stitch_kernel<3>, dim3(blocks), dim3(256), 0, stream, probs, tpr0, tpr1, g, mode, stitch, y0, y1, plane_rows, out); break;
+        case 4: hipLaunchKernelGGL(stitch_kernel<4>, dim3(blocks), dim3(256), 0, stream, probs, tpr0, tpr1, g, mode, stitch, y0, y1, plane_rows, out); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -90,7 +90,7 @@ struct Shard {
     int rank = 0, world = 1;
     hipStream_t comm_stream = nullptr;
     std::vector<hipEvent_t> events[2];   // per call slot (the raw entry keeps two slides in flight; the device entry uses slot 0)
-    Buf probs, slab;                     // written and read in the order of the context's stream only
+    Buf probs;                           // written and read in the order of the context's stream only
     Buf gathered[2], full_u8[2];         // per slot: the communication stream of slide i may still read them under slide i+1's tiles
     std::vector<Buf> send[2];
 };
@@ -124,7 +124,7 @@ void release(Shard& s) {
     if (s.comm && rccl()->CommDestroy) rccl()->CommDestroy(s.comm);
     if (s.comm_stream) hipStreamDestroy(s.comm_stream);
     for (auto& ev : s.events) for (auto e : ev) hipEventDestroy(e);
-    for (Buf* b : {&s.probs, &s.slab, &s.gathered[0], &s.gathered[1], &s.full_u8[0], &s.full_u8[1]}) if (b->d) hipFree(b->d);
+    for (Buf* b : {&s.probs, &s.gathered[0], &s.gathered[1], &s.full_u8[0], &s.full_u8[1]}) if (b->d) hipFree(b->d);
     for (auto& v : s.send) for (auto& b : v) if (b.d) hipFree(b.d);
 }
 
@@ -430,19 +430,17 @@ int sharded_run(umx_ctx* ctx, Shard& s, const RunIO& io, int C_img, int H, int W
     if ((int)send.size() < n) send.resize(n);
     int own0 = 0, own1 = 0;
     umx_geom::owned(pa, pb, npr, sub, margin, H, &own0, &own1);
-    {   // size the slab / gather buffers for the largest slab up front (no reallocation between enqueued operations)
-        int mx_all = 1, own_max = 1;
+    {   // size the gather buffers for the largest slab up front (no reallocation between enqueued operations: a grow() in the slab loop
+        // would synchronise the device and free memory between enqueued collectives when a later slide is larger).  The stitch writes
+        // straight into the padded send buffer [K][mx][W]; the padded tails stay uninitialised: the scatter never reads them.
+        int mx_all = 1;
         for (int i = 0; i < n; ++i)
             for (int q = 0; q < world; ++q) {
                 int a, b;
                 umx_geom::slab(A[q], B[q], npr, sub, margin, H, n, i, &a, &b);
                 mx_all = std::max(mx_all, b - a);
-                if (q == rank) own_max = std::max(own_max, b - a);
             }
         if ((rc = grow(ctx, &gathered, (size_t)world * K * mx_all * W * el))) return rc;
-        if ((rc = grow(ctx, &s.slab, (size_t)K * own_max * W * sel))) return rc;
-        // the send buffers too: a grow() in the slab loop would synchronise the device and free memory between enqueued
-        // collectives when a later slide is larger.  (Their padded tails stay uninitialised: the scatter never reads them.)
         for (int i = 0; i < n; ++i)
             if ((rc = grow(ctx, &send[i], (size_t)K * mx_all * W * el))) return rc;
     }
@@ -464,17 +462,8 @@ int sharded_run(umx_ctx* ctx, Shard& s, const RunIO& io, int C_img, int H, int W
             mx = std::max(mx, rb[q] - ra[q]);
         }
         const size_t plane_b = (size_t)mx * W * el, send_b = (size_t)K * plane_b;
-        if (s1 > s0) {
-            if ((rc = umx_stitch_dev(ctx, probs, lo, pb, H, W, mode, stitch, s0, s1, s.slab.d))) return rc;
-            for (int k = 0; k < K; ++k) {   // compact [K][rows][W] -> padded [K][mx][W]
-                const size_t rows_e = (size_t)(s1 - s0) * W;
-                if (io.u8)   // the drivers' cast on the way: np.uint8(255 * pm), identity resize, np.uint8(255 * .)
-                    S_HIP(ctx, umx::launch_half_to_u8((char*)s.slab.d + k * rows_e * sel, rows_e, (unsigned char*)send[i].d + k * plane_b, cs));
-                else
-                    S_HIP(ctx, hipMemcpyAsync((char*)send[i].d + k * plane_b, (char*)s.slab.d + k * rows_e * sel, rows_e * sel,
-                                              hipMemcpyDeviceToDevice, cs));
-            }
-        }
+        // straight into the padded gather buffer [K][mx][W] (uint8 path: the drivers' cast rides in the stitch)
+        if (s1 > s0 && (rc = umx::stitch_rows(ctx, probs, lo, pb, H, W, mode, io.u8 ? umx::kStitchU8 : stitch, s0, s1, send[i].d, mx))) return rc;
         hipEvent_t ev_s = evs[6 + 2 * i];
         S_HIP(ctx, hipEventRecord(ev_s, cs));
         S_HIP(ctx, hipStreamWaitEvent(ms, ev_s, 0));
