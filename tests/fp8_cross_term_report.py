@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Accuracy gate of the FP8 / block-scaled cross-term plan, on the CPU -- no GPU needed.
+
+The split-precision engine evaluates every fp32 product as  x_hi*w_hi + x_hi*w_lo + x_lo*w_hi  on the binary16 matrix pipe
+(3 units of matrix work).  The plan priced here keeps x_hi*w_hi in binary16 and moves the two CROSS terms to
+v_mfma_scale_f32_16x16x128_f8f6f4 (OCP e4m3 elements, one power-of-two e8m0 scale per 32 consecutive K elements of each operand,
+twice the binary16 rate): 1 + 2 * 0.5 = 2 units instead of 3.  This script emulates that arithmetic layer by layer -- activations
+re-split into (hi, lo) binary16 pairs after every layer exactly as the engine stores them, weights pre-scaled by the planner's power of
+two -- and prints max |p - p_oracle| over the softmax outputs for: the exact 3-product plan (calibration: must reproduce the engine's
+~1e-7 .. 3e-6), the 2-product plan of round 2 (calibration: profiles/r02/two_product_probe_report.log measured 5e-5 .. 2.2e-4 on the
+random graphs and 6.6e-3 on the shipped nucleiDAPI weights ON THE GPU), and the FP8 cross-term plan on all layers / on layer subsets.
+
+Lives in tests/ because it checks against the oracle (oracle/ is test infrastructure).  Usage: python tests/fp8_cross_term_report.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import helpers  # noqa: E402
+from oracle import oracle, pi2d_oracle  # noqa: E402
+from unmicst_amd import model  # noqa: E402
+
+BN_EPS = 1e-3
+LEAK = 0.2
+
+
+# ------------------------------------------------------------------------------------------------ number formats
+def f16(x):
+    return x.to(torch.float16).to(torch.float32)
+
+
+def split16(x):
+    hi = f16(x)
+    return hi, f16(x - hi)
+
+
+def q_e4m3(v):
+    """Round-to-nearest-even onto OCP e4m3 (bias 7, 3 mantissa bits, subnormals at 2^-9, max 448, saturating)."""
+    a = v.abs().clamp(max=448.0)
+    e = torch.floor(torch.log2(torch.where(a > 0, a, torch.ones_like(a)))).clamp(min=-6.0)   # exponent of the binade (subnormal: -6)
+    ulp = torch.exp2(e - 3.0)
+    q = torch.round(a / ulp) * ulp            # torch.round = half to even
+    return torch.sign(v) * q.clamp(max=448.0)
+
+
+def mx_e4m3(m, axis):
+    """MX block format along `axis` (K): blocks of 32, shared scale 2^(floor(log2(max|block|)) - 8), elements e4m3."""
+    m = m.movedim(axis, -1)
+    K = m.shape[-1]
+    pad = (-K) % 32
+    mp = F.pad(m, (0, pad))
+    blk = mp.reshape(*mp.shape[:-1], -1, 32)
+    amax = blk.abs().amax(dim=-1, keepdim=True)
+    scale = torch.exp2(torch.floor(torch.log2(torch.where(amax > 0, amax, torch.ones_like(amax)))) - 8.0)
+    deq = q_e4m3(blk / scale) * scale
+    return deq.reshape(*mp.shape)[..., :K].movedim(-1, axis)
+
+
+# ------------------------------------------------------------------------------------------------ the emulated GEMM
+def gemm(A, Wm, plan):
+    """A [M, K] activations (fp32 values as the previous layer produced them), Wm [K, N] weights -> [M, N].
+    plan: 'exact' (float64), 'f16x3', 'f16x2' (x_lo*w_hi dropped: the input rounded to binary16), 'fp8x' (cross terms in MX e4m3)."""
+    if plan == "exact":
+        return (A.double() @ Wm.double()).float()
+    wmax = float(Wm.abs().max())
+    sh = 0.0 if wmax == 0 else 14 - (np.frexp(wmax)[1])          # largest |w| lands in [2^13, 2^14): the planner's weight shift
+    Ws = Wm * (2.0 ** sh)
+    wh, wl = split16(Ws)
+    xh, xl = split16(A)
+    acc = (xh.double() @ wh.double())
+    if plan == "f16x3":
+        acc = acc + xh.double() @ wl.double() + xl.double() @ wh.double()
+    elif plan == "f16x2":
+        acc = acc + xh.double() @ wl.double()
+    elif plan == "fp8x":
+        acc = acc + mx_e4m3(xh, 1).double() @ mx_e4m3(wl, 0).double() + mx_e4m3(xl, 1).double() @ mx_e4m3(wh, 0).double()
+    else:
+        raise ValueError(plan)
+    return (acc * (2.0 ** -sh)).float()
+
+
+def conv_same(x, w_tf, plan):
+    """x NCHW fp32, w_tf [kh, kw, Cin, Cout]; K ordered (tap, channel) like the engine's (tap, octet) pairs."""
+    kh, kw, Ci, Co = w_tf.shape
+    B, _, H, W = x.shape
+    cols = F.unfold(x, (kh, kw), padding=(kh // 2, kw // 2))                 # [B, Ci*kh*kw, H*W], K order (channel, tap)
+    cols = cols.reshape(B, Ci, kh * kw, H * W).permute(0, 3, 2, 1).reshape(B * H * W, kh * kw * Ci)
+    out = gemm(cols, w_tf.reshape(kh * kw * Ci, Co), plan)
+    return out.reshape(B, H, W, Co).permute(0, 3, 1, 2)
+
+
+def conv_transpose_s2(x, wt_tf, plan):
+    """tf.nn.conv2d_transpose, stride 2, SAME (crop (k-2)//2 before): per output phase a GEMM over that phase's taps."""
+    kh, kw, Co, Ci = wt_tf.shape
+    B, _, H, W = x.shape
+    pb = max(kh - 2, 0) // 2
+    out = torch.zeros(B, Co, 2 * H, 2 * W)
+    xp = F.pad(x, (2, 2, 2, 2))
+    for oy in range(2):
+        for ox in range(2):
+            # output (2i+oy, 2j+ox) = sum over taps a with (2i + oy + pb - a) even: input row (2i + oy + pb - a) / 2
+            cols, ws = [], []
+            for a in range(kh):
+                if (oy + pb - a) % 2:
+                    continue
+                dy = (oy + pb - a) // 2
+                for b in range(kw):
+                    if (ox + pb - b) % 2:
+                        continue
+                    dx = (ox + pb - b) // 2
+                    cols.append(xp[:, :, 2 + dy:2 + dy + H, 2 + dx:2 + dx + W])
+                    ws.append(wt_tf[a, b].t())                                   # [Ci, Co]
+            A = torch.stack(cols, 1).permute(0, 3, 4, 1, 2).reshape(B * H * W, len(cols) * Ci)
+            o = gemm(A, torch.cat(ws, 0), plan).reshape(B, H, W, Co).permute(0, 3, 1, 2)
+            out[:, :, oy::2, ox::2] = o
+    return out
+
+
+def bn(x, T, p):
+    g, b, mu, va = (T[p + ".bn." + t] for t in ("gamma", "beta", "mean", "var"))
+    s = g / torch.sqrt(va + BN_EPS)
+    return x * s[None, :, None, None] + (b - mu * s)[None, :, None, None]
+
+
+def forward(hp, T, x_nhwc, plan_of):
+    """plan_of(layer name) -> plan; graph order follows oracle/unet_oracle.c (reference UnMicst1-5.py:83-237 / UnMicst.py:51-187)."""
+    v2 = hp.graph == model.GRAPH_V2
+    act = (lambda t: F.leaky_relu(t, LEAK)) if v2 else F.relu
+    L = hp.nLayers
+    x = x_nhwc.permute(0, 3, 1, 2)
+    ds = [x]
+    for i in range(L):
+        n = "ld%d" % i
+        pl = plan_of(n)
+        c = conv_same(ds[i], T[n + ".w1"], pl)
+        for e in range(hp.nExtraConvs):
+            c = conv_same(act(c), T["%s.wextra%d" % (n, e)], pl)
+        c = c + conv_same(ds[i], T[n + ".wshort"], pl)
+        c = act(bn(c, T, n)) if v2 else bn(act(c), T, n)
+        ds.append(F.max_pool2d(c, 2))
+    cur = conv_same(ds[L], T["lb.w"], plan_of("lb"))
+    cur = act(bn(cur, T, "lb")) if v2 else act(cur)
+    for idx in range(L - 1, -1, -1):
+        n = "lu%d" % idx
+        pl = plan_of(n)
+        us = act(conv_transpose_s2(cur, T[n + ".wt"], pl))
+        cv = conv_same(torch.cat([ds[idx], us], 1), T[n + ".w2"], pl)
+        cv = act(bn(cv, T, n)) if v2 else act(cv)
+        for e in range(hp.nExtraConvs):
+            cv = act(conv_same(cv, T["%s.wextra%d" % (n, e)], pl))
+        cur = cv
+    t = conv_same(cur, T["lt.w"], plan_of("lt"))
+    if v2:
+        t = bn(t, T, "lt")
+    return torch.softmax(t, 1).permute(0, 2, 3, 1)
+
+
+def run_case(name, hp, blob, x, plans):
+    T = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in model.tensors_from_blob(hp, blob).items()}
+    xt = torch.from_numpy(x)
+    ref = oracle.forward(hp, blob, x)
+    row = []
+    for label, plan_of in plans:
+        with torch.no_grad():
+            p = forward(hp, T, xt, plan_of).numpy()
+        row.append(float(np.abs(p - ref).max()))
+    print("%-42s" % name + "".join(" %10.3g" % e for e in row), flush=True)
+    return row
+
+
+def main():
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) - 1))
+    deep = {"ld2", "ld3", "ld4", "lb", "lu4", "lu3", "lu2"}
+    plans = [
+        ("exact", lambda n: "exact"),
+        ("f16x3", lambda n: "f16x3"),
+        ("f16x2 all", lambda n: "f16x2"),
+        ("fp8x all", lambda n: "fp8x"),
+        ("fp8x deep", lambda n: "fp8x" if n in deep else "f16x3"),
+        ("fp8x lb only", lambda n: "fp8x" if n == "lb" else "f16x3"),
+        ("fp8x top (lu0,lu1)", lambda n: "fp8x" if n in ("lu0", "lu1") else "f16x3"),
+    ]
+    print("max |p - p_oracle| over the softmax outputs; plans: " + " | ".join(l for l, _ in plans))
+    print("%-42s" % "case" + "".join(" %10s" % l.split()[0][:10] for l, _ in plans))
+    cases = dict(helpers.small_hps())
+    cases["duo hp (128x128x2, widths 36..1152)"] = model.KNOWN_HP["nucleiDAPILAMIN"]
+    worst = [0.0] * len(plans)
+    for name, hp in cases.items():
+        blob = model.random_blob(hp, seed=11)
+        n = 1 if hp.imSize >= 128 else 3
+        x = np.random.default_rng(5).normal(size=(n, hp.imSize, hp.imSize, hp.nChannels)).astype(np.float32)
+        row = run_case(name, hp, blob, x, plans)
+        worst = [max(a, b) for a, b in zip(worst, row)]
+    print("%-42s" % "worst of the nine random graphs" + "".join(" %10.3g" % e for e in worst))
+    # the three models the reference ships weights for, on real tiles of its sample image
+    raw = helpers.load_sample_105()[0]
+    I = helpers.legacy_preprocess(raw)
+    for key in ("nucleiDAPI", "mousenucleiDAPI", "CytoplasmIncell"):
+        art = model.load_model_dir(os.path.join(ROOT, "models", key))
+        hp = art.hp
+        pi = pi2d_oracle.PI2DOracle(I, hp.imSize, hp.margin, "accumulate")
+        nt = 4 if hp.imSize <= 128 else 2
+        x = pi2d_oracle.normalised_batch(pi, 5, nt, hp.nChannels, art.mean, art.std, False)
+        run_case("%s real weights, 105.tif tiles" % key, hp, art.blob, x, plans)
+
+
+if __name__ == "__main__":
+    main()

@@ -308,26 +308,34 @@ def test_eval_is_the_inference_mode_forward():
     tr.close()
 
 
-def test_train_loop_end_to_end(tmp_path):
-    """UNet2D.train on the GPU: the reference's file convention in, model directory + PNGs out, error goes down, and the
-    saved model serves the inference engine."""
-    from test_train_loop_cpu import HP, write_dataset
-    from unmicst_amd.unet2d import UNet2D
-    hp = dict(HP, nOut0=8, batchSize=4)
-    for name, n in (("train", 12), ("valid", 8), ("test", 2)):
-        write_dataset(str(tmp_path / name), n, 32, 1, 12, seed=len(name))
-    np.random.seed(1)
-    UNet2D.setupWithHP(hp)
-    UNet2D.train_regime = "solo"
-    hist = UNet2D.train(str(tmp_path / "train"), str(tmp_path / "valid"), str(tmp_path / "test"), str(tmp_path / "log"),
-                        str(tmp_path / "model"), str(tmp_path / "pm"), 12, 8, 2, False, 60, 0, 2)
-    losses = [l for l, _ in hist]
+def test_steps_over_resident_batches_learn_and_the_result_serves_the_engine(tmp_path):
+    """Row f-1 is the STEP: a plain loop over a few fixed batches calling Trainer.step (the shape of bench.py's train leg) brings the
+    loss down, and the parameters it leaves are a blob the inference engine loads as they are (train -> infer without conversion)."""
+    hp = model.HParams(model.GRAPH_V2, 32, 1, 3, 8, 2, 3, 0)
+    blob = model.random_blob(hp, seed=11)
+    rng = np.random.default_rng(5)
+    batches = []
+    for _ in range(3):   # a learnable rule: the class is a threshold of the (smoothed) input
+        x = rng.normal(size=(4, 32, 32, 1)).astype(np.float32)
+        cls = (x[..., 0] > 0.4).astype(int) + (x[..., 0] > -0.4).astype(int)
+        batches.append((x, np.eye(3, dtype=np.float32)[cls], np.ones((4, 32, 32, 3), np.float32)))
+    tr = trainer.Trainer(hp, blob, trainer.solo_options(), batch=4)
+    losses = [tr.step(*batches[i % 3])[0] for i in range(60)]
     assert np.mean(losses[-10:]) < np.mean(losses[:10])
-    assert len(os.listdir(tmp_path / "pm")) == 2 * 12 * 2
+    model.save_converted(model.ModelArtefacts(hp, tr.blob(), 0.0, 1.0), str(tmp_path / "model"))
+    tr.close()
     art = model.load_model_dir(str(tmp_path / "model"))
     with umx.Engine(art.hp, art.blob, max_batch=2) as eng:
         p = eng.forward_tiles(np.zeros((1, 32, 32, 1), np.float32))
     assert np.allclose(p.sum(-1), 1.0, atol=1e-5)
+
+
+def test_the_loops_around_the_step_are_refused():
+    from unmicst_amd.unet2d import UNet2D
+    with pytest.raises(NotImplementedError):
+        UNet2D.train()
+    with pytest.raises(NotImplementedError):
+        UNet2D.deploy()
 
 
 def test_weight_scale_refresh_does_not_change_a_result(monkeypatch):
@@ -471,13 +479,3 @@ def test_odd_shapes_match_oracle(hp_args, B):
     l2 = tr.step(data, labels, weights)[0]
     assert l2 == pytest.approx(want[0], rel=1e-5) and tr.step_count == 1
     tr.close()
-
-
-def test_deploy_on_the_gpu(tmp_path):
-    from test_train_loop_cpu import HP, write_dataset
-    from unmicst_amd.unet2d import UNet2D
-    hp = model.hparams_from_dict(dict(HP, nOut0=8), model.GRAPH_V2)
-    model.save_converted(model.ModelArtefacts(hp, model.random_blob(hp, seed=3), 0.3, 0.2), str(tmp_path / "model"))
-    write_dataset(str(tmp_path / "imgs"), 3, 32, 1, 0, seed=1)
-    UNet2D.deploy(str(tmp_path / "imgs"), 3, str(tmp_path / "model"), str(tmp_path / "pm"), 0, 2)
-    assert sorted(os.listdir(tmp_path / "pm")) == ["I%05d_%s.png" % (i, t) for i in range(1, 4) for t in ("Im", "PM")]

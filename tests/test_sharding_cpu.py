@@ -1,4 +1,4 @@
-"""world_size-2 (and 3) gloo runs of the sharded whole-slide path on CPU: the band partition + halo exchange +
+"""world_size-2 (3, and 8) gloo runs of the sharded whole-slide path on CPU: the band partition + halo exchange +
 all-gather host logic must reproduce the single-process oracle result bit for bit on every rank."""
 import os
 import socket
@@ -23,12 +23,14 @@ def _free_port():
 
 @pytest.mark.parametrize("world,hp_name,H,W,C", [(2, "v2_duo_like", 100, 61, 2), (3, "legacy_k3_x0", 130, 40, 1),
                                                   (2, "v2_duo_like", 20, 30, 2),    # fewer patch rows than ranks
-                                                  (2, "v2_solo_like", 260, 40, 1)])  # 6 + 5 patch rows: 4 slabs per band
+                                                  (2, "v2_solo_like", 260, 40, 1),   # 6 + 5 patch rows: 4 slabs per band
+                                                  # the target topology: 8 ranks, 19 patch rows -> bands of 3/3/3/2/2/2/2/2
+                                                  (8, "legacy_k3_x2", 12 * 19 - 5, 30, 2)])
 def test_sharded_equals_single_process(tmp_path, world, hp_name, H, W, C):
     from oracle import oracle
     from unmicst_amd import model
     out = str(tmp_path / "res")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OMP_NUM_THREADS="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OMP_NUM_THREADS="2" if world < 8 else "1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"],
            os.path.join(ROOT, "tests", "sharded_worker.py"), out, hp_name, str(H), str(W), str(C)]

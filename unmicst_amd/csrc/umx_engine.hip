@@ -346,6 +346,15 @@ int umx_internal_device(umx_ctx* ctx) { return ctx->device; }
 void umx_internal_hp(const umx_ctx* ctx, umx_hparams* out) { *out = ctx->hp; }
 int umx_internal_fail(umx_ctx* ctx, int code, const char* msg) { return fail(ctx, code, "%s", msg); }
 void umx_internal_set_destroy_hook(void (*hook)(umx_ctx*)) { g_destroy_hook = hook; }
+// (umx_shard.hip) how a submitted call's completion event is waited for on a context that holds a communicator: polling, so that a peer's
+// failure or a timeout ends the wait with a status instead of blocking for ever; NULL / no hook: hipEventSynchronize
+static int (*g_wait_hook)(umx_ctx*, hipEvent_t) = nullptr;
+void umx_internal_set_wait_hook(int (*hook)(umx_ctx*, hipEvent_t)) { g_wait_hook = hook; }
+int umx_internal_wait_event(umx_ctx* ctx, hipEvent_t ev) {
+    if (g_wait_hook) return g_wait_hook(ctx, ev);
+    const hipError_t e = hipEventSynchronize(ev);
+    return e == hipSuccess ? UMX_OK : fail(ctx, UMX_ERR_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(e));
+}
 
 extern "C" {
 

@@ -44,6 +44,8 @@ void range_threads(const T* x, size_t n, uint32_t* out) {
 }  // namespace
 
 
+int umx_internal_wait_event(umx_ctx* ctx, hipEvent_t ev);   // umx_engine.hip
+
 extern "C" {
 
 // ---- host entry points.  The reference hands host arrays across its seam (UnMicst1-5.py:687-710); here the slide goes up
@@ -60,7 +62,7 @@ static int host_wait(umx_ctx* ctx, int slot) {
     umx_ctx::HostSlot& hs = ctx->hs[slot];
     if (!hs.busy) return UMX_OK;
     hs.busy = false;
-    HIP_TRY(ctx, hipEventSynchronize(hs.done));
+    if (const int rc = umx_internal_wait_event(ctx, hs.done)) return rc;   // (a sharded context polls its communicator while it waits)
     if (*hs.flag_host)   // this slot's own flag word, cleared by the next submit on the slot in stream order
         return fail(ctx, UMX_ERR_RANGE, "an activation left the binary16 range of the split-precision path; "
                                         "create the context with UMX_PREC_F32 (or UMX_PRECISION=f32)");

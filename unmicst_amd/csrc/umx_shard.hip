@@ -17,11 +17,13 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "umx_internal.h"   // (same shared object: the raw entry stages its band like the host path of umx_host.hip)
@@ -32,6 +34,7 @@ int umx_internal_device(umx_ctx* ctx);
 void umx_internal_hp(const umx_ctx* ctx, umx_hparams* out);
 int umx_internal_fail(umx_ctx* ctx, int code, const char* msg);
 void umx_internal_set_destroy_hook(void (*hook)(umx_ctx*));
+void umx_internal_set_wait_hook(int (*hook)(umx_ctx*, hipEvent_t));
 
 namespace {
 
@@ -46,6 +49,8 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;   // (optional: failure detection)
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     std::string err;
 };
 
@@ -66,6 +71,8 @@ Rccl* rccl() {
         UMX_SYM(GetUniqueId) UMX_SYM(CommInitRank) UMX_SYM(CommDestroy) UMX_SYM(Send) UMX_SYM(Recv) UMX_SYM(AllGather)
         UMX_SYM(GroupStart) UMX_SYM(GroupEnd) UMX_SYM(GetErrorString)
 #undef UMX_SYM
+        r.CommGetAsyncError = reinterpret_cast<decltype(r.CommGetAsyncError)>(dlsym(r.h, "ncclCommGetAsyncError"));
+        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.h, "ncclCommAbort"));
     });
     return &r;
 }
@@ -86,6 +93,8 @@ struct Shard {
     ncclComm_t comm = nullptr;
     umx_shard_transport tp = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ready = false;
+    bool failed = false;          // a transport call failed, a peer's failure was seen or a wait timed out: the communicator (RCCL) is
+                                  // aborted and every later call on this context is refused until umx_shard_fini + a new umx_shard_init
     std::string tp_err;           // message of the last failed transport call (RCCL: ncclGetErrorString)
     int rank = 0, world = 1;
     hipStream_t comm_stream = nullptr;
@@ -97,6 +106,7 @@ struct Shard {
 
 std::map<umx_ctx*, Shard> g_shards;
 std::mutex g_mu;
+int shard_wait(umx_ctx* ctx, hipEvent_t ev);   // (below: the bounded wait of a submitted sharded call)
 
 int fail(umx_ctx* ctx, int code, const std::string& msg) { return umx_internal_fail(ctx, code, msg.c_str()); }
 
@@ -118,6 +128,13 @@ int grow(umx_ctx* ctx, Buf* b, size_t bytes) {
     S_HIP(ctx, hipMalloc(&b->d, bytes ? bytes : 16));
     b->cap = bytes;
     return UMX_OK;
+}
+
+// After a failure the collectives already enqueued can wait for peers that will never arrive: ncclCommAbort makes them return, so that
+// the streams drain and the peers' own waits see an error instead of blocking (they poll ncclCommGetAsyncError, shard_wait below).
+void shard_abort(Shard& s) {
+    s.failed = true;
+    if (s.comm && rccl()->CommAbort) { rccl()->CommAbort(s.comm); s.comm = nullptr; }
 }
 
 void release(Shard& s) {
@@ -229,6 +246,7 @@ int umx_shard_init(umx_ctx* ctx, const umx_unique_id* id, int rank, int world) {
     S_HIP(ctx, hipSetDevice(umx_internal_device(ctx)));
     std::lock_guard<std::mutex> lk(g_mu);
     umx_internal_set_destroy_hook(on_destroy);
+    umx_internal_set_wait_hook(shard_wait);
     Shard& s = g_shards[ctx];
     if (s.ready) { release(s); s = Shard(); }
     ncclUniqueId nid;
@@ -249,6 +267,7 @@ int umx_shard_init_transport(umx_ctx* ctx, const umx_shard_transport* tp, int ra
     S_HIP(ctx, hipSetDevice(umx_internal_device(ctx)));
     std::lock_guard<std::mutex> lk(g_mu);
     umx_internal_set_destroy_hook(on_destroy);
+    umx_internal_set_wait_hook(shard_wait);
     Shard& s = g_shards[ctx];
     if (s.ready) { release(s); s = Shard(); }
     s.tp = *tp;
@@ -324,8 +343,8 @@ struct RunIO {
     hipEvent_t* ev_cs_end = nullptr;       // out: recorded on the context's stream behind the call's last kernel
 };
 
-int sharded_run(umx_ctx* ctx, Shard& s, const RunIO& io, int C_img, int H, int W, int band_row0, int band_rows, double mean,
-                double stdv, int mode, int stitch, int nslabs) {
+int sharded_run_enqueue(umx_ctx* ctx, Shard& s, const RunIO& io, int C_img, int H, int W, int band_row0, int band_rows, double mean,
+                        double stdv, int mode, int stitch, int nslabs) {
     const umx_shard_transport& tp = s.tp;
 #define S_TP(ctx, expr)                                                                                       \
     do {                                                                                                      \
@@ -350,6 +369,21 @@ int sharded_run(umx_ctx* ctx, Shard& s, const RunIO& io, int C_img, int H, int W
     }
     n = std::max(1, n);
     const int pa = A[rank], pb = B[rank];
+    if (s.failed) return fail(ctx, UMX_ERR_INVALID, "the sharded world of this context failed earlier (its communicator was aborted): umx_shard_fini, then umx_shard_init in every rank");
+    // argument checks of both public entries (the range kernels below index the band unchecked; nothing is enqueued before these)
+    if (mode != UMX_MODE_ACCUMULATE && mode != UMX_MODE_REPLACE) return fail(ctx, UMX_ERR_INVALID, "sharded entry: bad stitch mode");
+    if (stitch != UMX_STITCH_FP16_COMPAT && stitch != UMX_STITCH_FP32)
+        return fail(ctx, UMX_ERR_INVALID, "sharded entry: stitch must be UMX_STITCH_FP16_COMPAT or UMX_STITCH_FP32");
+    if (!(stdv != 0.0) || C_img < 1 || (C_img != 1 && C_img != hp.nChannels))
+        return fail(ctx, UMX_ERR_INVALID, "sharded entry: std must be non-zero and the band must hold 1 or nChannels planes");
+    if (band_rows < 0 || band_row0 < 0 || band_row0 + band_rows > H) return fail(ctx, UMX_ERR_INVALID, "sharded entry: band outside the image");
+    if (pa < pb) {
+        if (!io.band_f64 && !io.raw_dev) return fail(ctx, UMX_ERR_INVALID, "sharded entry: NULL band");
+        int need0 = 0, need1 = 0;
+        umx_geom::needed(pa, pb, sub, margin, P, H, &need0, &need1);
+        if (band_row0 > need0 || band_row0 + band_rows < need1)
+            return fail(ctx, UMX_ERR_INVALID, "sharded entry: the band does not cover the image rows its patch rows read (umx_shard_plan: need_row0 .. need_row1)");
+    }
     const bool has_prev = pa < pb && pa > 0, has_next = pa < pb && pb < npr;
     const int lo = has_prev ? pa - 1 : pa;
     const size_t tile_f = (size_t)P * P * K, row_f = tile_f * npc;
@@ -488,6 +522,67 @@ int sharded_run(umx_ctx* ctx, Shard& s, const RunIO& io, int C_img, int H, int W
     if (io.ev_gathered) *io.ev_gathered = ev_done;
     if (io.ev_cs_end) *io.ev_cs_end = ev_end;
 #undef S_TP
+    return UMX_OK;
+}
+
+// An error in the middle of enqueueing: gathers and scatter copies into the caller's `out_full` may already sit on the communication
+// stream -- drain it (and the context's stream, whose kernels feed it) before the caller gets its buffers back; the message survives.
+int sharded_run(umx_ctx* ctx, Shard& s, const RunIO& io, int C_img, int H, int W, int band_row0, int band_rows, double mean,
+                double stdv, int mode, int stitch, int nslabs) {
+    const int rc = sharded_run_enqueue(ctx, s, io, C_img, H, W, band_row0, band_rows, mean, stdv, mode, stitch, nslabs);
+    if (rc && rc != UMX_ERR_INVALID) {   // (UMX_ERR_INVALID: the argument checks, nothing was enqueued)
+        const std::string msg = ctx->err;
+        shard_abort(s);                  // peers must not wait for this rank's collectives, and ours must not wait for theirs
+        hipStreamSynchronize(umx_internal_stream(ctx));
+        if (s.comm_stream) hipStreamSynchronize(s.comm_stream);
+        ctx->err = msg;
+    }
+    return rc;
+}
+
+// How a submitted sharded call is waited for (umx_infer_image_wait): the completion event is polled, and between polls the
+// communicator's asynchronous error state is read (ncclCommGetAsyncError: a peer died, a link failed) and a wall-clock bound is kept
+// (UMX_SHARD_TIMEOUT_S, default 600 s; 0 = none) -- either ends the wait with UMX_ERR_HIP after ncclCommAbort, never with a hang.
+int shard_wait(umx_ctx* ctx, hipEvent_t ev) {
+    Shard* sp = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_shards.find(ctx);
+        if (it != g_shards.end()) sp = &it->second;
+    }
+    if (!sp || !sp->ready) {
+        const hipError_t e = hipEventSynchronize(ev);
+        return e == hipSuccess ? UMX_OK : fail(ctx, UMX_ERR_HIP, std::string("hipEventSynchronize failed: ") + hipGetErrorString(e));
+    }
+    Shard& s = *sp;
+    double limit = 600.0;
+    if (const char* e = getenv("UMX_SHARD_TIMEOUT_S")) limit = atof(e);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    for (;;) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) { shard_abort(s); return fail(ctx, UMX_ERR_HIP, std::string("hipEventQuery failed: ") + hipGetErrorString(q)); }
+        if ((++spins & 63u) == 0u) {
+            if (s.comm && rccl()->CommGetAsyncError) {
+                ncclResult_t ae = ncclSuccess;
+                const ncclResult_t r = rccl()->CommGetAsyncError(s.comm, &ae);
+                if (r != ncclSuccess || (ae != ncclSuccess && ae != ncclInProgress)) {
+                    const std::string why = rccl()->GetErrorString(r != ncclSuccess ? r : ae);
+                    shard_abort(s);
+                    hipStreamSynchronize(s.comm_stream);
+                    return fail(ctx, UMX_ERR_HIP, "the sharded world failed while this rank waited (RCCL: " + why + "); the communicator was aborted");
+                }
+            }
+            const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (limit > 0.0 && waited > limit) {
+                shard_abort(s);
+                return fail(ctx, UMX_ERR_HIP, "timed out after " + std::to_string((int)waited) + " s waiting for a sharded call (UMX_SHARD_TIMEOUT_S): a peer "
+                                              "is not taking part; the communicator was aborted");
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    }
     return UMX_OK;
 }
 

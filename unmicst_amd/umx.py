@@ -396,6 +396,10 @@ class Engine:
     def shard_init(self, unique_id: bytes, rank: int, world: int) -> None:
         self._check(self._L.umx_shard_init(self._ctx, ctypes.create_string_buffer(unique_id, 128), int(rank), int(world)))
 
+    def shard_fini(self) -> None:
+        """umx_shard_fini: drop the communicator / transport (after a failure: ncclCommAbort instead of ncclCommDestroy)."""
+        self._check(self._L.umx_shard_fini(self._ctx))
+
     def shard_init_transport(self, send, recv, all_gather, rank: int, world: int, group_start=None, group_end=None) -> None:
         """umx_shard_init_transport with Python callables: send(dev_ptr, nbytes, peer, stream), recv(dev_ptr, nbytes, peer, stream),
         all_gather(send_ptr, recv_ptr, nbytes_per_rank, stream), group_start() / group_end(); an exception = failure."""

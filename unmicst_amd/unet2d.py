@@ -41,7 +41,6 @@ class UNet2D:
     _last = None            # (key, planes) of the most recent full pass
 
     # ---------------------------------------------------------------- training (v2 graph)
-    train_regime = "solo"   # which script's constants UNet2D.train uses: "solo" (UnMicst1-5.py) or "duo" (UnMicst2.py)
 
     @staticmethod
     def setupWithHP(hp):
@@ -60,21 +59,17 @@ class UNet2D:
         UNet2D.hparams = _model.hparams_from_dict(UNet2D.hp, _model.GRAPH_V2)
 
     @staticmethod
-    def train(imPath, validPath, testPath, logPath, modelPath, pmPath, nTrain, nValid, nTest, restoreVariables, nSteps,
-              gpuIndex, testPMIndex):
-        """== reference UnMicst1-5.py:240-578 / UnMicst2.py:237-561 (``UNet2D.train_regime`` picks the script's
-        constants); the optimisation step runs in libumx (unmicst_amd/train_loop.py, include/umx_train.h)."""
-        from . import train_loop
-        if UNet2D.hp is None:
-            raise RuntimeError("call UNet2D.setup / setupWithHP first")
-        return train_loop.train(UNet2D.hp, imPath, validPath, testPath, logPath, modelPath, pmPath, nTrain, nValid, nTest,
-                                restoreVariables, nSteps, gpuIndex, testPMIndex, regime=UNet2D.train_regime)
+    def train(*args, **kwargs):
+        """Out of scope: the reference's data loading, augmentation and bookkeeping around the
+        optimisation step (UnMicst1-5.py:240-578) are not part of the path this package replaces.  The step itself is
+        ``unmicst_amd.trainer.Trainer.step`` (include/umx_train.h); INTEGRATION.md shows where it goes in the reference's loop."""
+        raise NotImplementedError("UNet2D.train is out of scope: drive unmicst_amd.trainer.Trainer.step from your own loop "
+                                  "(INTEGRATION.md, 'Training step')")
 
     @staticmethod
-    def deploy(imPath, nImages, modelPath, pmPath, gpuIndex, pmIndex):
-        """== reference UnMicst1-5.py:583-654 (tile-sized images in, ``I%05d_Im.png`` / ``I%05d_PM.png`` out)."""
-        from . import train_loop
-        return train_loop.deploy(imPath, nImages, modelPath, pmPath, gpuIndex, pmIndex)
+    def deploy(*args, **kwargs):
+        """Out of scope like ``train`` (reference UnMicst1-5.py:583-654); ``singleImageInference`` is the inference entry."""
+        raise NotImplementedError("UNet2D.deploy is out of scope: use UNet2D.singleImageInference")
 
     # ---------------------------------------------------------------- setup / cleanup
     @staticmethod
