@@ -56,7 +56,7 @@ def parse_args(argv=None):
     ap.add_argument("--train-batch", type=int, default=8, help="train-synth256: images per optimisation step")
     ap.add_argument("--batch", type=int, default=0, help="tiles per UNet launch group (0: umx.auto_batch -- 2^24 pixels per group, "
                                                       "i.e. 256 tiles of the 256-pixel metric tile)")
-    ap.add_argument("--precision", default="default", choices=["default", "f32", "f16x3"],
+    ap.add_argument("--precision", default="default", choices=["default", "f32", "f16x3", "f16f6"],
                     help="conv arithmetic: exact fp32 MFMA, or 3 binary16 MFMA products per fp32 product (default)")
     ap.add_argument("--band-rows", type=int, default=0, help="override rows per GPU")
     ap.add_argument("--cols", type=int, default=0, help="override slide width")
@@ -164,7 +164,7 @@ def roofline_of(prof, elapsed_s, eng, batch):
     all_exec = sum(p["exec_flops"] for p in convs)
     all_ms = sum(p["total_ms"] for p in convs)
     all_ms_est = sum(k["ms_all"] for k in by_kernel.values())
-    peak = PEAK_F16_MFMA_TFLOPS if eng.precision == "f16x3" else PEAK_F32_MFMA_TFLOPS
+    peak = PEAK_F16_MFMA_TFLOPS if eng.precision in ("f16x3", "f16f6") else PEAK_F32_MFMA_TFLOPS
     return {
         # achieved = ALGORITHMIC fp32 FLOPs of the kernel's launches / HIP-event time of those launches; peak = dense MFMA
         # peak of the dtype the matrix cores run (f16x3 issues 3 binary16 MFMA FLOPs per algorithmic FLOP: "mfma_issued")
@@ -545,6 +545,18 @@ def main():
             del band_f64
             torch.cuda.empty_cache()
             f32 = f32_leg(torch, umx, hp, blob, local_rank, args.batch, host_u16, C_img, W, mean, std)
+        configs = None
+        if legs:
+            if eng.precision == "f32":
+                eng.close()
+            del host_u16, host_outs, host_out, dev_out
+            torch.cuda.empty_cache()
+            configs = []
+            for name, rows, nsteps in CONFIG_LEGS:
+                try:
+                    configs.append(config_leg(torch, umx, model, dev, local_rank, name, rows, nsteps, args.precision))
+                except Exception as e:   # noqa: BLE001  (a leg must not take the headline line down with it: say what happened)
+                    configs.append({"workload": name, "error": "%s: %s" % (type(e).__name__, e)})
         up_b = C_img * H * W * 2
         dn_b = K * H * W
         scope = ("H2D+D2H inside the timed region: uint16 planes up (%.0f MB), uint8 probability planes down (%.0f MB), "
@@ -559,7 +571,8 @@ def main():
             "metric": "tiles/sec (%dx%dx%d) whole-slide inference" % (hp.imSize, hp.imSize, hp.nChannels),
             "value": round(value, 2), "unit": "tiles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": {"f32": "f32", "f16x3": "f16x3 (fp32 products as 3 binary16 MFMA products, fp32 accumulate)"}[
+            "dtype": {"f32": "f32", "f16x3": "f16x3 (fp32 products as 3 binary16 MFMA products, fp32 accumulate)",
+                      "f16f6": "f16x3, cross terms of the layers at <= 1/4 resolution as block-scaled fp6 (MX e2m3) MFMA products; fp32 accumulate"}[
                 eng.precision], "data": "synthetic",
             "config": {"workload": "%s: %s hp (%s graph, seeded weights), %d-channel synthetic slide %dx%d, "
                                    "%d tiles/step, batch %d, fp16-compat stitch; %s" % (
@@ -572,7 +585,7 @@ def main():
                          "ms_per_step": round(1e3 * res_elapsed / args.steps, 3),
                          "note": "same slide already in HBM as float64, result left in HBM (no H2D / D2H): kernel-only"},
             "host_sync": host_sync, "weak_band": weak_band, "ranks": ranks, "shard_path": shard_path if sharded else None,
-            "roofline": roofline, "cpu_baseline": cpu, "f32": f32, "train": train,
+            "roofline": roofline, "cpu_baseline": cpu, "f32": f32, "train": train, "configs": configs,
             "workload_note": "the default workload is the full 16384 x 16384 slide at every N since round 4 (rounds 1-3 quoted its first "
                              "2048 rows: `weak_band` carries that line)",
         }
@@ -591,6 +604,77 @@ def crc32_of(t):
     for i in range(0, a.size, step):
         crc = zlib.crc32(a[i:i + step].tobytes() if a.dtype.itemsize != 1 else memoryview(a[i:i + step]), crc)
     return crc & 0xFFFFFFFF
+
+
+CONFIG_LEGS = (   # (workload, rows, steps): the other BASELINE.json configs as short legs of the default N = 1 line
+    ("solo-1024", 1024, 20),       # configs[1]: the reference's default tool (unmicstWrapper.py:55-57) on a 1024 x 1024 image
+    ("duo-4096", 4096, 10),        # configs[2]
+    ("solo-16384", 16384, 3),      # configs[3] as worded: the whole 16384 x 16384 slide, here on one GPU
+    ("legacy-1024", 1024, 20),     # the only graph with weights in the reference's tree
+)
+
+
+def config_leg(torch, umx, model, dev, local_rank, name, H, steps, precision):
+    """One BASELINE config through the same host path as the headline (uint16 planes up, uint8 planes down inside the timed region,
+    two slides in flight): tiles/s, CRC-32 of the uint8 stack, the dominant kernel's fraction of the matrix peak -- or, for the
+    16 - 64-channel legacy graph, which SURVEY section 2.2 classes HBM / LDS-bound, its compulsory bytes against 8 TB/s."""
+    key, C_img, _, W = WORKLOADS[name]
+    hp = model.KNOWN_HP[key]
+    blob = model.random_blob(hp, seed=20260101)
+    mean, std = NORMALISATION[key]
+    K = hp.nClasses
+    batch = umx.auto_batch(hp)
+    eng = umx.Engine(hp, blob, device=local_rank, max_batch=batch, precision=precision)
+    try:
+        npr, npc, _, _ = eng.tile_grid(H, W)
+        band = torch.empty((C_img, H, W), dtype=torch.int16).pin_memory()
+        rows_per = max(1, (1 << 26) // (W * C_img))          # (the slide is generated on the device in pieces of <= 64 M samples)
+        for y in range(0, H, rows_per):
+            n = min(rows_per, H - y)
+            band[:, y:y + n].copy_(synth_rows_u16(torch, C_img, y, n, W, dev).to(torch.int16))
+        outs = [torch.empty((K, H, W), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        inflight = []
+
+        def step(i):
+            slot = i & 1
+            if len(inflight) == 2:
+                eng.infer_image_wait(inflight.pop(0))
+            eng.infer_image_raw_submit(slot, band.data_ptr(), 16, C_img, H, W, False, mean, std, outs[slot].data_ptr())
+            inflight.append(slot)
+
+        def drain():
+            while inflight:
+                eng.infer_image_wait(inflight.pop(0))
+            eng.synchronize()
+        step(0)
+        drain()
+        eng.profile_enable(1)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        drain()
+        dt = time.perf_counter() - t0
+        prof = eng.profile_read()
+        eng.profile_enable(False)
+        tiles = npr * npc
+        r = roofline_of(prof, dt, eng, batch)
+        hbm_bound = hp.graph == 0     # legacy widths (16 .. 64 channels)
+        convs = [p for p in prof if p["kernel"].startswith("conv_")]
+        by = sum(p["bytes"] for p in convs)
+        ms = sum(p["total_ms"] for p in convs)
+        roof = {"bound": "mfma", "kernel": r["kernel"], "achieved": r["achieved"], "peak": r["peak"], "unit": "TFLOP/s", "frac": r["frac"],
+                "share_of_step": r["share_of_step"], "all_conv_launches": r["all_conv_launches"]}
+        if hbm_bound:
+            roof = {"bound": "hbm", "kernel": r["kernel"], "achieved": round(by / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                    "note": "compulsory activation bytes of all convolution launches / their time (SURVEY 2.2: this graph's 16 - 64-channel "
+                            "layers are HBM / LDS-bound, not matrix-bound); as a fraction of the binary16 matrix peak the same launches reach "
+                            "%.4f" % r["all_conv_launches"]["frac"]}
+        return {"workload": name, "model": key, "value": round(tiles * steps / dt, 2), "unit": "tiles/s", "tiles_per_step": int(tiles),
+                "tile": [hp.imSize, hp.imSize, hp.nChannels], "slide": [int(H), int(W)], "steps": steps, "ms_per_step": round(1e3 * dt / steps, 3),
+                "batch": batch, "dtype": eng.precision, "crc32_u8_planes": crc32_of(outs[(steps - 1) & 1]), "roofline": roof}
+    finally:
+        eng.close()
 
 
 def f32_leg(torch, umx, hp, blob, local_rank, batch, host_u16, C_img, W, mean, std, steps=4):

@@ -44,8 +44,13 @@ enum umx_status {
  *                   accumulation (~2^-21 relative error per product; 16/3 of the fp32 matrix rate).  Default.
  *   UMX_PREC_DEFAULT  = UMX_PREC_F16X3 where its planner covers every layer of the graph, else UMX_PREC_F32 (layers of 2x2 /
  *                     4x4 pixels under 5x5 / 7x7 filters exceed the split kernel's LDS image); UMX_PRECISION=f32|f16x3 in the
- *                     environment pins it.  umx_precision_of() tells which one a ctx runs. */
-enum umx_precision { UMX_PREC_DEFAULT = 0, UMX_PREC_F32 = 1, UMX_PREC_F16X3 = 2 };
+ *                     environment pins it.  umx_precision_of() tells which one a ctx runs.
+ *   UMX_PREC_F16X3_F6  UMX_PREC_F16X3 with the two CROSS terms (x_hi*w_lo + x_lo*w_hi, a 2^-11 correction) of the wide layers at
+ *                     <= 1/4 of the input resolution on the block-scaled matrix instruction (OCP MX fp6 e2m3, 4 x the K per
+ *                     instruction): half the matrix time on those layers.  Measured 2e-5 against the 1e-4 tolerance on the
+ *                     reference's trained weights (tests/fp8_cross_term_report.py); every other layer as UMX_PREC_F16X3.
+ *                     UMX_PRECISION=f16f6 selects it; umx_precision_of() reports it. */
+enum umx_precision { UMX_PREC_DEFAULT = 0, UMX_PREC_F32 = 1, UMX_PREC_F16X3 = 2, UMX_PREC_F16X3_F6 = 3 };
 
 typedef struct umx_options {
     int32_t device_ordinal;
@@ -298,6 +303,10 @@ UMX_API int umx_describe(const umx_hparams* hp, int* n_launches, double* flops_p
  * (UnMicst1-5.py:55-237; the op graph it saves: models/<name>/model.ckpt.meta).  Writes at most cap bytes (NUL-terminated) and
  * returns in *needed the bytes the whole text takes; UMX_ERR_INVALID if cap is too small. */
 UMX_API int umx_describe_graph(const umx_hparams* hp, char* json, size_t cap, size_t* needed);
+/* Host only (no device needed): would umx_create with UMX_PREC_F16X3 take this model?  UMX_OK, or UMX_ERR_INVALID with the first
+ * refused layer and the split-precision planner's reason in umx_last_error(NULL) -- what UMX_PREC_DEFAULT falls back to the exact-fp32
+ * engine on (and warns about). */
+UMX_API int umx_plan_check(const umx_hparams* hp);
 UMX_API const char* umx_version(void);
 
 #ifdef __cplusplus

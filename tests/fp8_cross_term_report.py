@@ -50,6 +50,31 @@ def q_e4m3(v):
     return torch.sign(v) * q.clamp(max=448.0)
 
 
+def q_e2m3(v):
+    """Round-to-nearest-even onto OCP fp6 e2m3 (bias 1, 3 mantissa bits, subnormals in steps of 1/8 below 1, max 7.5, saturating)."""
+    a = v.abs().clamp(max=7.5)
+    e = torch.floor(torch.log2(torch.where(a > 0, a, torch.ones_like(a)))).clamp(min=0.0)
+    ulp = torch.exp2(e - 3.0)
+    return torch.sign(v) * (torch.round(a / ulp) * ulp).clamp(max=7.5)
+
+
+def mx_block(m, axis, q, emax):
+    """MX block format along `axis` (K): blocks of 32, shared e8m0 scale 2^(floor(log2(max|block|)) - emax), elements quantised by q."""
+    m = m.movedim(axis, -1)
+    K = m.shape[-1]
+    pad = (-K) % 32
+    mp = F.pad(m, (0, pad))
+    blk = mp.reshape(*mp.shape[:-1], -1, 32)
+    amax = blk.abs().amax(dim=-1, keepdim=True)
+    scale = torch.exp2(torch.floor(torch.log2(torch.where(amax > 0, amax, torch.ones_like(amax)))) - emax)
+    deq = q(blk / scale) * scale
+    return deq.reshape(*mp.shape)[..., :K].movedim(-1, axis)
+
+
+def mx_e2m3(m, axis):
+    return mx_block(m, axis, q_e2m3, 2.0)
+
+
 def mx_e4m3(m, axis):
     """MX block format along `axis` (K): blocks of 32, shared scale 2^(floor(log2(max|block|)) - 8), elements e4m3."""
     m = m.movedim(axis, -1)
@@ -66,7 +91,7 @@ def mx_e4m3(m, axis):
 # ------------------------------------------------------------------------------------------------ the emulated GEMM
 def gemm(A, Wm, plan):
     """A [M, K] activations (fp32 values as the previous layer produced them), Wm [K, N] weights -> [M, N].
-    plan: 'exact' (float64), 'f16x3', 'f16x2' (x_lo*w_hi dropped: the input rounded to binary16), 'fp8x' (cross terms in MX e4m3)."""
+    plan: 'exact' (float64), 'f16x3', 'f16x2' (x_lo*w_hi dropped: the input rounded to binary16), 'fp8x' / 'fp6x' (cross terms in MX e4m3 / MX e2m3)."""
     if plan == "exact":
         return (A.double() @ Wm.double()).float()
     wmax = float(Wm.abs().max())
@@ -81,6 +106,8 @@ def gemm(A, Wm, plan):
         acc = acc + xh.double() @ wl.double()
     elif plan == "fp8x":
         acc = acc + mx_e4m3(xh, 1).double() @ mx_e4m3(wl, 0).double() + mx_e4m3(xl, 1).double() @ mx_e4m3(wh, 0).double()
+    elif plan == "fp6x":
+        acc = acc + mx_e2m3(xh, 1).double() @ mx_e2m3(wl, 0).double() + mx_e2m3(xl, 1).double() @ mx_e2m3(wh, 0).double()
     else:
         raise ValueError(plan)
     return (acc * (2.0 ** -sh)).float()
@@ -186,9 +213,11 @@ def main():
         ("fp8x deep", lambda n: "fp8x" if n in deep else "f16x3"),
         ("fp8x lb only", lambda n: "fp8x" if n == "lb" else "f16x3"),
         ("fp8x top (lu0,lu1)", lambda n: "fp8x" if n in ("lu0", "lu1") else "f16x3"),
+        ("fp6x all", lambda n: "fp6x"),
+        ("fp6x deep", lambda n: "fp6x" if n in deep else "f16x3"),
     ]
     print("max |p - p_oracle| over the softmax outputs; plans: " + " | ".join(l for l, _ in plans))
-    print("%-42s" % "case" + "".join(" %10s" % l.split()[0][:10] for l, _ in plans))
+    print("%-42s" % "case" + "".join(" %10s" % l.replace(" ", "-")[:10] for l, _ in plans))
     cases = dict(helpers.small_hps())
     cases["duo hp (128x128x2, widths 36..1152)"] = model.KNOWN_HP["nucleiDAPILAMIN"]
     worst = [0.0] * len(plans)

@@ -39,6 +39,88 @@ __device__ __forceinline__ void static_for(F&& f) {   // compile-time loop: the 
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),           \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
+typedef int i32x6 __attribute__((ext_vector_type(6)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h32 __attribute__((ext_vector_type(32)));
+
+// ---- F6 form: the two CROSS terms of the split product on the block-scaled matrix instruction ------------------------------------
+// x*w = x_hi*w_hi + [x_hi*w_lo + x_lo*w_hi]: the bracket is a 2^-11 correction, so it needs ~11 fewer significant bits than the leading
+// term -- OCP MX fp6 (e2m3: 4 significant bits, one power-of-two e8m0 scale per 32 consecutive K elements) holds the tolerance on the
+// layers at <= 1/4 of the input resolution (tests/fp8_cross_term_report.py: 2.2e-5 on the reference's trained weights, 3e-6 on random
+// graphs, against 1e-4).  v_mfma_scale_f32_16x16x128_f8f6f4 with e2m3 operands runs 4 x the K of a binary16 MFMA in the same 16
+// cycles: ONE instruction whose K axis is [32 K of k-step j | 32 K of k-step j+1] x [x_hi*w_lo | x_lo*w_hi] replaces the four
+// binary16 cross-term MFMAs of two k-steps -- 1.5 units of matrix time per k-step instead of 3 (tools/probes/mfma_loops.hip:
+// the bare mixed trip runs 1.71 x the 3-product trip).  Weights are quantised once by the planner; the pixel operand is quantised
+// on the fly from the (hi, lo) halo already in LDS: lane (pixel, q) reads the four (tap, octet) units of k-step j + (q & 1) from the hi
+// (q < 2) or lo plane, takes the block's exponent from its largest magnitude and converts all 32 values with one
+// v_cvt_scalef32_pk32_fp6_f16 (semantics probed: tools/probes/mx_fp6_semantics.hip).
+typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+#define UMX_MAX3(dst, a, b, c) asm volatile("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(dst) : "v"(a), "v"(b), "v"(c))
+#define UMX_MAX3N(dst, a, b, c) asm volatile("v_pk_maximum3_f16 %0, %1, %2, %3 neg_lo:[1,1,1] neg_hi:[1,1,1]" : "=v"(dst) : "v"(a), "v"(b), "v"(c))
+#define UMX_MAX3N2(dst, a, b, c) asm volatile("v_pk_maximum3_f16 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(dst) : "v"(a), "v"(b), "v"(c))
+// NB blocks at once (1 or 2: two independent dependency chains interleaved instruction by instruction -- the reduction is a tree of
+// depth 4, one block's chain alone leaves the vector unit waiting for its own results).  volatile: the sequence stays together and in
+// this order -- left to the scheduler, the conversions sink behind every block's reduction and all fragment registers stay live.
+template <int NB>
+__device__ __forceinline__ void quant_blocks_e2m3(const h8 (&v)[NB][4], i32x6 (&out)[NB], int (&scale_e8m0)[NB]) {
+    h32 x[NB];
+    u32x16 d[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[b][8 * p + j] = v[b][p][j];
+        d[b] = __builtin_bit_cast(u32x16, x[b]);
+    }
+    // per half-word position: the largest value (tree P) and the largest negated value (tree N) of the 16 words, three at a time
+    unsigned P[NB][5], N[NB][5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            UMX_MAX3(P[b][t], d[b][3 * t], d[b][3 * t + 1], d[b][3 * t + 2]);
+            UMX_MAX3N(N[b][t], d[b][3 * t], d[b][3 * t + 1], d[b][3 * t + 2]);
+        }
+    unsigned P2[NB][2], N2[NB][2], m2[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        UMX_MAX3(P2[b][0], P[b][0], P[b][1], P[b][2]);
+        UMX_MAX3(N2[b][0], N[b][0], N[b][1], N[b][2]);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        UMX_MAX3(P2[b][1], P[b][3], P[b][4], d[b][15]);
+        UMX_MAX3N2(N2[b][1], N[b][3], N[b][4], d[b][15]);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) UMX_MAX3(m2[b], P2[b][0], P2[b][1], N2[b][0]);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) UMX_MAX3(m2[b], m2[b], N2[b][1], N2[b][1]);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const unsigned m = m2[b] & 0x7fff7fffu;
+        const unsigned mm = max(m & 0xffffu, m >> 16);   // bit pattern of the block's largest magnitude (binary16 orders like its bits)
+        // its exponent through binary32 -- the lo halves of activations below 0.25 are binary16 SUBNORMALS (taking the exponent field of
+        // the binary16 pattern pins their blocks' scale at 2^-17 and leaves them one or two significant bits: the x_lo * w_hi term was
+        // as good as dropped, 1.5e-5 .. 3.6e-5 instead of 3e-6 on the random graphs).  2^(exponent - 2): the largest value lands in
+        // [4, 8) (e2m3: up to 7.5, saturating); an all-zero block takes the smallest scale
+        const unsigned ef = __float_as_uint((float)__builtin_bit_cast(_Float16, (unsigned short)mm)) >> 23;
+        const unsigned e = max(ef, 3u) - 2u;
+        scale_e8m0[b] = (int)e;
+        const float sc = __uint_as_float(e << 23);
+        asm volatile("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(out[b]) : "v"(x[b]), "v"(sc));   // (early clobber: a multi-pass instruction, the 6 result registers must not overlap the 16 + 1 it is still reading)
+    }
+}
+__device__ __forceinline__ void quant_block_e2m3(const h8 (&v)[4], i32x6& out, int& scale_e8m0) {
+    h8 vv[1][4] = {{v[0], v[1], v[2], v[3]}};
+    i32x6 o[1];
+    int s[1];
+    quant_blocks_e2m3<1>(vv, o, s);
+    out = o[0];
+    scale_e8m0 = s[0];
+}
+
 // NPH = 1: one output phase per workgroup (plain convolutions; transposed convolutions one sub-pixel phase at a time,
 //          phase = blockIdx.z), KMT = 4 M-tiles per wave (256 pixels per workgroup: a 16 x 16 tile).
 // NPH = 4: stride-2 transposed convolution with all four sub-pixel phases in one workgroup: the input halo is loaded
@@ -60,13 +142,26 @@ constexpr int conv_f16x3_waves(int NT, int KMT, int NPH, int MAXP, bool D2S = fa
 //       with KMT = 4 and no phase loop; only the epilogue differs: a stored octet's phase (sub-pixel offset) and destination
 //       octet come from a per-octet table, and an optional last "remainder" tile carries <= 4 channels of each phase in lane
 //       group q = phase slot, stored without the set exchange together with the appended raw-skip channels.
-template <int NT, int KMT, int NPH, bool DBG = false, int MAXP = 4, bool PK = false, bool D2S = false>
-__global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)) conv_f16x3(const HConvParams p) {
+// F6 = true: the cross terms run on the block-scaled fp6 matrix instruction (above).  A stage = up to two k-steps of x_hi * w_hi alone
+//       (hi weight images only, 1 KiB per k-step and N-tile) followed by ONE scaled MFMA per (M-tile, N-tile) that adds both cross terms
+//       of those k-steps (per N-tile a 2-KiB image of [64 lanes][24 bytes of e2m3 | scale byte] in two 16-byte planes): a 36-KiB weight
+//       block per stage.  Halving the matrix time of a stage exposes what it was hiding -- a stage cannot be shorter than the L2 -> LDS
+//       latency of the weight block issued one stage ahead (timing-only ablations, docs/experiments.md: with 2 / 3 of the matrix work
+//       removed the 4-wave kernel was 12 % faster) -- so the F6 form keeps the matrix time per stage where it was by doubling the K per
+//       stage, and pays for the 36-KiB blocks with the whole LDS of a CU: ONE workgroup of EIGHT waves per CU, waves 0..3 on tile 2 b,
+//       waves 4..7 on tile 2 b + 1 (each half with its own halo slots), both halves fed by the SAME weight stream -- half the L2 -> LDS
+//       weight traffic per tile as well.
+template <int NT, int KMT, int NPH, bool DBG = false, int MAXP = 4, bool PK = false, bool D2S = false, bool F6 = false>
+__global__ void __launch_bounds__(F6 ? 512 : 256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)) conv_f16x3(const HConvParams p) {
+    static_assert(!F6 || (NPH == 1 && !PK && !D2S && !DBG), "the fp6 cross-term form runs on the plain / per-phase kernel");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int kNW = F6 ? 2 * kWaves : kWaves;                       // waves that share a weight stream
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = F6 ? wave_all >> 2 : 0;                            // (F6) which of the workgroup's two tiles this wave works on
+    const int wave = F6 ? wave_all & 3 : wave_all;                      // the wave's place inside its tile: every geometry below
     const int q = lane >> 4;    // which 8-wide k group of the 16x16x32 MFMA this lane feeds
     const int li = lane & 15;   // pixel (A) / output channel (B, C/D) inside the tile
 
@@ -93,9 +188,10 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
         const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7, idx = bid >> 3;
         bid = xcd < r8 ? xcd * (q8 + 1) + idx : r8 * (q8 + 1) + (xcd - r8) * q8 + idx;
     }
+    if constexpr (F6) bid = 2 * bid + half;   // (a tile index past the launch's last one lands on image >= B: zero halo, nothing stored)
     const int tx_i = bid % p.tiles_x; bid /= p.tiles_x;
     const int ty_i = bid % p.tiles_y; bid /= p.tiles_y;
-    const int img0 = bid * p.imgs;
+    const int img0 = min(bid * p.imgs, p.B);
     const int y0 = ty_i * TH, x0 = tx_i * TWm;
     const HPhase& ph = p.ph[z_i];
     // K split (the trainer's launches on small batches: a deep layer of 8 images is 16 - 64 workgroups walking 80 - 240 k-steps at
@@ -133,7 +229,8 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
             for (int n = 0; n < NT; ++n) accs[h][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int lo_off = p.lo_off;   // byte offset of the lo planes
-    unsigned char* const Bl = smem + p.b_off;
+    unsigned char* const smem_h = smem + half * p.b_off;          // this tile's halo slots
+    unsigned char* const Bl = smem + (F6 ? 2 : 1) * p.b_off;
     const uint4* const wbase = ph.w + (size_t)nblk * ph.wblk_stride;
 
     // ---- load path.  Everything is LDS-DMA (no staging VGPRs) through buffer descriptors: `buffer_load_dwordx4 .. offen lds`
@@ -188,7 +285,7 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
         const int pixA = p.srcA[g1 ? 1 : 0];
         const int kqB = g1 ? kqB1 : kqB0;
         const __amdgpu_buffer_rsrc_t rh = g1 ? r1h : r0h, rl = g1 ? r1l : r0l;
-        unsigned char* const slot = smem + st.plane0 * p.slot_bytes;
+        unsigned char* const slot = smem_h + st.plane0 * p.slot_bytes;
         const int soff = st.oct0 * p.srcB[g1 ? 1 : 0];
         const bool kok = kq < st.noct;
 #pragma unroll
@@ -212,20 +309,20 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
     // per k-step of the 9-tile kernel 68 VALU + 90 SALU + 27 branches)
     int wq_np = 0, wq_soff = 0;
     unsigned char* wq_dst = Bl;
-    const int wq_w = wave * 1024;
+    const int wq_w = wave_all * 1024;
     auto wq_begin = [&](const HStage& st, int buf) {
         unsigned char* const wl = Bl + buf * p.wbuf_bytes;
-        if (wave == kWaves - 1 && lane < 4) UMX_BLDS16(rw, wl, lane16, st.woff * 16);
-        wq_np = st.nk * (NT * 2048);           // bytes of the block's 1-KiB pieces
+        if (wave_all == kNW - 1 && lane < 4) UMX_BLDS16(rw, wl, lane16, st.woff * 16);
+        wq_np = F6 ? NT * 4096 : st.nk * (NT * 2048);   // bytes of the block's 1-KiB pieces (F6: two k-steps of hi images + the fp6 images, always)
         wq_soff = st.woff * 16 + 64;
         wq_dst = wl + 64;
     };
     auto wq_one = [&](int c) {                 // the wave's c-th piece of the block
-        const int pc = wq_w + c * (kWaves * 1024);
+        const int pc = wq_w + c * (kNW * 1024);
         if (pc < wq_np) UMX_BLDS16(rw, wq_dst + pc, lane16, wq_soff + pc);
     };
     auto wq_drain = [&](int c0) {              // pieces c0, c0+1, .. (those the stage had no N-tile iteration for)
-        for (int pc = wq_w + c0 * (kWaves * 1024); pc < wq_np; pc += kWaves * 1024)
+        for (int pc = wq_w + c0 * (kNW * 1024); pc < wq_np; pc += kNW * 1024)
             UMX_BLDS16(rw, wq_dst + pc, lane16, wq_soff + pc);
     };
 
@@ -233,7 +330,7 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
     // folded on the host): loaded by LDS-DMA under the MFMAs of the last stage, into the weight buffer that stage frees
     const int ec_units = (p.head_K > 0 ? (4 + p.head_K) * (NT * 4) + 4 : NT * 16) + (D2S ? 16 : 0);   // uint4 per N-block
     auto issue_econst = [&](int buf) {
-        if (wave == kWaves - 1) {
+        if (wave_all == kNW - 1) {
             float* const dst = reinterpret_cast<float*>(Bl + buf * p.wbuf_bytes);
 #pragma unroll
             for (int i = 0; i < (8 * NT * 4 + 4 + 63) / 64; ++i)
@@ -296,7 +393,7 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
     // boundary, the next halo chunk into the other halo slot) are in flight while stage s runs its MFMAs.  One barrier
     // per stage: it orders "everyone's loads of stage s have landed" (each wave waits for its own first) and "everyone is
     // done computing stage s-1" (so the buffers stage s+1 loads into are free).
-    for (int s = 0; s < ph_nstages; ++s) {
+    auto stage_body = [&](const int s) {
         const HStage nxt = load_stage(ph_stage0 + (s + 1 < ph_nstages ? s + 1 : s));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (DBG && p.dbg) { const long long t_v = __builtin_amdgcn_s_memtime(); t_vm += t_v - t_a; }
@@ -314,9 +411,10 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
 
         const unsigned char* const wl = Bl + ((s + par0) & 1) * p.wbuf_bytes;
         // k-map of the stage up front: one LDS round trip per stage instead of one on every k-step's critical path
+        const int cur_nk = F6 ? (cur.nk & 0xff) : cur.nk;
         unsigned kbs[kStageK];
 #pragma unroll
-        for (int j = 0; j < kStageK; ++j)
+        for (int j = 0; j < (F6 ? 2 : kStageK); ++j)
             kbs[j] = (unsigned)*reinterpret_cast<const unsigned short*>(wl + (j * 4 + q) * 2) << 4;
         // the k-steps of this stage on one accumulator set (the phase loop is unrolled: static register indexing)
         // one k-step on accumulator set h.  SK (depth-to-space form, one block of four phases): the k-step's four (tap, octet) pairs
@@ -324,14 +422,15 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
         // no fragment reads and no MFMAs for them (lu0.convT: 5 of 9 tiles in every second k-step)
         auto kstep = [&](int h, int j, bool sk) {   // (sk: wave-uniform; the skippable tiles sit under one scalar branch each)
             constexpr int kLo = NT / 2, kHi = 2 * (NT / 2);
+            constexpr int kImg = F6 ? 1024 : 2048;    // bytes of one (k-step, N-tile) weight image: hi alone, or hi then lo
             auto live = [&](int n) { return !(D2S && sk && n >= kLo && n < kHi); };
-            const unsigned char* const bp = wl + 64 + j * (NT * 2048) + lane * 16;
-            const unsigned char* const ap = smem + kbs[j];
+            const unsigned char* const bp = wl + 64 + j * (NT * kImg) + lane * 16;
+            const unsigned char* const ap = smem_h + kbs[j];
             h8 ah[KMT], al[KMT];
 #pragma unroll
             for (int m = 0; m < KMT; ++m) {
                 ah[m] = *reinterpret_cast<const h8*>(ap + abase[m]);
-                al[m] = *reinterpret_cast<const h8*>(ap + abase[m] + lo_off);
+                if constexpr (!F6) al[m] = *reinterpret_cast<const h8*>(ap + abase[m] + lo_off);
             }
             // B (weight) fragments are streamed with a prefetch distance of two N-tiles (three (hi, lo) pairs live),
             // and the scheduler is asked for its DS-read / MFMA interleaving pipeline (iglp_opt 0): left to itself it
@@ -342,27 +441,92 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
 #pragma unroll
             for (int n = 0; n < kBPre && n < NT; ++n) {
                 if (!live(n)) continue;
-                bhq[n] = *reinterpret_cast<const h8*>(bp + n * 2048);
-                blq[n] = *reinterpret_cast<const h8*>(bp + n * 2048 + 1024);
+                bhq[n] = *reinterpret_cast<const h8*>(bp + n * kImg);
+                if constexpr (!F6) blq[n] = *reinterpret_cast<const h8*>(bp + n * kImg + 1024);
             }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 wq_one(j * NT + n);   // next stage's weight pieces, one per N-tile: spread under the MFMAs
                 __builtin_amdgcn_iglp_opt(0);
                 if (n + kBPre < NT && live(n + kBPre)) {
-                    bhq[(n + kBPre) % (kBPre + 1)] = *reinterpret_cast<const h8*>(bp + (n + kBPre) * 2048);
-                    blq[(n + kBPre) % (kBPre + 1)] = *reinterpret_cast<const h8*>(bp + (n + kBPre) * 2048 + 1024);
+                    bhq[(n + kBPre) % (kBPre + 1)] = *reinterpret_cast<const h8*>(bp + (n + kBPre) * kImg);
+                    if constexpr (!F6) blq[(n + kBPre) % (kBPre + 1)] = *reinterpret_cast<const h8*>(bp + (n + kBPre) * kImg + 1024);
                 }
                 if (!live(n)) continue;
-                const h8 bh = bhq[n % (kBPre + 1)], bl = blq[n % (kBPre + 1)];
+                const h8 bh = bhq[n % (kBPre + 1)];
 #pragma unroll
                 for (int m = 0; m < KMT; ++m) {
                     // weights are the A operand (rows = output channels), activations the B operand (columns =
                     // pixels): D[channel][pixel], so a lane ends up with 4 consecutive channels of one pixel
                     f32x4 c = accs[h][m][n];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[m], c, 0, 0, 0);
-                    if (!(PK && n == NT - 1)) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[m], c, 0, 0, 0);
+                    if constexpr (!F6) {
+                        const h8 bl = blq[n % (kBPre + 1)];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[m], c, 0, 0, 0);
+                        if (!(PK && n == NT - 1)) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[m], c, 0, 0, 0);
+                    }
                     accs[h][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[m], c, 0, 0, 0);
+                }
+            }
+        };
+        // the second half of an F6 stage: both cross terms of the stage's k-steps (0, 1) in one scaled MFMA per (M-tile, N-tile).
+        // This lane's K block: k-step q & 1, plane q >> 1 (hi: the x_hi * w_lo term; lo: x_lo * w_hi)
+        auto f6step = [&]() {
+            if constexpr (F6) {
+                const uint2 km = *reinterpret_cast<const uint2*>(wl + (q & 1) * 8);   // the k-step's four LDS slots
+                const unsigned pl = (q >> 1) ? (unsigned)lo_off : 0u;
+                const unsigned ko[4] = {((km.x & 0xffffu) << 4) + pl, ((km.x >> 16) << 4) + pl, ((km.y & 0xffffu) << 4) + pl, ((km.y >> 16) << 4) + pl};
+                i32x6 xb[KMT];
+                int sx[KMT];
+                // the first weight images on their way before the pixel blocks are converted
+                const unsigned char* const bpq = wl + 64 + 2 * NT * 1024 + lane * 16;   // (behind the room of two k-steps of hi images)
+                uint4 w0q[3];
+                uint4 w1q[3];
+#pragma unroll
+                for (int n = 0; n < 2 && n < NT; ++n) {
+                    w0q[n] = *reinterpret_cast<const uint4*>(bpq + n * 2048);
+                    w1q[n] = *reinterpret_cast<const uint4*>(bpq + n * 2048 + 1024);
+                }
+                // (timing-only ablations of the B stage, UMX_F6_ABLATE: bit 1 no pixel reads / conversion, bit 2 no scaled MFMAs)
+                if (p.f6 & 2) {
+#pragma unroll
+                    for (int m = 0; m < KMT; ++m) { xb[m] = (i32x6){0, 0, 0, 0, 0, 0}; sx[m] = 127; }
+                } else
+#pragma unroll
+                for (int m = 0; m < KMT; m += 2) {   // (two M-tiles at a time: all four blocks' fragments in flight at once would spill)
+                    h8 v[2][4];
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[b][t] = *reinterpret_cast<const h8*>(smem_h + ko[t] + abase[m + b]);
+                    i32x6 o[2];
+                    int sc2[2];
+                    quant_blocks_e2m3<2>(v, o, sc2);
+                    xb[m] = o[0]; xb[m + 1] = o[1];
+                    sx[m] = sc2[0]; sx[m + 1] = sc2[1];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const unsigned char* const bp = bpq;
+                constexpr int kBPre = 2;   // (prefetch distance of the weight images, like the binary16 k-steps; everything at once spills)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    wq_one(2 * NT + n);
+                    if (n + kBPre < NT) {
+                        w0q[(n + kBPre) % (kBPre + 1)] = *reinterpret_cast<const uint4*>(bp + (n + kBPre) * 2048);
+                        w1q[(n + kBPre) % (kBPre + 1)] = *reinterpret_cast<const uint4*>(bp + (n + kBPre) * 2048 + 1024);
+                    }
+                    const uint4 w0 = w0q[n % (kBPre + 1)], w1 = w1q[n % (kBPre + 1)];
+                    const i32x6 wa = (i32x6){(int)w0.x, (int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y};
+                    const int sa = (int)w1.z;
+                    // (inline assembly with the accumulator as ONE in/out operand: the builtin's destination is not tied to its C
+                    // operand, every result lands in a fresh register tuple and the allocator spills the accumulators moving them back
+                    // -- 109 .. 240 registers.  cbsz / blgp 2 = e2m3; op_sel 0: scale = byte 0 of the scale registers.  Operands come
+                    // from LDS reads and from conversions tens of instructions earlier; the results are next read behind a barrier.)
+                    if (p.f6 & 4) { asm volatile("" :: "v"(wa), "v"(sa)); continue; }
+#pragma unroll
+                    for (int m = 0; m < KMT; ++m)
+                        asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:2 blgp:2"
+                                     : "+v"(accs[0][m][n]) : "v"(wa), "v"(xb[m]), "v"(sa), "v"(sx[m]));
+                    __builtin_amdgcn_sched_barrier(0);   // (no iglp_opt here: with 4 MFMAs per image it hoists all nine images' reads to the top)
                 }
             }
         };
@@ -373,15 +537,17 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
         for (int h = 0; h < NPH; ++h) {
             if (NPH > 1 && cur.phase != h) continue;   // wave-uniform
 #pragma unroll
-            for (int j = 0; j < kStageK; ++j) {
-                if (j >= cur.nk) break;
+            for (int j = 0; j < (F6 ? 2 : kStageK); ++j) {
+                if (j >= cur_nk) break;
                 kstep(h, j, D2S && ((skips >> (8 * j)) & 1u) != 0u);
             }
         }
-        wq_drain(cur.nk * NT);
+        f6step();
+        wq_drain(F6 ? 3 * NT : cur_nk * NT);
         cur = nxt;
         if (DBG && p.dbg) { t_a = __builtin_amdgcn_s_memtime(); t_comp += t_a - t_b; }
-    }
+    };
+    for (int s = 0; s < ph_nstages; ++s) stage_body(s);
     // packed last N-tile: rows j (w_hi products) += rows j + 8 (w_lo products), i.e. lane l += lane l + 32.  The plain kernels do it
     // here, once; the fused-phase kernels where an accumulator is consumed (emit_t): their four accumulator sets moved to vector
     // registers at this point cost 19 registers, i.e. the third workgroup per CU of the 3-tile kernel
@@ -926,10 +1092,14 @@ __global__ void __launch_bounds__(256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)
     if (vmax >= 0x476a6000u) atomicOr(p.overflow_flag, 1);   // |v| >= 60000, infinity or NaN: binary16 range exceeded, the host reports it
 }
 
-template <int NT, int KMT, int NPH, bool DBG, int MAXP, bool PK = false, bool D2S = false>
+template <int NT, int KMT, int NPH, bool DBG, int MAXP, bool PK = false, bool D2S = false, bool F6 = false>
 static hipError_t launch_h_k(const HConvParams& p, hipStream_t stream) {
     const int img_groups = (p.B + p.imgs - 1) / p.imgs;
     dim3 grid((unsigned)(img_groups * p.tiles_y * p.tiles_x), (unsigned)p.nblocks, (unsigned)(NPH == 1 ? p.nphase : 1));
+    if (F6) {   // two tiles per workgroup of eight waves, one workgroup per CU (the whole LDS)
+        if (p.xcd_order == 2 || p.ksplit > 1) return hipErrorInvalidValue;
+        grid.x = (grid.x + 1) / 2;
+    }
     if (p.ksplit > 1) {   // (trainer: fp32 partial sums, one row of N-blocks per split)
         if (p.xcd_order == 2 || !p.dst_f32 || p.head_K > 0 || p.ksplit > kMaxKSplit) return hipErrorInvalidValue;
         grid.y *= (unsigned)p.ksplit;
@@ -939,12 +1109,12 @@ static hipError_t launch_h_k(const HConvParams& p, hipStream_t stream) {
         grid = dim3((unsigned)(8 * p.tiles_per_xcd) * grid.y * grid.z, 1, 1);
     }
     const size_t lds = (size_t)p.lds_bytes;
-    const void* kern = reinterpret_cast<const void*>(conv_f16x3<NT, KMT, NPH, DBG, MAXP, PK, D2S>);
+    const void* kern = reinterpret_cast<const void*>(conv_f16x3<NT, KMT, NPH, DBG, MAXP, PK, D2S, F6>);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((conv_f16x3<NT, KMT, NPH, DBG, MAXP, PK, D2S>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_f16x3<NT, KMT, NPH, DBG, MAXP, PK, D2S, F6>), grid, dim3(F6 ? 512 : 256), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -953,6 +1123,12 @@ template <int NT, int KMT, int NPH>
 static hipError_t launch_h_nt(const HConvParams& p, hipStream_t stream) {
     constexpr bool has4 = true, has12 = NT <= 5 && !(NPH == 4 && NT > 3);
     if (p.maxp != 4 && p.maxp != 12) return hipErrorInvalidValue;
+    if (p.f6) {   // fp6 cross terms: the 9-tile plain / per-phase kernel (the planner asks for nothing else)
+        if constexpr (NT == 9 && NPH == 1) {
+            if (p.maxp == 4 && !p.pk && !p.d2s && !p.dbg) return launch_h_k<NT, KMT, NPH, false, 4, false, false, true>(p, stream);
+        }
+        return hipErrorInvalidValue;
+    }
     if (p.d2s) {   // depth-to-space transposed convolution: the wide plain kernels, 4 pixel indices per wave
         if constexpr (NT >= 5 && NPH == 1) {
             if constexpr (NT == 9) {   // (stamped twin for the tile count the bench graph uses)

@@ -150,7 +150,7 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
             const double matrix_s = L.exec_flops * ns / 0.9e15;
             want2 = matrix_s > 0.0 && halo_bytes / matrix_s > 4e12;
         }
-        if (p.xcd_order == 1 && YZ > 1 && want2) {
+        if (p.xcd_order == 1 && YZ > 1 && want2 && !p.f6) {   // (the F6 form pairs x-adjacent tiles per workgroup: order 1 only)
             p.xcd_order = 2;
             p.ntiles_grid = ntiles;
             p.tiles_per_xcd = (ntiles + 7) / 8;
@@ -158,8 +158,8 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
     }
     char kn[64];
     // the instantiation as rocprofv3 names it (<NT, KMT, NPH>): bench.py groups the timed sites by kernel
-    snprintf(kn, sizeof kn, "conv_f16x3<%d, %d, %d, false, %d, %s, %s>", L.nt16, p.kmt, p.fused_phases ? 4 : 1, p.maxp, p.pk ? "true" : "false",
-             p.d2s ? "true" : "false");
+    snprintf(kn, sizeof kn, "conv_f16x3<%d, %d, %d, false, %d, %s, %s%s>", L.nt16, p.kmt, p.fused_phases ? 4 : 1, p.maxp, p.pk ? "true" : "false",
+             p.d2s ? "true" : "false", p.f6 ? ", true" : "");
     {
         // diagnostic: UMX_DEBUG_STAMPS=<layer name> prints the mean s_memtime segments of that layer's workgroups
         const char* const dbg_layer = getenv("UMX_DEBUG_STAMPS");
@@ -405,6 +405,30 @@ int umx_describe(const umx_hparams* hp, int* n_launches, double* flops_per_tile,
     return UMX_OK;
 }
 
+// Would umx_create(UMX_PREC_F16X3) take this model?  Host only (no device): the graph is built with zero weights and every launch goes
+// through the split-precision planner's search (plan_f16 in its dry form: geometry, N-tile choice, (chunk, stage) search against the LDS
+// budget).  UMX_OK, or UMX_ERR_INVALID with the first refused layer and the planner's reason in umx_last_error(NULL).
+int umx_plan_check(const umx_hparams* hp) {
+    std::string why;
+    int rc = check_hp(hp, &why);
+    if (rc) return fail(nullptr, rc, "%s", why.c_str());
+    std::unique_ptr<umx_ctx> ctx(new umx_ctx());
+    ctx->hp = *hp;
+    ctx->precision = UMX_PREC_F16X3;
+    std::vector<float> blob(blob_floats_needed(*hp), 0.f);
+    struct { std::vector<size_t> buf_floats; std::vector<std::pair<int, int>> buf_geom; size_t pos = 0; } b;
+    build_graph(*hp, blob.data(), &ctx->plan, &b.buf_floats, &b.buf_geom, &b.pos, conv_first_eligible(*hp));
+    const int head_src = ctx->plan.back().g[0].src;
+    for (auto& L : ctx->plan) {
+        if (L.head) continue;
+        make_d2s(L);
+        if (!conv_geometry(L, &why)) return fail(nullptr, UMX_ERR_INVALID, "%s: %s", L.name.c_str(), why.c_str());
+        if ((rc = plan_f16(ctx.get(), L, 0, L.dst == head_src, &ctx->plan.back(), &why, true)))
+            return fail(nullptr, rc, "%s: %s", L.name.c_str(), why.c_str());
+    }
+    return UMX_OK;
+}
+
 int umx_describe_graph(const umx_hparams* hp, char* json, size_t cap, size_t* needed) {
     std::string why;
     int rc = check_hp(hp, &why);
@@ -475,16 +499,21 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
         o2.precision = UMX_PREC_F32;
         rc = umx_create_opts(hp, weight_blob, blob_floats, &o2, out);
         if (rc) g_err = first + "; fp32 kernels: " + g_err;
+        // not silently: the exact-fp32 engine is ~4.6 x slower.  The note is what umx_last_error(ctx) returns until an error replaces it
+        else (*out)->err = "note: UMX_PREC_DEFAULT runs this model on the exact-fp32 engine, about 4.6 x slower than the split-precision "
+                           "kernels, whose planner refused it (" + first + ")";
         return rc;
     }
     const int device_ordinal = opts->device_ordinal, max_batch = opts->max_batch;
     int precision = opts->precision;
     if (precision == UMX_PREC_DEFAULT) {
         const char* e = getenv("UMX_PRECISION");
-        precision = (e && !strcmp(e, "f32")) ? UMX_PREC_F32 : UMX_PREC_F16X3;
+        precision = (e && !strcmp(e, "f32")) ? UMX_PREC_F32 : (e && !strcmp(e, "f16f6")) ? UMX_PREC_F16X3_F6 : UMX_PREC_F16X3;
     }
-    if (precision != UMX_PREC_F32 && precision != UMX_PREC_F16X3)
+    if (precision != UMX_PREC_F32 && precision != UMX_PREC_F16X3 && precision != UMX_PREC_F16X3_F6)
         return fail(nullptr, UMX_ERR_INVALID, "unknown precision %d", precision);
+    const bool f6 = precision == UMX_PREC_F16X3_F6;   // (internally: the split-precision engine with a flag)
+    if (f6) precision = UMX_PREC_F16X3;
     int act_shift = opts->act_shift;
     if (act_shift < 0) {
         const char* e = getenv("UMX_ACT_SHIFT");
@@ -517,6 +546,7 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
     ctx->device = device_ordinal;
     ctx->max_batch = max_batch;
     ctx->precision = precision;
+    ctx->f6 = f6;
     ctx->act_shift = act_shift;
     umx_ctx* c = ctx.get();
     HIP_TRY(nullptr, hipSetDevice(device_ordinal));
@@ -655,7 +685,7 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
     return UMX_OK;
 }
 
-int umx_precision_of(const umx_ctx* ctx) { return ctx ? ctx->precision : UMX_PREC_DEFAULT; }
+int umx_precision_of(const umx_ctx* ctx) { return !ctx ? UMX_PREC_DEFAULT : ctx->f6 ? UMX_PREC_F16X3_F6 : ctx->precision; }
 
 void umx_destroy(umx_ctx* ctx) {
     if (!ctx) return;

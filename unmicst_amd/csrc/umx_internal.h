@@ -173,6 +173,7 @@ struct umx_ctx {
     int site_gather = -1, site_stitch = -1, site_split = -1;
     // precision
     int precision = UMX_PREC_F16X3;
+    bool f6 = false;            // split precision with the cross terms of the deep layers on the block-scaled fp6 matrix instruction (UMX_PREC_F16X3_F6)
     int act_shift = 0;          // activations are stored times 2^act_shift in the (hi, lo) binary16 form
     float* d_tiles32 = nullptr; // fp32 staging of gathered tiles before the split (f16 path)
     int* d_flag = nullptr;      // binary16 range overflow flags (64 words): word 0 for the synchronous entry points, words 16 and

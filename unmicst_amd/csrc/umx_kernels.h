@@ -71,7 +71,7 @@ struct HStage {      // one pipeline stage: optional halo chunk load + one weigh
     short group;     // operand group whose halo chunk is loaded with this stage, or -1 (chunk already resident)
     short oct0;      // first octet (8 channels) of that group to load ...
     short noct;      // ... and how many ...
-    short nk;        // k-steps in this stage (<= kStageK)
+    short nk;        // k-steps in this stage (<= kStageK); F6 form: bit 8 set = "B" stage over the (nk & 0xff) k-steps of the stage before it
     short plane0;    // ... into halo slot plane0 (0 or 1: consecutive chunks alternate between the two slots)
     short phase;     // fused transposed convolution: the sub-pixel phase (accumulator set) this stage feeds
 };
@@ -134,6 +134,8 @@ struct HConvParams {
                                  //    constants, 64 ints: per block z [2 NT + 8]: element offset of (sub-pixel phase, destination
                                  //    octet) relative to output pixel (2y, 2x) per stored octet of the N axis (< 0: padding), then the
                                  //    same for the remainder tile's 4 lane groups, then their sub-pixel codes oy * 2 + ox
+    int f6;                      // 1: conv_f16x3's F6 form -- stages alternate between "A" (x_hi * w_hi, hi weight images only) and "B"
+                                 //    (HStage::nk bit 8: one block-scaled fp6 MFMA per tile pair for both cross terms of the A stage's k-steps)
     int pk;                      // 1: the last N-tile's weight image is [w_hi | w_lo] of its <= 8 real channels (conv_f16x3's PK form)
     int ksplit;                  // > 1 (trainer, fp32 output): the stage list is cut into `ksplit` runs of whole halo chunks, run s by workgroup
     short ks0[4][kMaxKSplit + 1];   //   rows [s * nblocks, (s + 1) * nblocks): stages [ks0[z][s], ks0[z][s + 1]) of phase z, relative to its

@@ -8,6 +8,39 @@
 
 namespace umx {
 
+// ---- OCP MX fp6 (e2m3) block of 32: shared scale 2^(floor(log2 amax) - 2) as an e8m0 byte, elements round-to-nearest-even and saturating
+// at 7.5, element i in bits [6 i, 6 i + 6) of the 24 bytes (the order v_cvt_scalef32_pk32_fp6_f16 writes and the scaled MFMA reads:
+// tools/probes/mx_fp6_semantics.hip)
+static int mx_pack_e2m3(const double (&v)[32], double amax, unsigned char (&out)[24]) {
+    memset(out, 0, sizeof out);
+    if (!(amax > 0.0) || !std::isfinite(amax)) return 127;
+    int e2;
+    std::frexp(amax, &e2);                        // amax = m * 2^e2, m in [0.5, 1): floor(log2 amax) = e2 - 1
+    int se = std::max(-127, std::min(127, e2 - 1 - 2));
+    const double inv = std::ldexp(1.0, -se);
+    for (int i = 0; i < 32; ++i) {
+        const double a = std::fabs(v[i]) * inv;
+        unsigned code;
+        if (a >= 7.5) code = 31;
+        else {
+            int eb = 0;                            // binade: [0, 1) subnormal step 1/8, [1, 2) 1/8, [2, 4) 1/4, [4, 8) 1/2
+            if (a >= 4.0) eb = 3; else if (a >= 2.0) eb = 2; else if (a >= 1.0) eb = 1;
+            const double step = eb <= 1 ? 0.125 : eb == 2 ? 0.25 : 0.5;
+            const double qv = std::nearbyint(a / step) * step;   // (default rounding mode: to nearest even)
+            if (qv >= 7.5) code = 31;
+            else if (qv < 1.0) code = (unsigned)std::lround(qv * 8.0);
+            else {
+                int ee = qv >= 4.0 ? 3 : qv >= 2.0 ? 2 : 1;
+                code = (unsigned)(ee << 3) | (unsigned)std::lround((qv / std::ldexp(1.0, ee - 1) - 1.0) * 8.0);
+            }
+        }
+        if (std::signbit(v[i]) && code) code |= 32u;
+        for (int b = 0; b < 6; ++b)
+            if ((code >> b) & 1u) out[(6 * i + b) / 8] |= (unsigned char)(1u << ((6 * i + b) % 8));
+    }
+    return se + 127;
+}
+
 // ---- split-precision plan of one conv launch: chunking of the input octets, k-step table, stage table, weight images
 // (layout documented in umx_conv_f16.hip).  Reads the fp32 packing [tap][Cp][Np] produced by the Builder.
 int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch* head, std::string* why, bool dry) {
@@ -75,6 +108,13 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     h.d2s = L.d2s;
     h.d2s_mix = L.d2s && L.d2s_R > 0;
     h.pk = (!L.d2s && !L.train && h.nblocks == 1 && nt16 >= 2 && nt16 <= 5 && last_real >= 1 && last_real <= 8 && !getenv("UMX_DEBUG_STAMPS")) ? 1 : 0;
+    // fp6 cross terms (conv_f16x3's F6 form): the 9-tile plain / per-phase kernel on the layers at <= 1/4 of the input resolution --
+    // where tests/fp8_cross_term_report.py holds 1e-4 with a 4 x margin on the reference's trained weights (the full-resolution layers do not)
+    const bool f6 = ctx->f6 && !fused && !L.d2s && !L.train && !out_f32 && nt16 == kMaxNT16 && !h.pk && L.H * 4 <= ctx->hp.imSize &&
+                    !getenv("UMX_DEBUG_STAMPS");
+    h.f6 = f6 ? 1 : 0;
+    if (f6)
+        if (const char* e = getenv("UMX_F6_ABLATE")) h.f6 |= (atoi(e) & 3) << 1;   // timing-only: wrong results (conv_f16x3, f6step)
     h.outH = L.outH; h.outW = L.outW; h.pool = L.pool; h.act = L.act;
     if (h.nhalo > kHaloChunks * 64) { *why = "halo too large for the split-precision kernel"; return UMX_ERR_INVALID; }
     h.plane_slots = round_up(h.nhalo, 16);
@@ -142,11 +182,21 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
             }
         }
     }
+    // last resort: the whole LDS of a CU for one workgroup.  Tiny layers under big filters (2 x 2 / 4 x 4 pixels, 5 x 5 taps, 16 images
+    // per tile: a 1024-pixel halo) fit nothing smaller; they are a few percent of such a model's work, and without them the whole model
+    // falls back to the exact-fp32 engine (4.6 x slower end to end)
+    {
+        const int mp_last = attempts.empty() ? 4 : attempts.back().maxp;
+        attempts.push_back({mp_last, 160 * 1024 - 512, 1 << 30});
+    }
     const int nwaves = kWaves;
     h.kmt = fused ? 2 : kMT;
     // dynamic LDS of a plan: halo slots (hi + lo) | weight buffer 0 | weight buffer 1 (the epilogue stores from registers)
+    // (F6 form: a stage holds two k-steps of hi images and one 2-KiB fp6 image per N-tile; a workgroup is two tiles with their own halo
+    // slots over one pair of weight buffers, and has its CU's whole LDS)
+    auto wbuf_of = [&](int ss) { return 64 + nt16 * (f6 ? 4096 : ss * 2048); };
     auto lds_total = [&](int nslots, int oc, int ss, int plane_pair_bytes) {
-        return nslots * oc * plane_pair_bytes + 2 * (64 + ss * nt16 * 2048);
+        return (f6 ? 2 : 1) * nslots * oc * plane_pair_bytes + 2 * wbuf_of(ss);
     };
 
     // One stage list (= one kernel phase, or the whole fused transposed convolution) for a given (OC, S, slot base E):
@@ -206,6 +256,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                     if (steps_out)
                         for (int j = 0; j < st.nk; ++j)
                             steps_out->push_back(std::vector<Pair>(pairs.begin() + (k + j) * 4, pairs.begin() + (k + j) * 4 + 4));
+                    if (f6) st.nk = (short)(st.nk | 0x100);   // (F6 form: the stage ends with the scaled MFMAs of its k-steps' cross terms)
                     if (stages_out) stages_out->push_back(st);
                 }
             }
@@ -220,7 +271,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     double bestCost = 1e30;
     for (size_t at = 0; at < attempts.size() && !bestOC; ++at) {
     maxp = attempts[at].maxp;
-    const int lds_cap = attempts[at].cap;
+    const int lds_cap = f6 ? 160 * 1024 - 512 : attempts[at].cap;
     for (int OC = 1; OC <= 9; ++OC) {
         int nslots = 1;
         double sectors = 0;   // 64-byte memory requests of the halo loads of one workgroup
@@ -231,7 +282,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         }
         // the kernel keeps one pixel index per (wave, piece of a chunk) in registers
         if (((h.nhalo + 64 / OC - 1) / (64 / OC) + nwaves - 1) / nwaves > maxp) continue;
-        for (int S = 1; S <= kStageK; ++S) {
+        for (int S = (f6 ? 2 : 1); S <= (f6 ? 2 : kStageK); ++S) {
             const int lds = lds_total(nslots, OC, S, plane_pair);
             if (lds > lds_cap) continue;
             int ksteps = 0, nchunks = 0;
@@ -242,7 +293,8 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
             }
             // executed k-steps (exact) with a barrier/latency charge per stage, a charge per halo chunk load (measured
             // ~0.35 k-steps on the deep layers) and per 64-byte halo request (halo reloads measured at 8-22 % of a layer)
-            const double cost = (ksteps * (1.0 + 0.30 / S) + 0.35 * nchunks + sectors / 1500.0) * ((OC & 1) ? 1.0 : 1.03);
+            // (F6 form: the chunking the 3-product plan would choose -- its k-steps are cheaper, not its halo)
+            const double cost = (ksteps * (1.0 + 0.30 / (f6 ? 1 : S)) + 0.35 * nchunks + sectors / 1500.0) * ((OC & 1) ? 1.0 : 1.03);
             if (nchunks > attempts[at].max_chunks) continue;
             if (cost < bestCost) { bestCost = cost; bestOC = OC; bestS = S; bestSlots = nslots; }
         }
@@ -263,7 +315,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
             char nm[64];
             int oc = 0, ss = 0, mp = 0;
             const int nf = sscanf(item.c_str(), "%63[^:]:%d:%d:%d", nm, &oc, &ss, &mp);
-            if (nf >= 3 && L.name == nm && oc >= 1 && oc <= 9 && ss >= 1 && ss <= kStageK) {
+            if (nf >= 3 && L.name == nm && oc >= 1 && oc <= 9 && ss >= 1 && ss <= (f6 ? 2 : kStageK)) {
                 if (nf == 4 && (mp == 4 || (mp == 12 && nt16 <= 5)) && !fused) maxp = mp;
                 int nslots = 1;
                 for (int list = 0; list < nlists; ++list)
@@ -290,9 +342,9 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     h.slot_bytes = h.plane_slots * OC * 16;
     h.lo_off = bestSlots * h.slot_bytes;
     h.b_off = 2 * h.lo_off;
-    h.wbuf_bytes = 64 + S * nt16 * 2048;
+    h.wbuf_bytes = wbuf_of(S);
     h.xcd_order = 1;   // XCD-aware tile order (run_launch_f16 turns it into order 2 where its rule says so)
-    h.lds_bytes = h.b_off + 2 * h.wbuf_bytes;
+    h.lds_bytes = (f6 ? 2 : 1) * h.b_off + 2 * h.wbuf_bytes;
 
     std::vector<HStage> stages;
     std::vector<std::vector<_Float16>> wimg(nlists);   // per stage list: [nblk][stage blocks] halves
@@ -309,7 +361,8 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         size_t per_blk = 0;   // halves
         for (int si = h.ph[list].stage0; si < (int)stages.size(); ++si) {
             stages[si].woff = (int)(per_blk / 8);
-            per_blk += 32 + (size_t)stages[si].nk * nt16 * 2 * 512;
+            if (!f6) per_blk += 32 + (size_t)stages[si].nk * nt16 * 2 * 512;
+            else per_blk += 32 + (size_t)nt16 * 2048;   // two k-steps of hi images (1 KiB each) + one 2-KiB fp6 image per N-tile
         }
         h.ph[list].wblk_stride = (int)(per_blk / 8);
         std::vector<_Float16>& W = wimg[list];
@@ -320,7 +373,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         std::vector<size_t> ks_of;   // first k-step of each stage of this list
         {
             size_t k0 = 0;
-            for (int si = h.ph[list].stage0; si < (int)stages.size(); ++si) { ks_of.push_back(k0); k0 += (size_t)stages[si].nk; }
+            for (int si = h.ph[list].stage0; si < (int)stages.size(); ++si) { ks_of.push_back(k0); k0 += (size_t)(stages[si].nk & 0xff); }
         }
         const bool d2s_skip = L.d2s && L.d2s_npb == 4;
         std::atomic<bool> bad_slot{false};
@@ -328,10 +381,58 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
         auto fill_task = [&](int task) {
             const int nb = task / nst, si = h.ph[list].stage0 + task % nst;
             size_t ks = ks_of[(size_t)(task % nst)];
+            if (f6) {
+                // the stage's fp6 images (behind the room of two k-steps of hi images): per N-tile [64 lanes] x {24 bytes of e2m3, scale byte}
+                // in two 16-byte planes.  Lane (row, qb): K block = k-step qb & 1 of the stage; qb < 2: w_lo (multiplies x_hi), qb >= 2: w_hi
+                // (multiplies x_lo) -- the kernel's pixel operand.  A lone k-step's partner block is zero.
+                const int nk = stages[si].nk & 0xff;
+                const size_t blk = nb * per_blk + (size_t)stages[si].woff * 8;
+                unsigned char* const img = reinterpret_cast<unsigned char*>(&W[blk + 32 + (size_t)2 * nt16 * 512]);
+                for (int n = 0; n < nt16; ++n)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int row = lane & 15, qb = lane >> 4, jj = qb & 1;
+                        const int co = nb * nt16 * 16 + n * 16 + row;
+                        double v32[32];
+                        double amax = 0.0;
+                        for (int i = 0; i < 32; ++i) v32[i] = 0.0;
+                        if (jj < nk && co < L.Cout)
+                            for (int pp = 0; pp < 4; ++pp) {
+                                const Pair& pr2 = steps[ks + jj][pp];
+                                if (pr2.tap < 0) continue;
+                                const Group& G = L.g[pr2.gi];
+                                const int Cp = round_up(G.C, 4);
+                                for (int e = 0; e < 8; ++e) {
+                                    const int c = pr2.oct * 8 + e;
+                                    if (c >= G.C) continue;
+                                    const float v = G.packed[pr2.ph][((size_t)pr2.tap * Cp + c) * L.Np + co] * wscale;
+                                    const _Float16 hi = (_Float16)v;
+                                    const double t = qb < 2 ? (double)(float)(_Float16)(v - (float)hi) : (double)(float)hi;
+                                    v32[pp * 8 + e] = t;
+                                    amax = std::max(amax, std::fabs(t));
+                                }
+                            }
+                        unsigned char bytes[24];
+                        const int e8 = mx_pack_e2m3(v32, amax, bytes);
+                        unsigned char* const p0 = img + (size_t)n * 2048 + (size_t)lane * 16;
+                        unsigned char* const p1 = p0 + 1024;
+                        memcpy(p0, bytes, 16);
+                        memcpy(p1, bytes + 16, 8);
+                        p1[8] = (unsigned char)e8; p1[9] = p1[10] = p1[11] = 0;
+                        memset(p1 + 12, 0, 4);
+                    }
+            }
             {
                 const size_t blk = nb * per_blk + (size_t)stages[si].woff * 8;
                 unsigned short* const hdr = reinterpret_cast<unsigned short*>(&W[blk]);
-                for (int j = 0; j < stages[si].nk; ++j, ++ks) {
+                const int nk_st = stages[si].nk & 0xff;
+                if (f6 && nk_st == 1) {   // (the scaled MFMA's lanes of the absent partner k-step read the lone k-step's slots; their weights are zero)
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const Pair& pr2 = steps[ks][qq];
+                        const auto& tp = L.g[pr2.gi].taps[pr2.ph][pr2.tap < 0 ? 0 : pr2.tap];
+                        hdr[4 + qq] = (unsigned short)(pr2.slot * (h.plane_slots * OC) + ((tp.first - g.ymin) * h.hw + (tp.second - g.xmin)) * OC + pr2.k);
+                    }
+                }
+                for (int j = 0; j < nk_st; ++j, ++ks) {
                     for (int qq = 0; qq < 4; ++qq) {
                         const Pair& pr2 = steps[ks][qq];
                         const auto& tp = L.g[pr2.gi].taps[pr2.ph][pr2.tap < 0 ? 0 : pr2.tap];
@@ -359,7 +460,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                             const bool packed = h.pk && n == nt16 - 1;   // rows 0..7: w_hi, rows 8..15: w_lo of the same 8 channels
                             const int row = lane & 15;
                             const int co = nb * nt16 * 16 + n * 16 + (packed ? (row & 7) : row);
-                            const size_t base = blk + 32 + (((size_t)j * nt16 + n) * 2) * 512 + (size_t)lane * 8;
+                            const size_t base = blk + 32 + (((size_t)j * nt16 + n) * (f6 ? 1 : 2)) * 512 + (size_t)lane * 8;
                             if (L.train) {   // by reference: the trainer fills this unit from its device-resident fp32 operand
                                 const int nv = std::min(8, G.C - pr2.oct * 8);
                                 if (nv > 0 && co < L.Cout)
@@ -374,7 +475,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                                 const _Float16 hi = (_Float16)v;
                                 if (packed) { W[base + e] = row < 8 ? hi : (_Float16)(v - (float)hi); continue; }   // (no lo image)
                                 W[base + e] = hi;
-                                W[base + 512 + e] = (_Float16)(v - (float)hi);
+                                if (!f6) W[base + 512 + e] = (_Float16)(v - (float)hi);   // (F6 form: the lo part lives in the B stage's image)
                             }
                         }
                 }
@@ -499,7 +600,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     }
     if (getenv("UMX_DEBUG_PLAN"))
         fprintf(stderr, "[umx plan] %-12s %sNT %d x %d blocks, OC %d x %d halo slot(s), S %d, LDS %d B, k-steps %d, wshift %d\n",
-                L.name.c_str(), fused ? (h.pk ? "fused-phase packed " : "fused-phase ") : (h.pk ? "packed " : ""), nt16, h.nblocks, OC, bestSlots, S, h.lds_bytes, L.n_ksteps,
+                L.name.c_str(), fused ? (h.pk ? "fused-phase packed " : "fused-phase ") : (h.pk ? "packed " : h.f6 ? "fp6-cross " : ""), nt16, h.nblocks, OC, bestSlots, S, h.lds_bytes, L.n_ksteps,
                 L.wshift);
     h.inv_imgplane = 1.f / (float)h.imgplane;
     h.inv_hw = 1.f / (float)h.hw;
@@ -521,6 +622,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     }
     L.exec_flops = 2.0 * 3.0 * (double)L.n_ksteps * 32.0 * Np16 * L.H * L.W;   // MFMA work incl. split and padding
     if (h.pk) L.exec_flops -= 2.0 * (double)L.n_ksteps * 32.0 * 16.0 * L.H * L.W;    // (the packed N-tile takes 2 products)
+    if (h.f6) L.exec_flops *= 0.5;   // matrix time in binary16-MFMA units: 1 (x_hi * w_hi) + 0.5 (one 16-cycle scaled MFMA per two k-steps)
     return UMX_OK;
 }
 

@@ -15,8 +15,9 @@ from . import build as _build
 from .model import HParams
 
 UMX_OK = 0
-PREC_DEFAULT, PREC_F32, PREC_F16X3 = 0, 1, 2      # enum umx_precision
-PRECISIONS = {"default": PREC_DEFAULT, "f32": PREC_F32, "f16x3": PREC_F16X3}
+PREC_DEFAULT, PREC_F32, PREC_F16X3, PREC_F16X3_F6 = 0, 1, 2, 3      # enum umx_precision
+PRECISIONS = {"default": PREC_DEFAULT, "f32": PREC_F32, "f16x3": PREC_F16X3, "f16f6": PREC_F16X3_F6}
+ERR_INVALID, ERR_HIP = 1, 4   # UMX_ERR_INVALID, UMX_ERR_HIP
 ERR_RANGE = 6   # UMX_ERR_RANGE
 MODE_ACCUMULATE, MODE_REPLACE = 0, 1
 STITCH_FP16_COMPAT, STITCH_FP32 = 0, 1
@@ -29,7 +30,7 @@ EXPORTS = [
     "umx_tiff_packbits_decode", "umx_shard_unique_id", "umx_shard_init", "umx_shard_init_transport", "umx_shard_fini", "umx_shard_plan",
     "umx_infer_image_sharded_dev", "umx_infer_image_sharded_raw", "umx_infer_image_sharded_raw_submit",
     "umx_band_tiles_dev", "umx_stitch_dev", "umx_profile_enable", "umx_profile_read", "umx_prof_entry_size", "umx_test_double_to_half",
-    "umx_describe", "umx_describe_graph", "umx_version",
+    "umx_describe", "umx_describe_graph", "umx_plan_check", "umx_version",
 ]
 
 
@@ -295,6 +296,16 @@ def describe_graph(hp: HParams) -> dict:
     return json.loads(buf.value.decode())
 
 
+def plan_check(hp: HParams) -> str:
+    """umx_plan_check: "" if the split-precision planner takes every layer of this model, else the first refused layer and why.  Host only."""
+    h = _hp_struct(hp)
+    L = load()
+    L.umx_plan_check.restype = ctypes.c_int
+    L.umx_plan_check.argtypes = [ctypes.c_void_p]
+    rc = L.umx_plan_check(ctypes.byref(h))
+    return "" if rc == 0 else L.umx_last_error(None).decode()
+
+
 def auto_batch(hp: HParams, arena_bytes: float = 12 * 2 ** 30) -> int:
     """Tiles per launch group for a model: enough pixels per launch to fill the chip at the deep, small layers (a 64 x 64-pixel
     tile is 4 x 4 pixels at the solo model's bottom: 256 tiles are 160 workgroups on 512 slots) -- 2^24 pixels per group, i.e.
@@ -359,7 +370,13 @@ class Engine:
             raise UmxError(rc, self._L.umx_last_error(None).decode())
         self.device = device
         self.max_batch = max_batch
-        self.precision = {PREC_F32: "f32", PREC_F16X3: "f16x3"}[self._L.umx_precision_of(self._ctx)]
+        self.precision = {PREC_F32: "f32", PREC_F16X3: "f16x3", PREC_F16X3_F6: "f16f6"}[self._L.umx_precision_of(self._ctx)]
+        self.note = ""
+        if precision == "default" and self.precision == "f32":   # the planner of the fast kernels refused the model: say so
+            import warnings
+            self.note = self._L.umx_last_error(self._ctx).decode()
+            if self.note.startswith("note:"):   # (not when UMX_PRECISION=f32 asked for it)
+                warnings.warn(self.note, RuntimeWarning, stacklevel=2)
 
     # -- lifetime
     def close(self) -> None:
