@@ -563,7 +563,7 @@ def test_forward_tiles_random_hyper_parameters(prec):
     planner covers fewer tiny-layer geometries than the fp32 kernels; "default" picks whichever covers the graph."""
     from oracle import oracle
     ran = 0
-    need = {"f32": 10, "default": 10, "f16x3": 4}[prec]
+    need = {"f32": 10, "default": 10, "f16x3": 8}[prec]   # (f16x3: 11 of 14 by the host-side planner check, tests/test_plan_check_cpu.py)
     for i, hp in enumerate(_random_hps(14, 2026)):
         blob = model.random_blob(hp, seed=100 + i)
         x = np.random.default_rng(i).normal(size=(3, hp.imSize, hp.imSize, hp.nChannels)).astype(np.float32)

@@ -151,17 +151,21 @@ constexpr int conv_f16x3_waves(int NT, int KMT, int NPH, int MAXP, bool D2S = fa
 //       stage, and pays for the 36-KiB blocks with the whole LDS of a CU: ONE workgroup of EIGHT waves per CU, waves 0..3 on tile 2 b,
 //       waves 4..7 on tile 2 b + 1 (each half with its own halo slots), both halves fed by the SAME weight stream -- half the L2 -> LDS
 //       weight traffic per tile as well.
-template <int NT, int KMT, int NPH, bool DBG = false, int MAXP = 4, bool PK = false, bool D2S = false, bool F6 = false>
-__global__ void __launch_bounds__(F6 ? 512 : 256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)) conv_f16x3(const HConvParams p) {
-    static_assert(!F6 || (NPH == 1 && !PK && !D2S && !DBG), "the fp6 cross-term form runs on the plain / per-phase kernel");
+// W2 = true: ONE workgroup of EIGHT waves per CU over TWO x-adjacent tiles (waves 0..3 on tile 2 b, waves 4..7 on tile 2 b + 1, each half
+//       with its own halo slots), both fed by the same weight stream, with the CU's whole LDS: half the L2 -> LDS weight bytes per tile,
+//       and room for two k-steps per stage (half the barriers) where the four-wave form holds one.  The F6 form implies it.
+template <int NT, int KMT, int NPH, bool DBG = false, int MAXP = 4, bool PK = false, bool D2S = false, bool F6 = false, bool W2 = F6>
+__global__ void __launch_bounds__(W2 ? 512 : 256, conv_f16x3_waves(NT, KMT, NPH, MAXP, D2S)) conv_f16x3(const HConvParams p) {
+    static_assert(!F6 || (NPH == 1 && !PK && !D2S && !DBG && W2), "the fp6 cross-term form runs on the plain / per-phase kernel (no stamped twin: it spills 426 registers)");
+    static_assert(!W2 || (NPH == 1 && !D2S && !DBG), "two tiles per workgroup: the plain / per-phase kernel");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    constexpr int kNW = F6 ? 2 * kWaves : kWaves;                       // waves that share a weight stream
+    constexpr int kNW = W2 ? 2 * kWaves : kWaves;                       // waves that share a weight stream
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = F6 ? wave_all >> 2 : 0;                            // (F6) which of the workgroup's two tiles this wave works on
-    const int wave = F6 ? wave_all & 3 : wave_all;                      // the wave's place inside its tile: every geometry below
+    const int half = W2 ? wave_all >> 2 : 0;                            // (W2) which of the workgroup's two tiles this wave works on
+    const int wave = W2 ? wave_all & 3 : wave_all;                      // the wave's place inside its tile: every geometry below
     const int q = lane >> 4;    // which 8-wide k group of the 16x16x32 MFMA this lane feeds
     const int li = lane & 15;   // pixel (A) / output channel (B, C/D) inside the tile
 
@@ -188,7 +192,7 @@ __global__ void __launch_bounds__(F6 ? 512 : 256, conv_f16x3_waves(NT, KMT, NPH,
         const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, xcd = bid & 7, idx = bid >> 3;
         bid = xcd < r8 ? xcd * (q8 + 1) + idx : r8 * (q8 + 1) + (xcd - r8) * q8 + idx;
     }
-    if constexpr (F6) bid = 2 * bid + half;   // (a tile index past the launch's last one lands on image >= B: zero halo, nothing stored)
+    if constexpr (W2) bid = 2 * bid + half;   // (a tile index past the launch's last one lands on image >= B: zero halo, nothing stored)
     const int tx_i = bid % p.tiles_x; bid /= p.tiles_x;
     const int ty_i = bid % p.tiles_y; bid /= p.tiles_y;
     const int img0 = min(bid * p.imgs, p.B);
@@ -230,7 +234,7 @@ __global__ void __launch_bounds__(F6 ? 512 : 256, conv_f16x3_waves(NT, KMT, NPH,
 
     const int lo_off = p.lo_off;   // byte offset of the lo planes
     unsigned char* const smem_h = smem + half * p.b_off;          // this tile's halo slots
-    unsigned char* const Bl = smem + (F6 ? 2 : 1) * p.b_off;
+    unsigned char* const Bl = smem + (W2 ? 2 : 1) * p.b_off;
     const uint4* const wbase = ph.w + (size_t)nblk * ph.wblk_stride;
 
     // ---- load path.  Everything is LDS-DMA (no staging VGPRs) through buffer descriptors: `buffer_load_dwordx4 .. offen lds`
@@ -1092,11 +1096,11 @@ __global__ void __launch_bounds__(F6 ? 512 : 256, conv_f16x3_waves(NT, KMT, NPH,
     if (vmax >= 0x476a6000u) atomicOr(p.overflow_flag, 1);   // |v| >= 60000, infinity or NaN: binary16 range exceeded, the host reports it
 }
 
-template <int NT, int KMT, int NPH, bool DBG, int MAXP, bool PK = false, bool D2S = false, bool F6 = false>
+template <int NT, int KMT, int NPH, bool DBG, int MAXP, bool PK = false, bool D2S = false, bool F6 = false, bool W2 = F6>
 static hipError_t launch_h_k(const HConvParams& p, hipStream_t stream) {
     const int img_groups = (p.B + p.imgs - 1) / p.imgs;
     dim3 grid((unsigned)(img_groups * p.tiles_y * p.tiles_x), (unsigned)p.nblocks, (unsigned)(NPH == 1 ? p.nphase : 1));
-    if (F6) {   // two tiles per workgroup of eight waves, one workgroup per CU (the whole LDS)
+    if (W2) {   // two tiles per workgroup of eight waves, one workgroup per CU (the whole LDS)
         if (p.xcd_order == 2 || p.ksplit > 1) return hipErrorInvalidValue;
         grid.x = (grid.x + 1) / 2;
     }
@@ -1109,12 +1113,12 @@ static hipError_t launch_h_k(const HConvParams& p, hipStream_t stream) {
         grid = dim3((unsigned)(8 * p.tiles_per_xcd) * grid.y * grid.z, 1, 1);
     }
     const size_t lds = (size_t)p.lds_bytes;
-    const void* kern = reinterpret_cast<const void*>(conv_f16x3<NT, KMT, NPH, DBG, MAXP, PK, D2S, F6>);
+    const void* kern = reinterpret_cast<const void*>(conv_f16x3<NT, KMT, NPH, DBG, MAXP, PK, D2S, F6, W2>);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((conv_f16x3<NT, KMT, NPH, DBG, MAXP, PK, D2S, F6>), grid, dim3(F6 ? 512 : 256), lds, stream, p);
+    hipLaunchKernelGGL((conv_f16x3<NT, KMT, NPH, DBG, MAXP, PK, D2S, F6, W2>), grid, dim3(W2 ? 512 : 256), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -1126,6 +1130,12 @@ static hipError_t launch_h_nt(const HConvParams& p, hipStream_t stream) {
     if (p.f6) {   // fp6 cross terms: the 9-tile plain / per-phase kernel (the planner asks for nothing else)
         if constexpr (NT == 9 && NPH == 1) {
             if (p.maxp == 4 && !p.pk && !p.d2s && !p.dbg) return launch_h_k<NT, KMT, NPH, false, 4, false, false, true>(p, stream);
+        }
+        return hipErrorInvalidValue;
+    }
+    if (p.w2) {   // two tiles per eight-wave workgroup: the 9-tile plain / per-phase kernel (the planner asks for nothing else)
+        if constexpr (NT == 9 && NPH == 1) {
+            if (p.maxp == 4 && !p.pk && !p.d2s && !p.dbg) return launch_h_k<NT, KMT, NPH, false, 4, false, false, false, true>(p, stream);
         }
         return hipErrorInvalidValue;
     }

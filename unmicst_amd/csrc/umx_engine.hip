@@ -150,7 +150,7 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
             const double matrix_s = L.exec_flops * ns / 0.9e15;
             want2 = matrix_s > 0.0 && halo_bytes / matrix_s > 4e12;
         }
-        if (p.xcd_order == 1 && YZ > 1 && want2 && !p.f6) {   // (the F6 form pairs x-adjacent tiles per workgroup: order 1 only)
+        if (p.xcd_order == 1 && YZ > 1 && want2 && !p.w2) {   // (the W2 / F6 forms pair x-adjacent tiles per workgroup: order 1 only)
             p.xcd_order = 2;
             p.ntiles_grid = ntiles;
             p.tiles_per_xcd = (ntiles + 7) / 8;
@@ -159,12 +159,14 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
     char kn[64];
     // the instantiation as rocprofv3 names it (<NT, KMT, NPH>): bench.py groups the timed sites by kernel
     snprintf(kn, sizeof kn, "conv_f16x3<%d, %d, %d, false, %d, %s, %s%s>", L.nt16, p.kmt, p.fused_phases ? 4 : 1, p.maxp, p.pk ? "true" : "false",
-             p.d2s ? "true" : "false", p.f6 ? ", true" : "");
+             p.d2s ? "true" : "false", p.f6 ? ", true" : p.w2 ? ", false, true" : "");
     {
         // diagnostic: UMX_DEBUG_STAMPS=<layer name> prints the mean s_memtime segments of that layer's workgroups
         const char* const dbg_layer = getenv("UMX_DEBUG_STAMPS");
         if (dbg_layer && L.name == dbg_layer) {
-            const size_t nwg = (size_t)((ns + p.imgs - 1) / p.imgs) * p.tiles_y * p.tiles_x * p.nblocks * (p.fused_phases ? 1 : p.nphase);
+            size_t nwg = (size_t)((ns + p.imgs - 1) / p.imgs) * p.tiles_y * p.tiles_x;
+            if (p.w2) nwg = (nwg + 1) / 2;   // (two tiles per workgroup)
+            nwg *= (size_t)p.nblocks * (p.fused_phases ? 1 : p.nphase);
             long long* d = nullptr;
             HIP_TRY(ctx, hipMalloc((void**)&d, nwg * 7 * sizeof(long long)));
             p.dbg = d;

@@ -134,6 +134,7 @@ struct HConvParams {
                                  //    constants, 64 ints: per block z [2 NT + 8]: element offset of (sub-pixel phase, destination
                                  //    octet) relative to output pixel (2y, 2x) per stored octet of the N axis (< 0: padding), then the
                                  //    same for the remainder tile's 4 lane groups, then their sub-pixel codes oy * 2 + ox
+    int w2;                      // 1: conv_f16x3's W2 form (two tiles per eight-wave workgroup, one workgroup per CU); set with f6 as well
     int f6;                      // 1: conv_f16x3's F6 form -- stages alternate between "A" (x_hi * w_hi, hi weight images only) and "B"
                                  //    (HStage::nk bit 8: one block-scaled fp6 MFMA per tile pair for both cross terms of the A stage's k-steps)
     int pk;                      // 1: the last N-tile's weight image is [w_hi | w_lo] of its <= 8 real channels (conv_f16x3's PK form)

@@ -113,6 +113,11 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     const bool f6 = ctx->f6 && !fused && !L.d2s && !L.train && !out_f32 && nt16 == kMaxNT16 && !h.pk && L.H * 4 <= ctx->hp.imSize &&
                     !getenv("UMX_DEBUG_STAMPS");
     h.f6 = f6 ? 1 : 0;
+    // two tiles per eight-wave workgroup (conv_f16x3's W2 form) for the 9-tile plain / per-phase layers: one weight stream for both,
+    // the CU's whole LDS (UMX_W2=0 keeps the four-wave form: the A/B of docs/experiments.md)
+    const bool w2 = f6 || (!fused && !L.d2s && !L.train && !out_f32 && nt16 == kMaxNT16 && !h.pk && !getenv("UMX_DEBUG_STAMPS") &&
+                           !(getenv("UMX_W2") && atoi(getenv("UMX_W2")) == 0));
+    h.w2 = w2 ? 1 : 0;
     if (f6)
         if (const char* e = getenv("UMX_F6_ABLATE")) h.f6 |= (atoi(e) & 3) << 1;   // timing-only: wrong results (conv_f16x3, f6step)
     h.outH = L.outH; h.outW = L.outW; h.pool = L.pool; h.act = L.act;
@@ -196,7 +201,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     // slots over one pair of weight buffers, and has its CU's whole LDS)
     auto wbuf_of = [&](int ss) { return 64 + nt16 * (f6 ? 4096 : ss * 2048); };
     auto lds_total = [&](int nslots, int oc, int ss, int plane_pair_bytes) {
-        return (f6 ? 2 : 1) * nslots * oc * plane_pair_bytes + 2 * wbuf_of(ss);
+        return (w2 ? 2 : 1) * nslots * oc * plane_pair_bytes + 2 * wbuf_of(ss);
     };
 
     // One stage list (= one kernel phase, or the whole fused transposed convolution) for a given (OC, S, slot base E):
@@ -271,7 +276,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     double bestCost = 1e30;
     for (size_t at = 0; at < attempts.size() && !bestOC; ++at) {
     maxp = attempts[at].maxp;
-    const int lds_cap = f6 ? 160 * 1024 - 512 : attempts[at].cap;
+    const int lds_cap = w2 ? 160 * 1024 - 512 : attempts[at].cap;
     for (int OC = 1; OC <= 9; ++OC) {
         int nslots = 1;
         double sectors = 0;   // 64-byte memory requests of the halo loads of one workgroup
@@ -339,12 +344,16 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     h.piece_bytes = h.nact * 16;
     h.inv_oc_q16 = 65536 / OC + 1;
     h.pix_bytes = OC * 16;
+    // 16-byte LDS slot of (halo pixel, octet k of the chunk) in halo slot `hs`
+    auto lds_slot = [&](int hs, int pixel, int k) {
+        return hs * (h.plane_slots * OC) + pixel * OC + k;
+    };
     h.slot_bytes = h.plane_slots * OC * 16;
     h.lo_off = bestSlots * h.slot_bytes;
     h.b_off = 2 * h.lo_off;
     h.wbuf_bytes = wbuf_of(S);
     h.xcd_order = 1;   // XCD-aware tile order (run_launch_f16 turns it into order 2 where its rule says so)
-    h.lds_bytes = (f6 ? 2 : 1) * h.b_off + 2 * h.wbuf_bytes;
+    h.lds_bytes = (w2 ? 2 : 1) * h.b_off + 2 * h.wbuf_bytes;
 
     std::vector<HStage> stages;
     std::vector<std::vector<_Float16>> wimg(nlists);   // per stage list: [nblk][stage blocks] halves
@@ -429,7 +438,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                     for (int qq = 0; qq < 4; ++qq) {
                         const Pair& pr2 = steps[ks][qq];
                         const auto& tp = L.g[pr2.gi].taps[pr2.ph][pr2.tap < 0 ? 0 : pr2.tap];
-                        hdr[4 + qq] = (unsigned short)(pr2.slot * (h.plane_slots * OC) + ((tp.first - g.ymin) * h.hw + (tp.second - g.xmin)) * OC + pr2.k);
+                        hdr[4 + qq] = (unsigned short)lds_slot(pr2.slot, (tp.first - g.ymin) * h.hw + (tp.second - g.xmin), pr2.k);
                     }
                 }
                 for (int j = 0; j < nk_st; ++j, ++ks) {
@@ -437,7 +446,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                         const Pair& pr2 = steps[ks][qq];
                         const auto& tp = L.g[pr2.gi].taps[pr2.ph][pr2.tap < 0 ? 0 : pr2.tap];
                         // 16-byte LDS slot of (halo pixel at this tap, octet k) in the pixel-major image of halo slot `slot`
-                        const int slot = pr2.slot * (h.plane_slots * OC) + ((tp.first - g.ymin) * h.hw + (tp.second - g.xmin)) * OC + pr2.k;
+                        const int slot = lds_slot(pr2.slot, (tp.first - g.ymin) * h.hw + (tp.second - g.xmin), pr2.k);
                         if (slot < 0 || slot >= bestSlots * h.plane_slots * OC || slot > 65535) { bad_slot = true; return; }
                         hdr[j * 4 + qq] = (unsigned short)slot;
                     }
@@ -600,7 +609,7 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     }
     if (getenv("UMX_DEBUG_PLAN"))
         fprintf(stderr, "[umx plan] %-12s %sNT %d x %d blocks, OC %d x %d halo slot(s), S %d, LDS %d B, k-steps %d, wshift %d\n",
-                L.name.c_str(), fused ? (h.pk ? "fused-phase packed " : "fused-phase ") : (h.pk ? "packed " : h.f6 ? "fp6-cross " : ""), nt16, h.nblocks, OC, bestSlots, S, h.lds_bytes, L.n_ksteps,
+                L.name.c_str(), fused ? (h.pk ? "fused-phase packed " : "fused-phase ") : (h.pk ? "packed " : h.f6 ? "fp6-cross " : h.w2 ? "two-tile " : ""), nt16, h.nblocks, OC, bestSlots, S, h.lds_bytes, L.n_ksteps,
                 L.wshift);
     h.inv_imgplane = 1.f / (float)h.imgplane;
     h.inv_hw = 1.f / (float)h.hw;
