@@ -295,6 +295,8 @@ UMX_API int umx_prof_entry_size(void);
 /* Host-side helpers exported for the CPU test-suite (no GPU needed): the double->float16 round-to-nearest-even
  * used by the fp16-compat stitch, and the library's view of a model (layer count, packed weight bytes, FLOPs). */
 UMX_API void umx_test_double_to_half(const double* in, uint16_t* out, size_t n);
+/* the same conversion by the DEVICE routine the stitch kernel uses (needs a GPU): must equal the host routine bit for bit */
+UMX_API int umx_test_double_to_half_dev(const double* in, uint16_t* out, size_t n);
 UMX_API int umx_describe(const umx_hparams* hp, int* n_launches, double* flops_per_tile, double* executed_flops_per_tile);
 /* The library's wiring of a model as JSON text (host only): activation buffers (spatial size, channels), the launch list in
  * execution order -- per launch its operand groups (source buffer, channels, filter taps: concat order = group order), output

@@ -170,3 +170,27 @@ def test_raw_gather_equals_the_float64_image_path(dtype, reference):
         first = (np.float16(255) * pl).astype(np.uint8)
         want = (255.0 * (first.astype(np.float64) * (1.0 / 255))).astype(np.uint8)
         assert np.array_equal(got, want)
+
+
+def test_the_stitch_kernels_double_to_half_equals_the_host_statement():
+    """stitch_kernel converts with d2h_rne (round-to-odd binary32, then v_cvt_f16_f32); the unit test of the conversion only
+    exercised the host routine.  Same directed vectors through the device routine: ties at every binade, half subnormals, values of the
+    form 2^-25 (1 +- eps), the overflow boundary, signed zeros -- bit for bit the host routine's (and numpy's) rounding."""
+    import numpy as np
+    from unmicst_amd import umx
+    rng = np.random.default_rng(0)
+    eps = 2.0 ** -40
+    vals = np.concatenate([
+        rng.normal(size=100000), rng.normal(size=100000) * 1e-5, rng.normal(size=50000) * 1e-7, rng.uniform(0, 4, 100000),
+        rng.normal(size=1000) * 7e4,
+        np.array([0.0, -0.0, 1.0, 65504.0, 65519.99, 65520.0, 1e6, np.inf, -np.inf, 2.0 ** -24, 2.0 ** -25, 2.0 ** -25 * (1 + eps),
+                  2.0 ** -25 * (1 - eps), -2.0 ** -25 * (1 + eps), 3 * 2.0 ** -25, 3 * 2.0 ** -25 * (1 - eps), 2.0 ** -14,
+                  2.0 ** -14 * (1 - 2.0 ** -12), 1 + 2.0 ** -11, 1 + 2.0 ** -11 + eps, 1 + 2.0 ** -11 - eps, 1 + 3 * 2.0 ** -11, 0.1, 1 / 3]),
+        (np.arange(1024, 2048)[None, :] + 0.5).ravel() * 2.0 ** -10,                                   # exact ties, normal range
+        (np.arange(0, 1024)[None, :] + 0.5).ravel() * 2.0 ** -24,                                      # exact ties among the subnormals
+        ((np.arange(0, 1024)[None, :] + 0.5) * 2.0 ** -24).ravel() * (1 + eps)])                       # ... and just above them
+    host = umx.double_to_half(vals)
+    dev = umx.double_to_half_dev(vals)
+    assert np.array_equal(dev.view(np.uint16), host.view(np.uint16))
+    with np.errstate(over="ignore"):
+        assert np.array_equal(dev.view(np.uint16), vals.astype(np.float16).view(np.uint16))

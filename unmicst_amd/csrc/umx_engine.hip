@@ -393,6 +393,24 @@ void umx_test_double_to_half(const double* in, uint16_t* out, size_t n) {
     for (size_t i = 0; i < n; ++i) out[i] = double_to_half_rne(in[i]);
 }
 
+// the DEVICE routine the stitch kernel converts with (d2h_rne: round-to-odd binary32, then v_cvt_f16_f32) on the same vectors: the
+// host routine above states the conversion, this one is what runs
+int umx_test_double_to_half_dev(const double* in, uint16_t* out, size_t n) {
+    if (!in || !out) return fail(nullptr, UMX_ERR_INVALID, "in / out is NULL");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, UMX_ERR_NO_DEVICE, "no HIP device available");
+    double* din = nullptr;
+    uint16_t* dout = nullptr;
+    HIP_TRY(nullptr, hipMalloc((void**)&din, n * sizeof(double) + 16));
+    if (hipMalloc((void**)&dout, n * sizeof(uint16_t) + 16) != hipSuccess) { hipFree(din); return fail(nullptr, UMX_ERR_OOM, "hipMalloc failed"); }
+    hipError_t e = hipMemcpy(din, in, n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_d2h_rne_test(din, dout, n, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out, dout, n * sizeof(uint16_t), hipMemcpyDeviceToHost);
+    hipFree(din);
+    hipFree(dout);
+    return e == hipSuccess ? UMX_OK : fail(nullptr, UMX_ERR_HIP, "umx_test_double_to_half_dev: %s", hipGetErrorString(e));
+}
+
 int umx_describe(const umx_hparams* hp, int* n_launches, double* flops_per_tile, double* executed_flops_per_tile) {
     std::string why;
     int rc = check_hp(hp, &why);

@@ -56,6 +56,7 @@ constexpr double kBnEpsilon = 0.001;  // tf.layers.batch_normalization's default
 constexpr int kModeReplace = 1;   // == UMX_MODE_REPLACE
 
 size_t conv_lds_bytes(int nt, int plane);
+hipError_t launch_d2h_rne_test(const double* in, uint16_t* out, size_t n, hipStream_t stream);   // (test entry: the stitch kernel's double -> binary16)
 hipError_t launch_conv(const ConvParams& p, int nt, int hpix, hipStream_t stream);
 
 // ---- split-precision (3 x fp16 MFMA) convolution, umx_conv_f16.hip --------------------------------------------

@@ -475,6 +475,17 @@ __device__ __forceinline__ uint16_t d2h_rne(double d) {
     return __half_as_ushort(__float2half_rn(f));
 }
 
+// test entry (umx_test_double_to_half_dev): the device routine on caller-given doubles, against the host statement of the conversion
+__global__ void d2h_rne_test_kernel(const double* __restrict__ in, uint16_t* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = d2h_rne(in[i]);
+}
+hipError_t launch_d2h_rne_test(const double* in, uint16_t* out, size_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(d2h_rne_test_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, in, out, n);
+    return hipGetLastError();
+}
+
 // the drivers' uint8 cast of one float16 probability (reference UnMicst1-5.py:848-854 at the identity grid; the same IEEE operations
 // as half_to_u8_kernel below, one rounding each): np.uint8(255 * pm) in float16, resize = u8 * (1 / 255) in float64, np.uint8(255 * .)
 __device__ __forceinline__ unsigned char u8_of_half(__half pm) {

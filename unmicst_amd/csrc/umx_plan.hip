@@ -113,10 +113,11 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     const bool f6 = ctx->f6 && !fused && !L.d2s && !L.train && !out_f32 && nt16 == kMaxNT16 && !h.pk && L.H * 4 <= ctx->hp.imSize &&
                     !getenv("UMX_DEBUG_STAMPS");
     h.f6 = f6 ? 1 : 0;
-    // two tiles per eight-wave workgroup (conv_f16x3's W2 form) for the 9-tile plain / per-phase layers: one weight stream for both,
-    // the CU's whole LDS (UMX_W2=0 keeps the four-wave form: the A/B of docs/experiments.md)
-    const bool w2 = f6 || (!fused && !L.d2s && !L.train && !out_f32 && nt16 == kMaxNT16 && !h.pk && !getenv("UMX_DEBUG_STAMPS") &&
-                           !(getenv("UMX_W2") && atoi(getenv("UMX_W2")) == 0));
+    // two tiles per eight-wave workgroup (conv_f16x3's W2 form): the F6 form runs on it.  For the 3-product kernel alone it measured 4 %
+    // SLOWER (docs/experiments.md, round 6: two independent four-wave workgroups per CU de-phase and cover each other's stage waits; one
+    // eight-wave workgroup runs its waves in lock-step) -- UMX_W2=1 selects it there for that A/B
+    const bool w2 = f6 || (getenv("UMX_W2") && atoi(getenv("UMX_W2")) == 1 && !fused && !L.d2s && !L.train && !out_f32 && nt16 == kMaxNT16 &&
+                           !h.pk && !getenv("UMX_DEBUG_STAMPS"));
     h.w2 = w2 ? 1 : 0;
     if (f6)
         if (const char* e = getenv("UMX_F6_ABLATE")) h.f6 |= (atoi(e) & 3) << 1;   // timing-only: wrong results (conv_f16x3, f6step)

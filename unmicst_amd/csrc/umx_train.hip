@@ -1413,7 +1413,7 @@ int umx_trainer_loss(umx_trainer* tr, double* loss3) {
     if (flag || tr->range_pending) {   // sticky: raised by any step since the last report; reported once, then cleared
         flag = 1;
         tr->range_pending = false;
-        T_HIP(tr, hipMemset(tr->d_maxw + tr->n_maxw, 0, sizeof(unsigned)));
+        T_HIP(tr, hipMemsetAsync(tr->d_maxw + tr->n_maxw, 0, sizeof(unsigned), tr->stream));   // (in the order of the work that can raise the flag)
     }
     if (flag)
         return tfail(tr, UMX_ERR_RANGE, "an operand of a split-precision convolution or weight gradient left the binary16 range "
@@ -1454,7 +1454,7 @@ int umx_trainer_eval(umx_trainer* tr, const float* data, float* probs_host) {
     T_HIP(tr, hipStreamSynchronize(tr->stream));
     if (before) {
         tr->range_pending = true;
-        T_HIP(tr, hipMemset(tr->d_maxw + tr->n_maxw, 0, sizeof(unsigned)));
+        T_HIP(tr, hipMemsetAsync(tr->d_maxw + tr->n_maxw, 0, sizeof(unsigned), tr->stream));   // (in the order of the work that can raise the flag)
     }
     T_HIP(tr, hipMemcpyAsync(own, data, npx * tr->n[0] * sizeof(float), hipMemcpyHostToDevice, tr->stream));
     T_TRY(pack_all(tr, tr->stream, 0));
@@ -1466,7 +1466,7 @@ int umx_trainer_eval(umx_trainer* tr, const float* data, float* probs_host) {
     T_HIP(tr, hipMemcpyAsync(&flag, tr->d_maxw + tr->n_maxw, sizeof flag, hipMemcpyDeviceToHost, tr->stream));
     T_HIP(tr, hipStreamSynchronize(tr->stream));
     if (flag) {
-        T_HIP(tr, hipMemset(tr->d_maxw + tr->n_maxw, 0, sizeof(unsigned)));
+        T_HIP(tr, hipMemsetAsync(tr->d_maxw + tr->n_maxw, 0, sizeof(unsigned), tr->stream));   // (in the order of the work that can raise the flag)
         return tfail(tr, UMX_ERR_RANGE, "an operand of the split-precision forward pass of umx_trainer_eval left the binary16 range (|v| >= 6e4 or "
                                         "not finite): the probabilities are not valid; UMX_TRAIN_CONV_F32=1 selects the exact-fp32 kernels");
     }

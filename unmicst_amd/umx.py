@@ -29,7 +29,7 @@ EXPORTS = [
     "umx_infer_image_raw", "umx_infer_image_raw_range", "umx_plane_range", "umx_infer_image_raw_scaled", "umx_infer_image_raw_outlier", "umx_infer_image_raw_submit", "umx_infer_image_wait", "umx_tiff_lzw_decode",
     "umx_tiff_packbits_decode", "umx_shard_unique_id", "umx_shard_init", "umx_shard_init_transport", "umx_shard_fini", "umx_shard_plan",
     "umx_infer_image_sharded_dev", "umx_infer_image_sharded_raw", "umx_infer_image_sharded_raw_submit",
-    "umx_band_tiles_dev", "umx_stitch_dev", "umx_profile_enable", "umx_profile_read", "umx_prof_entry_size", "umx_test_double_to_half",
+    "umx_band_tiles_dev", "umx_stitch_dev", "umx_profile_enable", "umx_profile_read", "umx_prof_entry_size", "umx_test_double_to_half", "umx_test_double_to_half_dev",
     "umx_describe", "umx_describe_graph", "umx_plan_check", "umx_version",
 ]
 
@@ -323,6 +323,19 @@ def double_to_half(x: np.ndarray) -> np.ndarray:
     x = np.ascontiguousarray(x, np.float64)
     out = np.empty(x.shape, np.uint16)
     load().umx_test_double_to_half(x.ctypes.data, out.ctypes.data, x.size)
+    return out.view(np.float16)
+
+
+def double_to_half_dev(x: np.ndarray) -> np.ndarray:
+    """umx_test_double_to_half_dev: the DEVICE routine of the stitch kernel (needs a GPU)."""
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.empty(x.shape, np.uint16)
+    L = load()
+    L.umx_test_double_to_half_dev.restype = ctypes.c_int
+    L.umx_test_double_to_half_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    rc = L.umx_test_double_to_half_dev(x.ctypes.data, out.ctypes.data, x.size)
+    if rc:
+        raise UmxError(rc, L.umx_last_error(None).decode())
     return out.view(np.float16)
 
 
