@@ -117,7 +117,7 @@ def pmc_traffic(kernel, precision, batch):
     this configuration is committed."""
     import csv
     path = None
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         cand = os.path.join(ROOT, "profiles", rnd, "final_%s_b%d_by_layer_pmc.csv" % (precision, batch))
         if os.path.exists(cand):
             path = cand
