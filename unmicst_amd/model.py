@@ -360,6 +360,11 @@ def load_model_dir(model_path: str, graph: int = None, synthetic_if_missing: boo
         graph = detect_graph(model_path, prefix)
     hp_dict = load_pickle(os.path.join(model_path, "hp.data"))
     if prefix != "model.ckpt":
+        import warnings
+        warnings.warn("%s: converting checkpoint %r, not the directory's model.ckpt -- the layer widths are read from that checkpoint, but "
+                      "imSize / batchSize (hp.data) and the normalisation scalars (datasetMean.data / datasetStDev.data) are the "
+                      "directory's and may belong to another training run: they cannot be verified against the weights that are loaded"
+                      % (model_path, prefix), RuntimeWarning, stacklevel=2)
         hp_dict = hp_dict_from_checkpoint(hp_dict, tfckpt.read_index(os.path.join(model_path, prefix + ".index")))
     hp = hparams_from_dict(hp_dict, graph)
     mean = float(load_pickle(os.path.join(model_path, "datasetMean.data")))
