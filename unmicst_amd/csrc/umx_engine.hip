@@ -158,8 +158,9 @@ int run_launch_f16(umx_ctx* ctx, Launch& L, const float* tiles, int n, int k0, i
     }
     char kn[64];
     // the instantiation as rocprofv3 names it (<NT, KMT, NPH>): bench.py groups the timed sites by kernel
-    snprintf(kn, sizeof kn, "conv_f16x3<%d, %d, %d, false, %d, %s, %s%s>", L.nt16, p.kmt, p.fused_phases ? 4 : 1, p.maxp, p.pk ? "true" : "false",
-             p.d2s ? "true" : "false", p.f6 ? ", true" : p.w2 ? ", false, true" : "");
+    // (<NT, KMT, NPH, DBG, MAXP, PK, D2S, F6, W2>)
+    snprintf(kn, sizeof kn, "conv_f16x3<%d, %d, %d, false, %d, %s, %s, %s, %s>", L.nt16, p.kmt, p.fused_phases ? 4 : 1, p.maxp, p.pk ? "true" : "false",
+             p.d2s ? "true" : "false", p.f6 ? "true" : "false", p.w2 ? "true" : "false");
     {
         // diagnostic: UMX_DEBUG_STAMPS=<layer name> prints the mean s_memtime segments of that layer's workgroups
         const char* const dbg_layer = getenv("UMX_DEBUG_STAMPS");
