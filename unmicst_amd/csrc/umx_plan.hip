@@ -120,7 +120,13 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
                            !h.pk && !getenv("UMX_DEBUG_STAMPS"));
     h.w2 = w2 ? 1 : 0;
     if (f6)
-        if (const char* e = getenv("UMX_F6_ABLATE")) h.f6 |= (atoi(e) & 3) << 1;   // timing-only: wrong results (conv_f16x3, f6step)
+        if (const char* e = getenv("UMX_F6_ABLATE"))
+            if (atoi(e) & 3) {   // timing-only ablations of docs/experiments.md (conv_f16x3, f6step): WRONG RESULTS, said so once per process
+                static std::atomic<bool> told{false};
+                if (!told.exchange(true))
+                    fprintf(stderr, "[umx] UMX_F6_ABLATE=%s: parts of the fp6 cross-term stage are switched off -- timing only, the results are WRONG\n", e);
+                h.f6 |= (atoi(e) & 3) << 1;
+            }
     h.outH = L.outH; h.outW = L.outW; h.pool = L.pool; h.act = L.act;
     if (h.nhalo > kHaloChunks * 64) { *why = "halo too large for the split-precision kernel"; return UMX_ERR_INVALID; }
     h.plane_slots = round_up(h.nhalo, 16);
