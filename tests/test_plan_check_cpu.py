@@ -41,3 +41,13 @@ def test_a_refusal_names_the_layer_and_the_reason():
     hp = model.HParams(model.GRAPH_LEGACY, 32, 1, 2, 13, 3, 7, 1)
     r = umx.plan_check(hp)
     assert r.startswith("lb.conv:") and "halo" in r
+
+
+def test_the_command_line_tool_reports_both_outcomes(tmp_path):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "plan_check.py"), "nucleiDAPI1-5", os.path.join(root, "models", "nucleiDAPI")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.count("split precision") == 2, r.stdout + r.stderr
