@@ -165,6 +165,15 @@ def roofline_of(prof, elapsed_s, eng, batch):
     all_ms = sum(p["total_ms"] for p in convs)
     all_ms_est = sum(k["ms_all"] for k in by_kernel.values())
     peak = PEAK_F16_MFMA_TFLOPS if eng.precision in ("f16x3", "f16f6") else PEAK_F32_MFMA_TFLOPS
+    # every instantiation that shares the dominant kernel's <N-tiles, M-tiles, phases> (since round 6 the long-K convolutions of the duo
+    # widths run the fp6 cross-term instantiation of the same 9-tile kernel: rocprofv3 lists it as a kernel of its own)
+    def first7(n):   # <NT, KMT, NPH, DBG, MAXP, PK, D2S | F6, W2>
+        return n[n.index("<") + 1:-1].split(", ")[:7] if n.startswith("conv_f16x3<") else [n]
+    fam_names = sorted(n for n in by_kernel if first7(n) == first7(dom_name))
+    fam = [by_kernel[n] for n in fam_names]
+    fam_ms, fam_fl, fam_all = sum(k["ms"] for k in fam), sum(k["flops"] for k in fam), sum(k["ms_all"] for k in fam)
+    same_template = {"kernels": fam_names, "achieved": round(fam_fl / (fam_ms * 1e-3) / 1e12, 2),
+                     "frac": round(fam_fl / (fam_ms * 1e-3) / 1e12 / peak, 4), "share_of_step": round(fam_all / (1e3 * elapsed_s), 4)}
     if eng.hp.graph == 0 and eng.precision != "f32":
         # the legacy graph's 16 - 64-channel layers are HBM / LDS-bound, not matrix-bound: its line is quoted on
         # the compulsory activation bytes of the dominant kernel's launches against 8 TB/s; the matrix fraction rides along
@@ -191,6 +200,7 @@ def roofline_of(prof, elapsed_s, eng, batch):
                         "frac": round(dom["exec"] / (dom["ms"] * 1e-3) / 1e12 / peak, 4)},
         "compulsory_hbm": {"GBps": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1),
                            "frac_of_8TBps": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
+        "same_template": same_template,
         "slowest_layer": {"layer": slow["name"], "kernel": slow["kernel"],
                           "achieved": round(slow["flops"] / (slow["total_ms"] * 1e-3) / 1e12, 2),
                           "frac": round(slow["flops"] / (slow["total_ms"] * 1e-3) / 1e12 / peak, 4),

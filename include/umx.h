@@ -38,18 +38,20 @@ enum umx_status {
     UMX_ERR_RANGE = 6        /* split-precision path only: an activation left the binary16 range (|v| >= 6e4) */
 };
 
-/* Arithmetic of the convolutions.  Both hold the 1e-4 tolerance on the probability maps.
+/* Arithmetic of the convolutions.  All hold the 1e-4 tolerance on the probability maps.
  *   UMX_PREC_F32    exact fp32 products on v_mfma_f32_16x16x4_f32 (bit-for-bit an fp32 fma chain).
  *   UMX_PREC_F16X3  every fp32 product as three binary16 MFMA products of a (hi, lo) split of both operands with fp32
- *                   accumulation (~2^-21 relative error per product; 16/3 of the fp32 matrix rate).  Default.
- *   UMX_PREC_DEFAULT  = UMX_PREC_F16X3 where its planner covers every layer of the graph, else UMX_PREC_F32 (layers of 2x2 /
- *                     4x4 pixels under 5x5 / 7x7 filters exceed the split kernel's LDS image); UMX_PRECISION=f32|f16x3 in the
- *                     environment pins it.  umx_precision_of() tells which one a ctx runs.
- *   UMX_PREC_F16X3_F6  UMX_PREC_F16X3 with the two CROSS terms (x_hi*w_lo + x_lo*w_hi, a 2^-11 correction) of the wide layers at
- *                     <= 1/4 of the input resolution on the block-scaled matrix instruction (OCP MX fp6 e2m3, 4 x the K per
- *                     instruction): half the matrix time on those layers.  Measured 2e-5 against the 1e-4 tolerance on the
- *                     reference's trained weights (tests/fp8_cross_term_report.py); every other layer as UMX_PREC_F16X3.
- *                     UMX_PRECISION=f16f6 selects it; umx_precision_of() reports it. */
+ *                   accumulation (~2^-21 relative error per product; 16/3 of the fp32 matrix rate).
+ *   UMX_PREC_F16X3_F6  UMX_PREC_F16X3 with the two CROSS terms (x_hi*w_lo + x_lo*w_hi, a 2^-11 correction) of the wide plain
+ *                   convolutions at <= 1/4 of the input resolution (>= 2 blocks of 144 output channels: the duo widths' ld3 / ld4 /
+ *                   lu3 / lu4 convolutions; no layer of the solo or legacy models) on the block-scaled matrix instruction (OCP MX fp6
+ *                   e2m3, 4 x the K per instruction): half the matrix time on those layers, 5 - 13 % of their run time.  1e-6 .. 3e-6
+ *                   on the GPU against the oracle, 2e-5 in emulation on the reference's trained weights
+ *                   (tests/fp8_cross_term_report.py); every other layer as UMX_PREC_F16X3.
+ *   UMX_PREC_DEFAULT  = UMX_PREC_F16X3_F6 where the split-precision planner covers every layer of the graph, else UMX_PREC_F32
+ *                   (layers of 4x4 pixels under 7x7 filters exceed the split kernels' halo image) -- said through
+ *                   umx_last_error(ctx); UMX_PRECISION=f32|f16x3|f16f6 in the environment pins it.  umx_precision_of() tells
+ *                   which one a ctx runs (UMX_PREC_F16X3 when no layer of the model takes the fp6 form). */
 enum umx_precision { UMX_PREC_DEFAULT = 0, UMX_PREC_F32 = 1, UMX_PREC_F16X3 = 2, UMX_PREC_F16X3_F6 = 3 };
 
 typedef struct umx_options {

@@ -147,7 +147,8 @@ def test_depth_to_space_transposed_convolution_shapes(shape):
         got = eng.forward_tiles(x)
         kernels = {e["name"]: e["kernel"] for e in eng.profile_read()}
     assert np.abs(got - want).max() <= TILE_TOL, shape
-    d2s = [n for n, k in kernels.items() if k.startswith("conv_f16x3") and k.endswith(", true>")]
+    # (conv_f16x3<NT, KMT, NPH, DBG, MAXP, PK, D2S, F6, W2>: the seventh template argument)
+    d2s = [n for n, k in kernels.items() if k.startswith("conv_f16x3<") and k[k.index("<") + 1:-1].split(", ")[6] == "true"]
     assert d2s and all("convT" in n for n in d2s), kernels
 
 

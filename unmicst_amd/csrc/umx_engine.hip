@@ -513,8 +513,11 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
         // default = split precision where its planner covers every layer, else the exact-fp32 MFMA kernels (tiny layers
         // under big filters exceed the LDS image of conv_f16x3).  Both are HIP paths; there is no CPU fallback.
         umx_options o2 = *opts;
-        o2.precision = UMX_PREC_F16X3;
+        o2.precision = UMX_PREC_F16X3_F6;   // (= UMX_PREC_F16X3 for every model without wide low-resolution layers)
         int rc = umx_create_opts(hp, weight_blob, blob_floats, &o2, out);
+        if (rc != UMX_ERR_INVALID) return rc;
+        o2.precision = UMX_PREC_F16X3;
+        rc = umx_create_opts(hp, weight_blob, blob_floats, &o2, out);
         if (rc != UMX_ERR_INVALID) return rc;
         const std::string first = g_err;
         o2.precision = UMX_PREC_F32;
@@ -529,7 +532,7 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
     int precision = opts->precision;
     if (precision == UMX_PREC_DEFAULT) {
         const char* e = getenv("UMX_PRECISION");
-        precision = (e && !strcmp(e, "f32")) ? UMX_PREC_F32 : (e && !strcmp(e, "f16f6")) ? UMX_PREC_F16X3_F6 : UMX_PREC_F16X3;
+        precision = (e && !strcmp(e, "f32")) ? UMX_PREC_F32 : (e && !strcmp(e, "f16x3")) ? UMX_PREC_F16X3 : UMX_PREC_F16X3_F6;
     }
     if (precision != UMX_PREC_F32 && precision != UMX_PREC_F16X3 && precision != UMX_PREC_F16X3_F6)
         return fail(nullptr, UMX_ERR_INVALID, "unknown precision %d", precision);
@@ -667,6 +670,7 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
             if ((rc = plan_first(c, L, act_shift, &why))) { c->err = L.name + ": " + why; return bail(rc); }
             L.hcp.zeros = c->d_zeros;
             L.hcp.overflow_flag = c->d_flag;
+            if (L.hcp.f6) c->f6_used = true;
             if (L.hcp.head_K > 0) {
                 c->head_fused = true;
                 const Launch& Hd = c->plan.back();
@@ -706,7 +710,7 @@ int umx_create_opts(const umx_hparams* hp, const float* weight_blob, size_t blob
     return UMX_OK;
 }
 
-int umx_precision_of(const umx_ctx* ctx) { return !ctx ? UMX_PREC_DEFAULT : ctx->f6 ? UMX_PREC_F16X3_F6 : ctx->precision; }
+int umx_precision_of(const umx_ctx* ctx) { return !ctx ? UMX_PREC_DEFAULT : ctx->f6_used ? UMX_PREC_F16X3_F6 : ctx->precision; }
 
 void umx_destroy(umx_ctx* ctx) {
     if (!ctx) return;

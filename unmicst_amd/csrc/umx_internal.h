@@ -174,6 +174,7 @@ struct umx_ctx {
     // precision
     int precision = UMX_PREC_F16X3;
     bool f6 = false;            // split precision with the cross terms of the deep layers on the block-scaled fp6 matrix instruction (UMX_PREC_F16X3_F6)
+    bool f6_used = false;       // ... and at least one layer of this model runs in that form (what umx_precision_of reports)
     int act_shift = 0;          // activations are stored times 2^act_shift in the (hi, lo) binary16 form
     float* d_tiles32 = nullptr; // fp32 staging of gathered tiles before the split (f16 path)
     int* d_flag = nullptr;      // binary16 range overflow flags (64 words): word 0 for the synchronous entry points, words 16 and

@@ -110,8 +110,14 @@ int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch*
     h.pk = (!L.d2s && !L.train && h.nblocks == 1 && nt16 >= 2 && nt16 <= 5 && last_real >= 1 && last_real <= 8 && !getenv("UMX_DEBUG_STAMPS")) ? 1 : 0;
     // fp6 cross terms (conv_f16x3's F6 form): the 9-tile plain / per-phase kernel on the layers at <= 1/4 of the input resolution --
     // where tests/fp8_cross_term_report.py holds 1e-4 with a 4 x margin on the reference's trained weights (the full-resolution layers do not)
+    // ... and, of those, the plain convolutions of >= 2 N-blocks on tiles of one image (>= 16 x 16 pixels): the per-phase transposed
+    // convolutions (1 - 4 taps: a handful of stages per workgroup) and the 8 x 8-pixel layers (four images per tile: a 400-pixel halo,
+    // chunks of one octet in the two-tile workgroup's LDS) measured 15 - 22 % SLOWER in the form, the single-N-block layers at 1/4
+    // resolution level (+0.3 ... +3 %), the long-K convolutions of 2 - 4 N-blocks 5 - 13 % faster (docs/experiments.md); UMX_F6_ALL=1
+    // takes every eligible layer (the A/B)
+    const bool f6_all = getenv("UMX_F6_ALL") && atoi(getenv("UMX_F6_ALL")) == 1;
     const bool f6 = ctx->f6 && !fused && !L.d2s && !L.train && !out_f32 && nt16 == kMaxNT16 && !h.pk && L.H * 4 <= ctx->hp.imSize &&
-                    !getenv("UMX_DEBUG_STAMPS");
+                    (f6_all || (L.nphase == 1 && g.imgs == 1 && h.nblocks >= 2)) && !getenv("UMX_DEBUG_STAMPS");
     h.f6 = f6 ? 1 : 0;
     // two tiles per eight-wave workgroup (conv_f16x3's W2 form): the F6 form runs on it.  For the 3-product kernel alone it measured 4 %
     // SLOWER (docs/experiments.md, round 6: two independent four-wave workgroups per CU de-phase and cover each other's stage waits; one
