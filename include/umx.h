@@ -307,6 +307,9 @@ UMX_API int umx_describe(const umx_hparams* hp, int* n_launches, double* flops_p
  * (UnMicst1-5.py:55-237; the op graph it saves: models/<name>/model.ckpt.meta).  Writes at most cap bytes (NUL-terminated) and
  * returns in *needed the bytes the whole text takes; UMX_ERR_INVALID if cap is too small. */
 UMX_API int umx_describe_graph(const umx_hparams* hp, char* json, size_t cap, size_t* needed);
+/* test entry (host): one OCP MX fp6 block as the planner packs the F6 form's weights -- 32 doubles in, 24 bytes out (element i in bits
+ * [6 i, 6 i + 6): e2m3, round-to-nearest-even, saturating at 7.5), returns the block's e8m0 scale byte (2^(floor(log2 max) - 2)) */
+UMX_API int umx_test_mx_pack_e2m3(const double* v32, uint8_t* out24);
 /* Host only (no device needed): would umx_create with UMX_PREC_F16X3 take this model?  UMX_OK, or UMX_ERR_INVALID with the first
  * refused layer and the split-precision planner's reason in umx_last_error(NULL) -- what UMX_PREC_DEFAULT falls back to the exact-fp32
  * engine on (and warns about). */

@@ -51,3 +51,37 @@ def test_the_command_line_tool_reports_both_outcomes(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "plan_check.py"), "nucleiDAPI1-5", os.path.join(root, "models", "nucleiDAPI")],
                        capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.count("split precision") == 2, r.stdout + r.stderr
+
+
+def test_the_planners_mx_fp6_packing_is_the_ocp_rule():
+    """The F6 form's weight images: blocks of 32 with one e8m0 scale 2^(floor(log2 max) - 2) and e2m3 elements (bias 1, subnormals in
+    steps of 1/8, largest 7.5), round-to-nearest-even, saturating, element i in bits [6 i, 6 i + 6) -- against a numpy statement of the
+    rule (the device side of the same format is probed on the GPU: tools/probes/mx_fp6_semantics.hip)."""
+    import ctypes
+    L = umx.load()
+    L.umx_test_mx_pack_e2m3.restype = ctypes.c_int
+    L.umx_test_mx_pack_e2m3.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    grid = np.array([m / 8 for m in range(8)] + [(1 + m / 8) * 2.0 ** (e - 1) for e in (1, 2, 3) for m in range(8)])   # the 32 magnitudes
+    rng = np.random.default_rng(0)
+    for trial in range(300):
+        scale = 2.0 ** rng.integers(-20, 12)
+        v = rng.normal(size=32) * scale * (rng.random(32) < 0.9) * 2.0 ** -rng.integers(0, 6, 32)
+        if trial == 0:
+            v[:] = 0.0
+        if trial == 1:
+            v = np.array([7.75, -7.75, 7.5, 7.25, 0.0625, 0.1875, 0.5625, 1.0625] + [0.0] * 24)     # saturation and exact ties
+        out = np.zeros(24, np.uint8)
+        vv = np.ascontiguousarray(v, np.float64)
+        e8 = L.umx_test_mx_pack_e2m3(vv.ctypes.data, out.ctypes.data)
+        amax = np.abs(v).max()
+        if amax == 0:
+            assert not out.any()
+            continue
+        want_e = int(np.floor(np.log2(amax))) - 2
+        assert e8 == want_e + 127
+        bits = np.unpackbits(out, bitorder="little")
+        codes = np.array([int(sum(int(bits[6 * i + b]) << b for b in range(6))) for i in range(32)])
+        a = np.minimum(np.abs(v) / 2.0 ** want_e, 7.5)
+        idx = np.array([min(range(32), key=lambda c: (abs(grid[c] - x), c & 1)) for x in a])   # nearest, ties to the even code
+        assert np.array_equal(codes & 31, idx), (trial, v, codes)
+        assert np.array_equal((codes >> 5)[idx > 0], (v < 0).astype(int)[idx > 0])

@@ -394,6 +394,17 @@ void umx_test_double_to_half(const double* in, uint16_t* out, size_t n) {
     for (size_t i = 0; i < n; ++i) out[i] = double_to_half_rne(in[i]);
 }
 
+// the planner's OCP MX fp6 packing of one block of 32 (what the F6 form's weight images are made of): 24 bytes + the e8m0 scale byte
+int umx_test_mx_pack_e2m3(const double* v32, uint8_t* out24) {
+    if (!v32 || !out24) return -1;
+    double v[32], amax = 0.0;
+    for (int i = 0; i < 32; ++i) { v[i] = v32[i]; amax = std::max(amax, std::fabs(v[i])); }
+    unsigned char b[24];
+    const int e8 = mx_pack_e2m3(v, amax, b);
+    memcpy(out24, b, 24);
+    return e8;
+}
+
 // the DEVICE routine the stitch kernel converts with (d2h_rne: round-to-odd binary32, then v_cvt_f16_f32) on the same vectors: the
 // host routine above states the conversion, this one is what runs
 int umx_test_double_to_half_dev(const double* in, uint16_t* out, size_t n) {

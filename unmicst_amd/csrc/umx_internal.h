@@ -219,6 +219,7 @@ int build_graph(const umx_hparams& hp, const float* blob, std::vector<Launch>* p
 bool conv_geometry(Launch& L, std::string* why);
 
 // ---- umx_plan.hip: split-precision plan of one launch
+int mx_pack_e2m3(const double (&v)[32], double amax, unsigned char (&out)[24]);   // umx_plan.hip: one OCP MX fp6 (e2m3) block of 32
 int plan_f16(umx_ctx* ctx, Launch& L, int act_shift, bool out_f32, const Launch* head, std::string* why, bool dry = false);
 // dense-K plan of the first down-sampling layer, for a launch plan_f16 has just planned (sets L.use_first when it applies)
 int plan_first(umx_ctx* ctx, Launch& L, int act_shift, std::string* why);

@@ -11,7 +11,7 @@ namespace umx {
 // ---- OCP MX fp6 (e2m3) block of 32: shared scale 2^(floor(log2 amax) - 2) as an e8m0 byte, elements round-to-nearest-even and saturating
 // at 7.5, element i in bits [6 i, 6 i + 6) of the 24 bytes (the order v_cvt_scalef32_pk32_fp6_f16 writes and the scaled MFMA reads:
 // tools/probes/mx_fp6_semantics.hip)
-static int mx_pack_e2m3(const double (&v)[32], double amax, unsigned char (&out)[24]) {
+int mx_pack_e2m3(const double (&v)[32], double amax, unsigned char (&out)[24]) {
     memset(out, 0, sizeof out);
     if (!(amax > 0.0) || !std::isfinite(amax)) return 127;
     int e2;

@@ -30,7 +30,7 @@ EXPORTS = [
     "umx_tiff_packbits_decode", "umx_shard_unique_id", "umx_shard_init", "umx_shard_init_transport", "umx_shard_fini", "umx_shard_plan",
     "umx_infer_image_sharded_dev", "umx_infer_image_sharded_raw", "umx_infer_image_sharded_raw_submit",
     "umx_band_tiles_dev", "umx_stitch_dev", "umx_profile_enable", "umx_profile_read", "umx_prof_entry_size", "umx_test_double_to_half", "umx_test_double_to_half_dev",
-    "umx_describe", "umx_describe_graph", "umx_plan_check", "umx_version",
+    "umx_describe", "umx_describe_graph", "umx_plan_check", "umx_test_mx_pack_e2m3", "umx_version",
 ]
 
 
